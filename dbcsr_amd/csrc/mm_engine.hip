@@ -1,0 +1,885 @@
+// mm_engine.hip -- device-resident local multiply (include/dbcsr_amd_mm.h).
+//
+// Symbolic phase (integer, HBM/L2-bound): block-level bitmaps.
+//   Bbm[k][w]  : bit j set iff B(k,j) present                 (bitmap_from_index)
+//   Cbm[i][w]  = Cin_bm[i][w] | OR_{k in A-row(i)} Bbm[k][w]  (c_bitmap)
+//   row prefix popcounts give, without any hashing, the sorted column index of
+//   C (what dbcsr_finalize produces, work/dbcsr_work_operations.F:749+) and the
+//   rank of any block inside its row (row_prefix).
+//   For every C block the list of products (a_off, b_off, k) is emitted in
+//   ascending k: deterministic, no atomics (count_products / fill_products).
+// This restates WHAT dbcsr_mm_csr_multiply_low computes (mm/dbcsr_mm_csr.F:
+// 257-357: which C blocks exist, which (A,B) pairs feed each) with a data-
+// parallel algorithm instead of its per-thread hash tables and 30000-entry
+// parameter stacks.
+//
+// Numeric phase (fp64/fp32 MFMA): one wavefront per C block, all products of
+// the block accumulated in registers, C written exactly once (no atomics, no
+// zero-fill pass, bitwise reproducible).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "../../include/dbcsr_amd_mm.h"
+#include "common.h"
+#include "smm_core.h"
+
+namespace dbcsr_amd {
+
+struct Entry {  // one block product feeding a C block
+  uint32_t a_off, b_off;  // element offsets into the A / B data areas
+  uint32_t ks;            // k extent of this product
+};
+
+struct Desc {  // one C block
+  int64_t c_off;       // element offset in C_out data
+  int64_t cin_off;     // element offset in C_in data, -1 if the block is new
+  int64_t prod_start;  // first Entry
+  int32_t prod_cnt;
+  int16_t m, n;
+};
+
+// ----------------------------------------------------------------------------
+// small utilities
+// ----------------------------------------------------------------------------
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t n) {
+    if (n <= cap) return 0;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = n + n / 8 + 64;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), want * sizeof(T));
+    if (e != hipSuccess) return check(e, "hipMalloc(workspace)", __FILE__, __LINE__);
+    cap = want;
+    return 0;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  // Workgroup b is dispatched to XCD b % 8 (MI355X_MICROARCH.md); give each XCD a
+  // contiguous range of C blocks so that the A block-row it works on stays in
+  // that XCD's L2.  Bijective for any nwg.  Speed only, never correctness.
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int q = nwg >> 3, r = nwg & 7;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+// ----------------------------------------------------------------------------
+// exclusive scan (int32 in -> TO out), three small kernels
+// ----------------------------------------------------------------------------
+constexpr int kScanThreads = 256;
+constexpr int kScanItems = 16;
+constexpr int kScanChunk = kScanThreads * kScanItems;
+
+__device__ __forceinline__ int64_t block_exclusive_scan(int64_t v, int64_t* total) {
+  __shared__ int64_t wsum[kScanThreads / 64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int64_t inc = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int64_t t = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += t;
+  }
+  if (lane == 63) wsum[w] = inc;
+  __syncthreads();
+  int64_t woff = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < kScanThreads / 64; ++i) {
+    if (i < w) woff += wsum[i];
+    tot += wsum[i];
+  }
+  __syncthreads();
+  *total = tot;
+  return woff + inc - v;
+}
+
+__global__ void __launch_bounds__(kScanThreads) scan_reduce(const int* __restrict__ in, int64_t n, int64_t* __restrict__ partial) {
+  const int64_t base = (int64_t)blockIdx.x * kScanChunk;
+  int64_t s = 0;
+  for (int it = 0; it < kScanItems; ++it) {
+    const int64_t i = base + (int64_t)it * kScanThreads + threadIdx.x;
+    if (i < n) s += in[i];
+  }
+  int64_t tot;
+  (void)block_exclusive_scan(s, &tot);
+  if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+__global__ void __launch_bounds__(kScanThreads) scan_partials(int64_t* __restrict__ partial, int np, int64_t* __restrict__ total_out) {
+  int64_t carry = 0;
+  for (int base = 0; base < np; base += kScanThreads) {
+    const int i = base + threadIdx.x;
+    const int64_t v = i < np ? partial[i] : 0;
+    int64_t tot;
+    const int64_t ex = block_exclusive_scan(v, &tot);
+    if (i < np) partial[i] = carry + ex;
+    carry += tot;
+  }
+  if (threadIdx.x == 0 && total_out) *total_out = carry;
+}
+
+template <typename TO>
+__global__ void __launch_bounds__(kScanThreads) scan_apply(const int* __restrict__ in, int64_t n, const int64_t* __restrict__ partial,
+                                                            TO* __restrict__ out, int write_total_at_n) {
+  const int64_t base = (int64_t)blockIdx.x * kScanChunk;
+  // thread t owns kScanItems consecutive items
+  const int64_t first = base + (int64_t)threadIdx.x * kScanItems;
+  int v[kScanItems];
+  int64_t s = 0;
+#pragma unroll
+  for (int it = 0; it < kScanItems; ++it) {
+    const int64_t i = first + it;
+    v[it] = i < n ? in[i] : 0;
+    s += v[it];
+  }
+  int64_t tot;
+  int64_t ex = block_exclusive_scan(s, &tot) + partial[blockIdx.x];
+#pragma unroll
+  for (int it = 0; it < kScanItems; ++it) {
+    const int64_t i = first + it;
+    if (i < n) out[i] = (TO)ex;
+    ex += v[it];
+    if (write_total_at_n && i == n - 1) out[n] = (TO)ex;
+  }
+}
+
+// ----------------------------------------------------------------------------
+// symbolic kernels
+// ----------------------------------------------------------------------------
+
+// one wavefront per block row: set bit (row, col) for every block
+__global__ void __launch_bounds__(256) bitmap_from_index(const int* __restrict__ row_p, const int* __restrict__ col_i, int nbr, int W,
+                                                         uint32_t* __restrict__ bm) {
+  const int lane = threadIdx.x & 63;
+  const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (row >= nbr) return;
+  for (int b = row_p[row] + lane; b < row_p[row + 1]; b += 64) {
+    const int j = col_i[b];
+    atomicOr(&bm[(size_t)row * W + (j >> 5)], 1u << (j & 31));
+  }
+}
+
+// thread per (row i, word w)
+__global__ void __launch_bounds__(256) c_bitmap(const int* __restrict__ a_row_p, const int* __restrict__ a_col_i,
+                                                const uint32_t* __restrict__ b_bm, const uint32_t* __restrict__ cin_bm, int nbr, int W,
+                                                int retain, uint32_t* __restrict__ c_bm) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (int64_t)nbr * W) return;
+  const int i = (int)(t / W), w = (int)(t % W);
+  uint32_t v = cin_bm ? cin_bm[t] : 0u;
+  if (!retain) {
+    for (int ab = a_row_p[i]; ab < a_row_p[i + 1]; ++ab) v |= b_bm[(size_t)a_col_i[ab] * W + w];
+  }
+  c_bm[t] = v;
+}
+
+// one wavefront per row: exclusive prefix of popcounts inside the row + row total
+__global__ void __launch_bounds__(256) row_prefix(const uint32_t* __restrict__ bm, int nbr, int W, int* __restrict__ pre,
+                                                  int* __restrict__ row_nnz) {
+  const int lane = threadIdx.x & 63;
+  const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (row >= nbr) return;
+  int carry = 0;
+  for (int base = 0; base < W; base += 64) {
+    const int w = base + lane;
+    const int c = w < W ? __popc(bm[(size_t)row * W + w]) : 0;
+    int inc = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int t = __shfl_up(inc, off, 64);
+      if (lane >= off) inc += t;
+    }
+    if (w < W) pre[(size_t)row * W + w] = carry + inc - c;
+    carry += __shfl(inc, 63, 64);
+  }
+  if (lane == 0 && row_nnz) row_nnz[row] = carry;
+}
+
+// thread per (row i, word w): per C block product count, block size, flop
+__global__ void __launch_bounds__(256) count_products(const int* __restrict__ a_row_p, const int* __restrict__ a_col_i,
+                                                      const int* __restrict__ rs, const int* __restrict__ ks, const int* __restrict__ cs,
+                                                      const uint32_t* __restrict__ b_bm, const uint32_t* __restrict__ c_bm,
+                                                      const int* __restrict__ c_pre, const int* __restrict__ c_row_p, int nbr, int W,
+                                                      int* __restrict__ prod_cnt, int* __restrict__ blk_nze,
+                                                      unsigned long long* __restrict__ flop_out) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long flop = 0;
+  if (t < (int64_t)nbr * W) {
+    const int i = (int)(t / W), w = (int)(t % W);
+    uint32_t v = c_bm[t];
+    if (v) {
+      const int m = rs[i];
+      int cb = c_row_p[i] + c_pre[t];
+      const int a0 = a_row_p[i], a1 = a_row_p[i + 1];
+      while (v) {
+        const int bit = __ffs(v) - 1;
+        v &= v - 1;
+        const int n = cs[32 * w + bit];
+        int cnt = 0;
+        long long ksum = 0;
+        for (int ab = a0; ab < a1; ++ab) {
+          const int k = a_col_i[ab];
+          if ((b_bm[(size_t)k * W + w] >> bit) & 1u) {
+            ++cnt;
+            ksum += ks[k];
+          }
+        }
+        prod_cnt[cb] = cnt;
+        blk_nze[cb] = m * n;
+        flop += 2ull * (unsigned long long)m * n * ksum;
+        ++cb;
+      }
+    }
+  }
+  // block reduce, one atomic per workgroup
+  __shared__ unsigned long long red[4];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) flop += __shfl_down(flop, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = flop;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long s = red[0] + red[1] + red[2] + red[3];
+    if (s) atomicAdd(flop_out, s);
+  }
+}
+
+// thread per (row i, word w): emit C index, descriptors and product lists
+__global__ void __launch_bounds__(256)
+fill_products(const int* __restrict__ a_row_p, const int* __restrict__ a_col_i, const int64_t* __restrict__ a_blk_p,
+              const int* __restrict__ b_row_p, const int64_t* __restrict__ b_blk_p, const int* __restrict__ cin_row_p,
+              const int64_t* __restrict__ cin_blk_p, const int* __restrict__ rs, const int* __restrict__ ks,
+              const int* __restrict__ cs, const uint32_t* __restrict__ b_bm, const int* __restrict__ b_pre,
+              const uint32_t* __restrict__ cin_bm, const int* __restrict__ cin_pre, const uint32_t* __restrict__ c_bm,
+              const int* __restrict__ c_pre, const int* __restrict__ c_row_p, const int64_t* __restrict__ prod_start,
+              const int64_t* __restrict__ c_blk_p_ws, int nbr, int W, int* __restrict__ c_col_i, int64_t* __restrict__ c_blk_p,
+              Desc* __restrict__ descs, Entry* __restrict__ entries) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (int64_t)nbr * W) return;
+  const int i = (int)(t / W), w = (int)(t % W);
+  uint32_t v = c_bm[t];
+  if (!v) return;
+  const int m = rs[i];
+  int cb = c_row_p[i] + c_pre[t];
+  const int a0 = a_row_p[i], a1 = a_row_p[i + 1];
+  const uint32_t cinw = cin_bm ? cin_bm[t] : 0u;
+  while (v) {
+    const int bit = __ffs(v) - 1;
+    v &= v - 1;
+    const uint32_t below = (1u << bit) - 1u;
+    const int j = 32 * w + bit;
+    int64_t p = prod_start[cb];
+    int cnt = 0;
+    for (int ab = a0; ab < a1; ++ab) {
+      const int k = a_col_i[ab];
+      const uint32_t bw = b_bm[(size_t)k * W + w];
+      if ((bw >> bit) & 1u) {
+        const int bidx = b_row_p[k] + b_pre[(size_t)k * W + w] + __popc(bw & below);
+        Entry e;
+        e.a_off = (uint32_t)a_blk_p[ab];
+        e.b_off = (uint32_t)b_blk_p[bidx];
+        e.ks = (uint32_t)ks[k];
+        entries[p + cnt] = e;
+        ++cnt;
+      }
+    }
+    Desc d;
+    d.c_off = c_blk_p_ws[cb];
+    d.cin_off = -1;
+    if ((cinw >> bit) & 1u) d.cin_off = cin_blk_p[cin_row_p[i] + cin_pre[t] + __popc(cinw & below)];
+    d.prod_start = p;
+    d.prod_cnt = cnt;
+    d.m = (int16_t)m;
+    d.n = (int16_t)cs[j];
+    descs[cb] = d;
+    c_col_i[cb] = j;
+    c_blk_p[cb] = d.c_off;
+    ++cb;
+  }
+}
+
+// ----------------------------------------------------------------------------
+// numeric kernels
+// ----------------------------------------------------------------------------
+template <int MA, int NC>
+__device__ __forceinline__ void cblock_f64(const Desc& d, const Entry* __restrict__ entries, const double* __restrict__ a_data,
+                                           const double* __restrict__ b_data, double* __restrict__ c_out,
+                                           const double* __restrict__ c_in, double alpha, double beta, const LaneMap& L, int row0,
+                                           int col0) {
+  double acc[MA][NC];
+#pragma unroll
+  for (int a = 0; a < MA; ++a)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[a][c] = 0.0;
+  const int m = d.m, n = d.n;
+  const Entry* e = entries + d.prod_start;
+  for (int p = 0; p < d.prod_cnt; ++p) {
+    const uint32_t ao = e[p].a_off, bo = e[p].b_off, kk = e[p].ks;
+    block_product_f64<MA, NC, false>(acc, a_data + ao, b_data + bo, m, n, (int)kk, L, row0, col0);
+  }
+  double* C = c_out + d.c_off;
+  const bool has_in = d.cin_off >= 0;
+  const double* Ci = c_in + (has_in ? d.cin_off : 0);
+#pragma unroll
+  for (int a = 0; a < MA; ++a)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int row = row0 + 8 * a + L.rowd, col = col0 + 8 * c + L.coll;
+      if (row < m && col < n) {
+        double v = alpha * acc[a][c];
+        if (has_in) v += beta * Ci[row + (size_t)m * col];
+        C[row + (size_t)m * col] = v;
+      }
+    }
+}
+
+__global__ void __launch_bounds__(256) mm_numeric_f64(const Desc* __restrict__ descs, int64_t nblk, const Entry* __restrict__ entries,
+                                                      const double* __restrict__ a_data, const double* __restrict__ b_data,
+                                                      double* __restrict__ c_out, const double* __restrict__ c_in, double alpha,
+                                                      double beta) {
+  const int lane = threadIdx.x & 63;
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int64_t cb = __builtin_amdgcn_readfirstlane(wg * 4 + (int)(threadIdx.x >> 6));
+  if (cb >= nblk) return;
+  const Desc d = descs[cb];
+  const LaneMap L(lane);
+  const int m = d.m, n = d.n;
+  if (m <= 32 && n <= 32) {
+    const int MA = (m + 7) >> 3, NC = (n + 7) >> 3;
+    switch (MA * 4 + NC) {
+#define DBCSR_CASE(A_, C_) \
+  case A_ * 4 + C_: cblock_f64<A_, C_>(d, entries, a_data, b_data, c_out, c_in, alpha, beta, L, 0, 0); break;
+      DBCSR_CASE(1, 1) DBCSR_CASE(1, 2) DBCSR_CASE(1, 3) DBCSR_CASE(1, 4)
+      DBCSR_CASE(2, 1) DBCSR_CASE(2, 2) DBCSR_CASE(2, 3) DBCSR_CASE(2, 4)
+      DBCSR_CASE(3, 1) DBCSR_CASE(3, 2) DBCSR_CASE(3, 3) DBCSR_CASE(3, 4)
+      DBCSR_CASE(4, 1) DBCSR_CASE(4, 2) DBCSR_CASE(4, 3) DBCSR_CASE(4, 4)
+#undef DBCSR_CASE
+      default: break;
+    }
+  } else {  // large blocks: 32 x 32 tiles, one after the other
+    for (int row0 = 0; row0 < m; row0 += 32)
+      for (int col0 = 0; col0 < n; col0 += 32) cblock_f64<4, 4>(d, entries, a_data, b_data, c_out, c_in, alpha, beta, L, row0, col0);
+  }
+}
+
+__global__ void __launch_bounds__(256) mm_numeric_f32(const Desc* __restrict__ descs, int64_t nblk, const Entry* __restrict__ entries,
+                                                      const float* __restrict__ a_data, const float* __restrict__ b_data,
+                                                      float* __restrict__ c_out, const float* __restrict__ c_in, float alpha,
+                                                      float beta) {
+  const int lane = threadIdx.x & 63;
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int64_t cb = __builtin_amdgcn_readfirstlane(wg * 4 + (int)(threadIdx.x >> 6));
+  if (cb >= nblk) return;
+  const Desc d = descs[cb];
+  const int m = d.m, n = d.n;
+  const Entry* e = entries + d.prod_start;
+  const bool has_in = d.cin_off >= 0;
+  for (int row0 = 0; row0 < m; row0 += 32)
+    for (int col0 = 0; col0 < n; col0 += 32) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+      for (int p = 0; p < d.prod_cnt; ++p)
+        block_product_f32<false>(acc, a_data + e[p].a_off, b_data + e[p].b_off, m, n, (int)e[p].ks, lane, row0, col0);
+      float* C = c_out + d.c_off;
+      const float* Ci = c_in + (has_in ? d.cin_off : 0);
+      const int col = col0 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < m && col < n) {
+          float v = alpha * acc[r];
+          if (has_in) v += beta * Ci[row + (size_t)m * col];
+          C[row + (size_t)m * col] = v;
+        }
+      }
+    }
+}
+
+// ----------------------------------------------------------------------------
+// auxiliary kernels: checksum, random fill, transpose
+// ----------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) checksum_blocks(const int* __restrict__ row_p, const int* __restrict__ col_i,
+                                                       const int64_t* __restrict__ blk_p, const T* __restrict__ data,
+                                                       const int* __restrict__ rs, const int* __restrict__ cs,
+                                                       const int64_t* __restrict__ roff, const int64_t* __restrict__ coff, int nbr,
+                                                       double* __restrict__ row_sums) {
+  // one wavefront per block row; fixed summation order -> reproducible
+  const int lane = threadIdx.x & 63;
+  const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (row >= nbr) return;
+  const int m = rs[row];
+  double s2 = 0.0, sp = 0.0;
+  for (int b = row_p[row]; b < row_p[row + 1]; ++b) {
+    const int c = col_i[b];
+    const int n = cs[c];
+    const T* d = data + blk_p[b];
+    for (int e = lane; e < m * n; e += 64) {
+      const double x = (double)d[e];
+      const int r = e % m, cc = e / m;
+      s2 += x * x;
+      sp += x * log(fabs((double)(roff[row] + r + 1) * (double)(coff[c] + cc + 1)));
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    s2 += __shfl_down(s2, off, 64);
+    sp += __shfl_down(sp, off, 64);
+  }
+  if (lane == 0) {
+    row_sums[2 * row] = s2;
+    row_sums[2 * row + 1] = sp;
+  }
+}
+
+__global__ void __launch_bounds__(256) checksum_final(const double* __restrict__ row_sums, int nbr, double* __restrict__ out2) {
+  __shared__ double r2[256], rp[256];
+  double s2 = 0.0, sp = 0.0;
+  for (int i = threadIdx.x; i < nbr; i += 256) {
+    s2 += row_sums[2 * i];
+    sp += row_sums[2 * i + 1];
+  }
+  r2[threadIdx.x] = s2;
+  rp[threadIdx.x] = sp;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) {
+      r2[threadIdx.x] += r2[threadIdx.x + off];
+      rp[threadIdx.x] += rp[threadIdx.x + off];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out2[0] = r2[0];
+    out2[1] = rp[0];
+  }
+}
+
+// LAPACK xLARUV stream: x_i = seed * a^i mod 2^48 (a = 33952834046453); see
+// oracle/dbcsr_oracle.c for the statement of the published algorithm.
+__device__ __forceinline__ uint64_t larnv_block_seed(int irow, int nrow, int icol, int ival) {
+  // set_larnv_seed, src/utils/dbcsr_blas_operations.F:29-52 (irow/icol 1-based)
+  long long ivm = ((long long)ival) % 65536;
+  if (ivm < 0) ivm += 65536;
+  long long map = (((long long)irow - 1 + (long long)icol * (long long)nrow) * (1 + ivm)) * 2 + 1;
+  const uint64_t s4 = (uint64_t)(map % 4096);
+  map /= 4096;
+  const uint64_t s3 = (uint64_t)((map ^ 3541) % 4096);
+  map /= 4096;
+  const uint64_t s2 = (uint64_t)((map ^ 1153) % 4096);
+  map /= 4096;
+  const uint64_t s1 = (uint64_t)((map ^ 2029) % 4096);
+  return (s1 << 36) | (s2 << 24) | (s3 << 12) | s4;
+}
+
+__device__ __forceinline__ uint64_t pow48(uint64_t base, uint64_t e) {
+  const uint64_t mask = (1ull << 48) - 1;
+  uint64_t r = 1;
+  base &= mask;
+  while (e) {
+    if (e & 1) r = (r * base) & mask;
+    base = (base * base) & mask;
+    e >>= 1;
+  }
+  return r;
+}
+
+__global__ void __launch_bounds__(256) fill_random_f64(const int* __restrict__ row_p, const int* __restrict__ col_i,
+                                                       const int64_t* __restrict__ blk_p, double* __restrict__ data,
+                                                       const int* __restrict__ rs, const int* __restrict__ cs, int nbr, int nbc,
+                                                       int counter) {
+  // one wavefront per block row, lanes over the elements of each block
+  const int lane = threadIdx.x & 63;
+  const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (row >= nbr) return;
+  (void)nbc;
+  const uint64_t mask = (1ull << 48) - 1, A = 33952834046453ull;
+  const uint64_t a64 = pow48(A, 64);
+  for (int b = row_p[row]; b < row_p[row + 1]; ++b) {
+    const int c = col_i[b];
+    const int ne = rs[row] * cs[c];
+    const uint64_t seed = larnv_block_seed(row + 1, nbr, c + 1, counter);
+    uint64_t x = (seed * pow48(A, (uint64_t)lane + 1)) & mask;
+    double* d = data + blk_p[b];
+    for (int e = lane; e < ne; e += 64) {
+      d[e] = (double)x * (1.0 / 281474976710656.0);
+      x = (x * a64) & mask;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) fill_random_f32(const int* __restrict__ row_p, const int* __restrict__ col_i,
+                                                       const int64_t* __restrict__ blk_p, float* __restrict__ data,
+                                                       const int* __restrict__ rs, const int* __restrict__ cs, int nbr, int nbc,
+                                                       int counter) {
+  // slarnv draws in chunks of 64 and, inside a chunk, a value that rounds to 1.0f
+  // bumps the chunk's base seed (LAPACK slaruv) -- so one thread walks one block.
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  (void)nbc;
+  const int row = (int)t;  // thread per block row is too coarse; use thread per block below
+  (void)row;
+  // thread per block: find row by binary search in row_p
+  const int64_t nblks = row_p[nbr];
+  if (t >= nblks) return;
+  int lo = 0, hi = nbr;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (row_p[mid] <= t) lo = mid; else hi = mid;
+  }
+  const int r = lo, c = col_i[t];
+  const int ne = rs[r] * cs[c];
+  const uint64_t mask = (1ull << 48) - 1, A = 33952834046453ull;
+  uint64_t seed = larnv_block_seed(r + 1, nbr, c + 1, counter);
+  float* d = data + blk_p[t];
+  const float rr = 1.0f / 4096.0f;
+  for (int done = 0; done < ne; done += 64) {
+    const int il = (ne - done) < 64 ? (ne - done) : 64;
+    // limbs of the chunk's base seed (may exceed 4095 after a bump)
+    long long i1 = (long long)((seed >> 36) & 4095), i2 = (long long)((seed >> 24) & 4095), i3 = (long long)((seed >> 12) & 4095),
+              i4 = (long long)(seed & 4095);
+    uint64_t apow = 1, last = 0;
+    for (int i = 0; i < il; ++i) {
+      apow = (apow * A) & mask;
+      for (;;) {
+        const uint64_t full = ((uint64_t)i1 << 36) + ((uint64_t)i2 << 24) + ((uint64_t)i3 << 12) + (uint64_t)i4;
+        const uint64_t p = (full * apow) & mask;
+        const float v = rr * ((float)((p >> 36) & 4095) + rr * ((float)((p >> 24) & 4095) + rr * ((float)((p >> 12) & 4095) + rr * (float)(p & 4095))));
+        if (v == 1.0f) {
+          i1 += 2; i2 += 2; i3 += 2; i4 += 2;
+          continue;
+        }
+        d[done + i] = v;
+        last = p;
+        break;
+      }
+    }
+    seed = last;
+  }
+}
+
+// transpose: dst block (c, r) <- src block (r, c)^T
+template <typename T>
+__global__ void __launch_bounds__(256)
+transpose_fill(const int* __restrict__ s_row_p, const int* __restrict__ s_col_i, const int64_t* __restrict__ s_blk_p,
+               const T* __restrict__ s_data, const int* __restrict__ s_rs, const int* __restrict__ s_cs, const uint32_t* __restrict__ t_bm,
+               const int* __restrict__ t_pre, const int* __restrict__ t_row_p, const int64_t* __restrict__ t_blk_p_ws, int s_nbr, int Wt,
+               int* __restrict__ t_col_i, int64_t* __restrict__ t_blk_p, T* __restrict__ t_data) {
+  // one wavefront per source block row
+  const int lane = threadIdx.x & 63;
+  const int r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (r >= s_nbr) return;
+  const int m = s_rs[r];
+  for (int b = s_row_p[r]; b < s_row_p[r + 1]; ++b) {
+    const int c = s_col_i[b];
+    const int n = s_cs[c];
+    // position of (c, r) in the transposed index
+    const uint32_t wv = t_bm[(size_t)c * Wt + (r >> 5)];
+    const int tb = t_row_p[c] + t_pre[(size_t)c * Wt + (r >> 5)] + __popc(wv & ((1u << (r & 31)) - 1u));
+    const int64_t toff = t_blk_p_ws[tb];
+    if (lane == 0) {
+      t_col_i[tb] = r;
+      t_blk_p[tb] = toff;
+    }
+    const T* src = s_data + s_blk_p[b];
+    T* dst = t_data + toff;
+    for (int e = lane; e < m * n; e += 64) {
+      const int i = e % m, j = e / m;  // src(i, j) -> dst(j, i), dst is n x m
+      dst[j + (size_t)n * i] = src[e];
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) transpose_mark(const int* __restrict__ s_row_p, const int* __restrict__ s_col_i, int s_nbr, int Wt,
+                                                      uint32_t* __restrict__ t_bm) {
+  const int lane = threadIdx.x & 63;
+  const int r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (r >= s_nbr) return;
+  for (int b = s_row_p[r] + lane; b < s_row_p[r + 1]; b += 64) atomicOr(&t_bm[(size_t)s_col_i[b] * Wt + (r >> 5)], 1u << (r & 31));
+}
+
+// thread per (row c of the transposed matrix, word w): block sizes in index order
+__global__ void __launch_bounds__(256) transpose_sizes(const uint32_t* __restrict__ t_bm, const int* __restrict__ t_pre,
+                                                       const int* __restrict__ t_row_p, const int* __restrict__ s_rs,
+                                                       const int* __restrict__ s_cs, int t_nbr, int Wt, int* __restrict__ blk_nze) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (int64_t)t_nbr * Wt) return;
+  const int c = (int)(t / Wt), w = (int)(t % Wt);
+  uint32_t v = t_bm[t];
+  int tb = t_row_p[c] + t_pre[t];
+  while (v) {
+    const int bit = __ffs(v) - 1;
+    v &= v - 1;
+    blk_nze[tb++] = s_cs[c] * s_rs[32 * w + bit];
+  }
+}
+
+// ----------------------------------------------------------------------------
+// host side
+// ----------------------------------------------------------------------------
+struct Engine {
+  DevBuf<uint32_t> b_bm, c_bm, cin_bm;
+  DevBuf<int> b_pre, c_pre, cin_pre, row_nnz, prod_cnt, blk_nze, tmp_i32;
+  DevBuf<int64_t> prod_start, c_blk_p_ws, partial, off_a, off_b;
+  DevBuf<Entry> entries;
+  DevBuf<Desc> descs;
+  DevBuf<double> row_sums;
+  DevBuf<unsigned long long> dev_scalars;
+  int64_t* host_scalars = nullptr;  // pinned: [0]=c_nblks [1]=c_nze [2]=nproducts [3]=flop
+  // state carried from symbolic to numeric
+  int nbr = 0, W = 0;
+  int64_t c_nblks = 0, nproducts = 0;
+  bool have_cin = false, retain = false, valid = false;
+};
+
+template <typename TO>
+static int exclusive_scan(Engine* E, const int* in, int64_t n, TO* out, int64_t* total_dev, bool write_total_at_n, hipStream_t st) {
+  const int nb = (int)((n + kScanChunk - 1) / kScanChunk);
+  if (E->partial.ensure((size_t)(nb > 0 ? nb : 1))) return -1;
+  if (n <= 0) {
+    if (total_dev) ACC_CHECK(hipMemsetAsync(total_dev, 0, sizeof(int64_t), st));
+    if (write_total_at_n) ACC_CHECK(hipMemsetAsync(out, 0, sizeof(TO), st));
+    return 0;
+  }
+  hipLaunchKernelGGL(scan_reduce, dim3(nb), dim3(kScanThreads), 0, st, in, n, E->partial.p);
+  hipLaunchKernelGGL(scan_partials, dim3(1), dim3(kScanThreads), 0, st, E->partial.p, nb, total_dev);
+  hipLaunchKernelGGL((scan_apply<TO>), dim3(nb), dim3(kScanThreads), 0, st, in, n, E->partial.p, out, write_total_at_n ? 1 : 0);
+  return check(hipGetLastError(), "exclusive_scan", __FILE__, __LINE__);
+}
+
+static inline dim3 grid_for(int64_t nthreads) { return dim3((unsigned)((nthreads + 255) / 256)); }
+
+}  // namespace dbcsr_amd
+
+using namespace dbcsr_amd;
+
+extern "C" {
+
+int dbcsr_amd_mm_create(void** handle) {
+  if (!handle) return -1;
+  Engine* E = new (std::nothrow) Engine();
+  if (!E) return -1;
+  hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&E->host_scalars), 8 * sizeof(int64_t), hipHostMallocDefault);
+  if (e != hipSuccess) {
+    delete E;
+    return check(e, "hipHostMalloc", __FILE__, __LINE__);
+  }
+  *handle = E;
+  return 0;
+}
+
+int dbcsr_amd_mm_destroy(void* handle) {
+  if (!handle) return 0;
+  Engine* E = static_cast<Engine*>(handle);
+  E->b_bm.release(); E->c_bm.release(); E->cin_bm.release();
+  E->b_pre.release(); E->c_pre.release(); E->cin_pre.release(); E->row_nnz.release(); E->prod_cnt.release();
+  E->blk_nze.release(); E->tmp_i32.release();
+  E->prod_start.release(); E->c_blk_p_ws.release(); E->partial.release(); E->off_a.release(); E->off_b.release();
+  E->entries.release(); E->descs.release(); E->row_sums.release(); E->dev_scalars.release();
+  if (E->host_scalars) (void)hipHostFree(E->host_scalars);
+  delete E;
+  return 0;
+}
+
+int dbcsr_amd_mm_symbolic(void* handle, const dbcsr_amd_bcsr* a, const dbcsr_amd_bcsr* b, const dbcsr_amd_bcsr* c_in,
+                          int retain_sparsity, int32_t* c_out_row_p, dbcsr_amd_mm_counts* counts, void* stream) {
+  Engine* E = static_cast<Engine*>(handle);
+  if (!E || !a || !b || !c_in || !c_out_row_p || !counts) return -1;
+  if (a->nblkcols != b->nblkrows || a->nblkrows != c_in->nblkrows || b->nblkcols != c_in->nblkcols) {
+    fprintf(stderr, "dbcsr_amd_mm_symbolic: incompatible block dimensions\n");
+    return -2;
+  }
+  hipStream_t st = stream_of(stream);
+  const int nbr = a->nblkrows, nbk = a->nblkcols, nbc = b->nblkcols;
+  const int W = (nbc + 31) / 32;
+  E->valid = false;
+  E->nbr = nbr;
+  E->W = W;
+  E->retain = retain_sparsity != 0;
+  E->have_cin = c_in->nblks > 0;
+  if (E->b_bm.ensure((size_t)nbk * W + 1) || E->b_pre.ensure((size_t)nbk * W + 1) || E->c_bm.ensure((size_t)nbr * W + 1) ||
+      E->c_pre.ensure((size_t)nbr * W + 1) || E->row_nnz.ensure((size_t)nbr + 1) || E->dev_scalars.ensure(8))
+    return -1;
+  if (E->have_cin && (E->cin_bm.ensure((size_t)nbr * W + 1) || E->cin_pre.ensure((size_t)nbr * W + 1))) return -1;
+  ACC_CHECK(hipMemsetAsync(E->dev_scalars.p, 0, 8 * sizeof(unsigned long long), st));
+  if (nbr == 0 || nbc == 0) {
+    ACC_CHECK(hipMemsetAsync(c_out_row_p, 0, sizeof(int32_t) * ((size_t)nbr + 1), st));
+    ACC_CHECK(hipStreamSynchronize(st));
+    counts->c_nblks = counts->c_nze = counts->nproducts = counts->flop = 0;
+    E->c_nblks = 0;
+    E->nproducts = 0;
+    E->valid = true;
+    return 0;
+  }
+  // 1. bitmaps of B (and C_in)
+  ACC_CHECK(hipMemsetAsync(E->b_bm.p, 0, sizeof(uint32_t) * (size_t)nbk * W, st));
+  if (nbk > 0) {
+    hipLaunchKernelGGL(bitmap_from_index, grid_for((int64_t)nbk * 64), dim3(256), 0, st, b->row_p, b->col_i, nbk, W, E->b_bm.p);
+    hipLaunchKernelGGL(row_prefix, grid_for((int64_t)nbk * 64), dim3(256), 0, st, E->b_bm.p, nbk, W, E->b_pre.p, (int*)nullptr);
+  }
+  if (E->have_cin) {
+    ACC_CHECK(hipMemsetAsync(E->cin_bm.p, 0, sizeof(uint32_t) * (size_t)nbr * W, st));
+    hipLaunchKernelGGL(bitmap_from_index, grid_for((int64_t)nbr * 64), dim3(256), 0, st, c_in->row_p, c_in->col_i, nbr, W,
+                       E->cin_bm.p);
+    hipLaunchKernelGGL(row_prefix, grid_for((int64_t)nbr * 64), dim3(256), 0, st, E->cin_bm.p, nbr, W, E->cin_pre.p, (int*)nullptr);
+  }
+  // 2. pattern of C_out, its row prefix and row pointer
+  hipLaunchKernelGGL(c_bitmap, grid_for((int64_t)nbr * W), dim3(256), 0, st, a->row_p, a->col_i, E->b_bm.p,
+                     E->have_cin ? E->cin_bm.p : (const uint32_t*)nullptr, nbr, W, retain_sparsity ? 1 : 0, E->c_bm.p);
+  hipLaunchKernelGGL(row_prefix, grid_for((int64_t)nbr * 64), dim3(256), 0, st, E->c_bm.p, nbr, W, E->c_pre.p, E->row_nnz.p);
+  int64_t* dsc = reinterpret_cast<int64_t*>(E->dev_scalars.p);
+  if (exclusive_scan<int32_t>(E, E->row_nnz.p, nbr, c_out_row_p, dsc + 0, true, st)) return -1;
+  // need c_nblks on the host to size per-block work arrays
+  ACC_CHECK(hipMemcpyAsync(E->host_scalars, dsc, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+  ACC_CHECK(hipStreamSynchronize(st));
+  const int64_t c_nblks = E->host_scalars[0];
+  if (E->prod_cnt.ensure((size_t)c_nblks + 1) || E->blk_nze.ensure((size_t)c_nblks + 1) || E->prod_start.ensure((size_t)c_nblks + 1) ||
+      E->c_blk_p_ws.ensure((size_t)c_nblks + 1))
+    return -1;
+  // 3. per C block: number of products, size; flop
+  hipLaunchKernelGGL(count_products, grid_for((int64_t)nbr * W), dim3(256), 0, st, a->row_p, a->col_i, a->row_blk_size,
+                     a->col_blk_size, b->col_blk_size, E->b_bm.p, E->c_bm.p, E->c_pre.p, c_out_row_p, nbr, W, E->prod_cnt.p,
+                     E->blk_nze.p, E->dev_scalars.p + 3);
+  if (exclusive_scan<int64_t>(E, E->prod_cnt.p, c_nblks, E->prod_start.p, dsc + 2, false, st)) return -1;
+  if (exclusive_scan<int64_t>(E, E->blk_nze.p, c_nblks, E->c_blk_p_ws.p, dsc + 1, false, st)) return -1;
+  ACC_CHECK(hipMemcpyAsync(E->host_scalars, dsc, 4 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+  ACC_CHECK(hipStreamSynchronize(st));
+  counts->c_nblks = E->host_scalars[0];
+  counts->c_nze = E->host_scalars[1];
+  counts->nproducts = E->host_scalars[2];
+  counts->flop = E->host_scalars[3];
+  E->c_nblks = counts->c_nblks;
+  E->nproducts = counts->nproducts;
+  E->valid = true;
+  return check(hipGetLastError(), "dbcsr_amd_mm_symbolic", __FILE__, __LINE__);
+}
+
+int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha, const dbcsr_amd_bcsr* a, const dbcsr_amd_bcsr* b,
+                         double beta, const dbcsr_amd_bcsr* c_in, dbcsr_amd_bcsr* c_out, void* stream) {
+  Engine* E = static_cast<Engine*>(handle);
+  if (!E || !E->valid || !a || !b || !c_in || !c_out) {
+    fprintf(stderr, "dbcsr_amd_mm_numeric: no valid symbolic phase for this handle\n");
+    return -1;
+  }
+  if (datatype != dbcsr_type_real_8 && datatype != dbcsr_type_real_4) return -10;
+  hipStream_t st = stream_of(stream);
+  const int nbr = E->nbr, W = E->W;
+  const int64_t nblk = E->c_nblks;
+  if (nblk == 0) return 0;
+  if (E->entries.ensure((size_t)E->nproducts + 1) || E->descs.ensure((size_t)nblk + 1)) return -1;
+  hipLaunchKernelGGL(fill_products, grid_for((int64_t)nbr * W), dim3(256), 0, st, a->row_p, a->col_i, a->blk_p, b->row_p, b->blk_p,
+                     c_in->row_p, c_in->blk_p, a->row_blk_size, a->col_blk_size, b->col_blk_size, E->b_bm.p, E->b_pre.p,
+                     E->have_cin ? E->cin_bm.p : (const uint32_t*)nullptr, E->have_cin ? E->cin_pre.p : (const int*)nullptr,
+                     E->c_bm.p, E->c_pre.p, c_out->row_p, E->prod_start.p, E->c_blk_p_ws.p, nbr, W, c_out->col_i, c_out->blk_p,
+                     E->descs.p, E->entries.p);
+  const unsigned nwg = (unsigned)((nblk + 3) / 4);
+  if (datatype == dbcsr_type_real_8) {
+    hipLaunchKernelGGL(mm_numeric_f64, dim3(nwg), dim3(256), 0, st, E->descs.p, nblk, E->entries.p,
+                       static_cast<const double*>(a->data), static_cast<const double*>(b->data), static_cast<double*>(c_out->data),
+                       static_cast<const double*>(c_in->data), alpha, beta);
+  } else {
+    hipLaunchKernelGGL(mm_numeric_f32, dim3(nwg), dim3(256), 0, st, E->descs.p, nblk, E->entries.p,
+                       static_cast<const float*>(a->data), static_cast<const float*>(b->data), static_cast<float*>(c_out->data),
+                       static_cast<const float*>(c_in->data), (float)alpha, (float)beta);
+  }
+  c_out->nblks = nblk;
+  return check(hipGetLastError(), "dbcsr_amd_mm_numeric", __FILE__, __LINE__);
+}
+
+static int element_offsets(Engine* E, const int* sizes, int n, DevBuf<int64_t>& off, hipStream_t st) {
+  if (off.ensure((size_t)n + 1)) return -1;
+  return exclusive_scan<int64_t>(E, sizes, n, off.p, nullptr, false, st);
+}
+
+int dbcsr_amd_bcsr_checksum(void* handle, libsmm_acc_data_t datatype, const dbcsr_amd_bcsr* m, double* out2, void* stream) {
+  Engine* E = static_cast<Engine*>(handle);
+  if (!E || !m || !out2) return -1;
+  hipStream_t st = stream_of(stream);
+  const int nbr = m->nblkrows;
+  out2[0] = out2[1] = 0.0;
+  if (nbr == 0 || m->nblks == 0) return 0;
+  if (E->row_sums.ensure((size_t)2 * nbr + 2)) return -1;
+  if (element_offsets(E, m->row_blk_size, nbr, E->off_a, st)) return -1;
+  if (element_offsets(E, m->col_blk_size, m->nblkcols, E->off_b, st)) return -1;
+  if (datatype == dbcsr_type_real_8)
+    hipLaunchKernelGGL((checksum_blocks<double>), grid_for((int64_t)nbr * 64), dim3(256), 0, st, m->row_p, m->col_i, m->blk_p,
+                       static_cast<const double*>(m->data), m->row_blk_size, m->col_blk_size, E->off_a.p, E->off_b.p, nbr,
+                       E->row_sums.p);
+  else if (datatype == dbcsr_type_real_4)
+    hipLaunchKernelGGL((checksum_blocks<float>), grid_for((int64_t)nbr * 64), dim3(256), 0, st, m->row_p, m->col_i, m->blk_p,
+                       static_cast<const float*>(m->data), m->row_blk_size, m->col_blk_size, E->off_a.p, E->off_b.p, nbr,
+                       E->row_sums.p);
+  else
+    return -10;
+  hipLaunchKernelGGL(checksum_final, dim3(1), dim3(256), 0, st, E->row_sums.p, nbr, E->row_sums.p + 2 * (size_t)nbr);
+  ACC_CHECK(hipMemcpyAsync(E->host_scalars + 4, E->row_sums.p + 2 * (size_t)nbr, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+  ACC_CHECK(hipStreamSynchronize(st));
+  memcpy(out2, E->host_scalars + 4, 2 * sizeof(double));
+  return 0;
+}
+
+int dbcsr_amd_bcsr_fill_random(void* handle, libsmm_acc_data_t datatype, const dbcsr_amd_bcsr* m, int counter, void* stream) {
+  if (!handle || !m) return -1;
+  hipStream_t st = stream_of(stream);
+  if (m->nblks == 0) return 0;
+  if (datatype == dbcsr_type_real_8)
+    hipLaunchKernelGGL(fill_random_f64, grid_for((int64_t)m->nblkrows * 64), dim3(256), 0, st, m->row_p, m->col_i, m->blk_p,
+                       static_cast<double*>(m->data), m->row_blk_size, m->col_blk_size, m->nblkrows, m->nblkcols, counter);
+  else if (datatype == dbcsr_type_real_4)
+    hipLaunchKernelGGL(fill_random_f32, grid_for(m->nblks), dim3(256), 0, st, m->row_p, m->col_i, m->blk_p,
+                       static_cast<float*>(m->data), m->row_blk_size, m->col_blk_size, m->nblkrows, m->nblkcols, counter);
+  else
+    return -10;
+  return check(hipGetLastError(), "dbcsr_amd_bcsr_fill_random", __FILE__, __LINE__);
+}
+
+int dbcsr_amd_bcsr_transpose(void* handle, libsmm_acc_data_t datatype, const dbcsr_amd_bcsr* src, dbcsr_amd_bcsr* dst, void* stream) {
+  Engine* E = static_cast<Engine*>(handle);
+  if (!E || !src || !dst) return -1;
+  if (datatype != dbcsr_type_real_8 && datatype != dbcsr_type_real_4) return -10;
+  hipStream_t st = stream_of(stream);
+  const int s_nbr = src->nblkrows, t_nbr = src->nblkcols;
+  const int Wt = (s_nbr + 31) / 32;
+  E->valid = false;  // shares workspace with the symbolic phase
+  if (E->c_bm.ensure((size_t)t_nbr * Wt + 1) || E->c_pre.ensure((size_t)t_nbr * Wt + 1) || E->row_nnz.ensure((size_t)t_nbr + 1) ||
+      E->blk_nze.ensure((size_t)src->nblks + 1) || E->c_blk_p_ws.ensure((size_t)src->nblks + 1))
+    return -1;
+  if (t_nbr == 0) return 0;
+  ACC_CHECK(hipMemsetAsync(E->c_bm.p, 0, sizeof(uint32_t) * (size_t)t_nbr * Wt, st));
+  if (s_nbr > 0) hipLaunchKernelGGL(transpose_mark, grid_for((int64_t)s_nbr * 64), dim3(256), 0, st, src->row_p, src->col_i, s_nbr, Wt, E->c_bm.p);
+  hipLaunchKernelGGL(row_prefix, grid_for((int64_t)t_nbr * 64), dim3(256), 0, st, E->c_bm.p, t_nbr, Wt, E->c_pre.p, E->row_nnz.p);
+  if (exclusive_scan<int32_t>(E, E->row_nnz.p, t_nbr, dst->row_p, nullptr, true, st)) return -1;
+  if (src->nblks > 0) {
+    hipLaunchKernelGGL(transpose_sizes, grid_for((int64_t)t_nbr * Wt), dim3(256), 0, st, E->c_bm.p, E->c_pre.p, dst->row_p,
+                       src->row_blk_size, src->col_blk_size, t_nbr, Wt, E->blk_nze.p);
+    if (exclusive_scan<int64_t>(E, E->blk_nze.p, src->nblks, E->c_blk_p_ws.p, nullptr, false, st)) return -1;
+    if (datatype == dbcsr_type_real_8)
+      hipLaunchKernelGGL((transpose_fill<double>), grid_for((int64_t)s_nbr * 64), dim3(256), 0, st, src->row_p, src->col_i, src->blk_p,
+                         static_cast<const double*>(src->data), src->row_blk_size, src->col_blk_size, E->c_bm.p, E->c_pre.p, dst->row_p,
+                         E->c_blk_p_ws.p, s_nbr, Wt, dst->col_i, dst->blk_p, static_cast<double*>(dst->data));
+    else
+      hipLaunchKernelGGL((transpose_fill<float>), grid_for((int64_t)s_nbr * 64), dim3(256), 0, st, src->row_p, src->col_i, src->blk_p,
+                         static_cast<const float*>(src->data), src->row_blk_size, src->col_blk_size, E->c_bm.p, E->c_pre.p, dst->row_p,
+                         E->c_blk_p_ws.p, s_nbr, Wt, dst->col_i, dst->blk_p, static_cast<float*>(dst->data));
+  }
+  dst->nblks = src->nblks;
+  return check(hipGetLastError(), "dbcsr_amd_bcsr_transpose", __FILE__, __LINE__);
+}
+
+const char* dbcsr_amd_mm_kernel_name(libsmm_acc_data_t datatype) {
+  return datatype == dbcsr_type_real_4 ? "mm_numeric_f32" : "mm_numeric_f64";
+}
+
+}  // extern "C"

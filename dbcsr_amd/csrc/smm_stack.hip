@@ -1,0 +1,251 @@
+// smm_stack.hip -- libsmm_acc_process / libsmm_acc_transpose / c_calculate_norms
+// of the DBCSR accelerator C-ABI (include/dbcsr_acc_libsmm.h) as hand-written
+// gfx950 kernels.  Replaces /root/reference/src/acc/libsmm_acc/libsmm_acc.cpp
+// (run-time JIT of five templated CUDA/HIP kernels) and
+// src/acc/cuda_hip/calculate_norms.cpp.
+//
+// Stack kernel: one wavefront per group of consecutive stack entries.  The host
+// (src/mm/dbcsr_mm_accdrv.F:481-486) sorts a stack by C offset, so a wave keeps
+// the C block in MFMA accumulators across a run of equal c and adds it to
+// memory once per run with hardware fp64/fp32 atomics (runs may straddle
+// waves, and several host threads' stacks never share C blocks).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+
+#include "../../include/dbcsr_acc_libsmm.h"
+#include "common.h"
+#include "smm_core.h"
+
+namespace dbcsr_amd {
+
+constexpr int kStackGroup = 16;  // stack entries per wavefront
+
+template <int MA, int NC, bool BT>
+__global__ void __launch_bounds__(256) smm_stack_f64(const int* __restrict__ stack, int nstack, const double* __restrict__ a_data,
+                                                     const double* __restrict__ b_data, double* __restrict__ c_data, int m,
+                                                     int n, int k) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+  const int row0 = blockIdx.y * (8 * MA), col0 = blockIdx.z * (8 * NC);
+  const int first = wave * kStackGroup;
+  if (first >= nstack) return;
+  const int last = min(first + kStackGroup, nstack);
+  const LaneMap L(lane);
+  double acc[MA][NC];
+#pragma unroll
+  for (int a = 0; a < MA; ++a)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[a][c] = 0.0;
+  int cur_c = __builtin_amdgcn_readfirstlane(stack[3 * first + 2]);
+  for (int s = first; s <= last; ++s) {
+    int ao = 0, bo = 0, co = -1;
+    if (s < last) {
+      ao = __builtin_amdgcn_readfirstlane(stack[3 * s]);
+      bo = __builtin_amdgcn_readfirstlane(stack[3 * s + 1]);
+      co = __builtin_amdgcn_readfirstlane(stack[3 * s + 2]);
+    }
+    if (co != cur_c) {  // end of a run of equal C offsets: C += acc (1-based offsets)
+      double* C = c_data + (cur_c - 1);
+#pragma unroll
+      for (int a = 0; a < MA; ++a)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          const int row = row0 + 8 * a + L.rowd, col = col0 + 8 * c + L.coll;
+          if (row < m && col < n) unsafeAtomicAdd(C + row + (size_t)m * col, acc[a][c]);
+          acc[a][c] = 0.0;
+        }
+      cur_c = co;
+    }
+    if (s < last) block_product_f64<MA, NC, BT>(acc, a_data + (ao - 1), b_data + (bo - 1), m, n, k, L, row0, col0);
+  }
+}
+
+template <bool BT>
+__global__ void __launch_bounds__(256) smm_stack_f32(const int* __restrict__ stack, int nstack, const float* __restrict__ a_data,
+                                                     const float* __restrict__ b_data, float* __restrict__ c_data, int m, int n,
+                                                     int k) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+  const int row0 = blockIdx.y * 32, col0 = blockIdx.z * 32;
+  const int first = wave * kStackGroup;
+  if (first >= nstack) return;
+  const int last = min(first + kStackGroup, nstack);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  int cur_c = __builtin_amdgcn_readfirstlane(stack[3 * first + 2]);
+  for (int s = first; s <= last; ++s) {
+    int ao = 0, bo = 0, co = -1;
+    if (s < last) {
+      ao = __builtin_amdgcn_readfirstlane(stack[3 * s]);
+      bo = __builtin_amdgcn_readfirstlane(stack[3 * s + 1]);
+      co = __builtin_amdgcn_readfirstlane(stack[3 * s + 2]);
+    }
+    if (co != cur_c) {
+      float* C = c_data + (cur_c - 1);
+      const int col = col0 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < m && col < n) unsafeAtomicAdd(C + row + (size_t)m * col, acc[r]);
+        acc[r] = 0.0f;
+      }
+      cur_c = co;
+    }
+    if (s < last) block_product_f32<BT>(acc, a_data + (ao - 1), b_data + (bo - 1), m, n, k, lane, row0, col0);
+  }
+}
+
+// In-place transpose of listed m x n column-major blocks (-> n x m column-major).
+// One workgroup per block, the block staged in LDS.
+__global__ void __launch_bounds__(256) transpose_blocks_f64(const int* __restrict__ trs_stack, double* __restrict__ data, int m,
+                                                            int n) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* buf = reinterpret_cast<double*>(smem);
+  double* blk = data + trs_stack[blockIdx.x];
+  const int mn = m * n;
+  for (int i = threadIdx.x; i < mn; i += blockDim.x) buf[i] = blk[i];
+  __syncthreads();
+  for (int i = threadIdx.x; i < mn; i += blockDim.x) {
+    const int r = i % n, c = i / n;  // element (r, c) of the n x m result = element (c, r) of the source
+    blk[i] = buf[r * m + c];
+  }
+}
+
+// norms[b] = sum_j mat[offsets[b] + j]^2 ; one wavefront per block.
+__global__ void __launch_bounds__(256) block_norms_f64(const double* __restrict__ mat, int nblks, const int* __restrict__ offsets,
+                                                       const int* __restrict__ nelems, float* __restrict__ norms) {
+  const int lane = threadIdx.x & 63;
+  const int b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (b >= nblks) return;
+  const double* p = mat + offsets[b];
+  const int ne = nelems[b];
+  double s = 0.0;
+  for (int i = lane; i < ne; i += 64) s += p[i] * p[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if (lane == 0) norms[b] = (float)s;
+}
+
+template <int MA, int NC>
+static int launch_f64(bool bt, dim3 grid, hipStream_t st, const int* stack, int nstack, const double* a, const double* b, double* c,
+                      int m, int n, int k) {
+  if (bt)
+    hipLaunchKernelGGL((smm_stack_f64<MA, NC, true>), grid, dim3(256), 0, st, stack, nstack, a, b, c, m, n, k);
+  else
+    hipLaunchKernelGGL((smm_stack_f64<MA, NC, false>), grid, dim3(256), 0, st, stack, nstack, a, b, c, m, n, k);
+  return dbcsr_amd::check(hipGetLastError(), "smm_stack_f64 launch", __FILE__, __LINE__);
+}
+
+template <int MA>
+static int launch_f64_nc(int NC, bool bt, dim3 grid, hipStream_t st, const int* stack, int nstack, const double* a,
+                         const double* b, double* c, int m, int n, int k) {
+  switch (NC) {
+    case 1: return launch_f64<MA, 1>(bt, grid, st, stack, nstack, a, b, c, m, n, k);
+    case 2: return launch_f64<MA, 2>(bt, grid, st, stack, nstack, a, b, c, m, n, k);
+    case 3: return launch_f64<MA, 3>(bt, grid, st, stack, nstack, a, b, c, m, n, k);
+    default: return launch_f64<MA, 4>(bt, grid, st, stack, nstack, a, b, c, m, n, k);
+  }
+}
+
+int process_stack_f64(const int* dev_stack, int nstack, const double* a, const double* b, double* c, int m, int n, int k, bool bt,
+                      hipStream_t st) {
+  if (nstack <= 0) return 0;
+  if (m <= 0 || n <= 0 || k <= 0) return 0;
+  // C tile per wave: up to 32 x 32; larger blocks are tiled over grid.y/z
+  const int MA = m >= 32 ? 4 : (m + 7) / 8, NC = n >= 32 ? 4 : (n + 7) / 8;
+  const int tiles_r = (m + 8 * MA - 1) / (8 * MA), tiles_c = (n + 8 * NC - 1) / (8 * NC);
+  const int nwaves = (nstack + kStackGroup - 1) / kStackGroup;
+  dim3 grid((nwaves + 3) / 4, tiles_r, tiles_c);
+  switch (MA) {
+    case 1: return launch_f64_nc<1>(NC, bt, grid, st, dev_stack, nstack, a, b, c, m, n, k);
+    case 2: return launch_f64_nc<2>(NC, bt, grid, st, dev_stack, nstack, a, b, c, m, n, k);
+    case 3: return launch_f64_nc<3>(NC, bt, grid, st, dev_stack, nstack, a, b, c, m, n, k);
+    default: return launch_f64_nc<4>(NC, bt, grid, st, dev_stack, nstack, a, b, c, m, n, k);
+  }
+}
+
+int process_stack_f32(const int* dev_stack, int nstack, const float* a, const float* b, float* c, int m, int n, int k, bool bt,
+                      hipStream_t st) {
+  if (nstack <= 0) return 0;
+  if (m <= 0 || n <= 0 || k <= 0) return 0;
+  const int nwaves = (nstack + kStackGroup - 1) / kStackGroup;
+  dim3 grid((nwaves + 3) / 4, (m + 31) / 32, (n + 31) / 32);
+  if (bt)
+    hipLaunchKernelGGL((smm_stack_f32<true>), grid, dim3(256), 0, st, dev_stack, nstack, a, b, c, m, n, k);
+  else
+    hipLaunchKernelGGL((smm_stack_f32<false>), grid, dim3(256), 0, st, dev_stack, nstack, a, b, c, m, n, k);
+  return dbcsr_amd::check(hipGetLastError(), "smm_stack_f32 launch", __FILE__, __LINE__);
+}
+
+}  // namespace dbcsr_amd
+
+using namespace dbcsr_amd;
+
+extern "C" {
+
+int libsmm_acc_init(void) {
+  // libsmm_acc_init.cpp:60-73 checks the wavefront width; gfx950 is 64-wide.
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;  // no device: nothing to initialise (the host decides what to do)
+  }
+  hipDeviceProp_t prop;
+  ACC_CHECK(hipGetDeviceProperties(&prop, dev));
+  if (prop.warpSize != 64) {
+    fprintf(stderr, "dbcsr_acc_amd: wavefront size %d != 64 (this library targets gfx950 only)\n", prop.warpSize);
+    return -1;
+  }
+  return 0;
+}
+
+int libsmm_acc_finalize(void) { return 0; }
+
+// All entry points are re-entrant (no shared mutable state): every OpenMP
+// thread of the host may call with its own streams (core/dbcsr_lib.F:248-262).
+c_dbcsr_acc_bool_t libsmm_acc_is_thread_safe(void) { return 1; }
+
+int libsmm_acc_gpu_warp_size(void) { return 64; }
+
+int libsmm_acc_transpose(const int* dev_trs_stack, int offset, int stack_size, void* dev_data, libsmm_acc_data_t datatype, int m,
+                         int n, int max_kernel_dim, void* stream) {
+  if (datatype != dbcsr_type_real_8) return 0;               // transpose not needed (libsmm_acc.cpp:484)
+  if (m > max_kernel_dim || n > max_kernel_dim) return 0;    // (libsmm_acc.cpp:485)
+  if (stack_size <= 0 || m <= 0 || n <= 0) return 0;
+  const size_t lds = sizeof(double) * (size_t)m * n;
+  hipLaunchKernelGGL(transpose_blocks_f64, dim3(stack_size), dim3(m * n >= 256 ? 256 : (m * n > 64 ? 128 : 64)), lds,
+                     stream_of(stream), dev_trs_stack + offset, static_cast<double*>(dev_data), m, n);
+  return dbcsr_amd::check(hipGetLastError(), "transpose_blocks_f64 launch", __FILE__, __LINE__);
+}
+
+int libsmm_acc_process(const int* host_param_stack, const int* dev_param_stack, int stack_size, libsmm_acc_data_t datatype,
+                       const void* dev_a_data, const void* dev_b_data, void* dev_c_data, int m_max, int n_max, int k_max,
+                       int max_kernel_dim, c_dbcsr_acc_bool_t def_mnk, void* stack_stream, void* c_stream) {
+  (void)host_param_stack;
+  (void)c_stream;
+  if (def_mnk != 1) return -1;  // inhomogeneous stack: host path
+  if (datatype == dbcsr_type_real_8) {
+    // B was transposed by libsmm_acc_transpose iff its own dims (k x n) are both <= max_kernel_dim
+    const bool bt = (k_max <= max_kernel_dim && n_max <= max_kernel_dim);
+    return process_stack_f64(dev_param_stack, stack_size, static_cast<const double*>(dev_a_data),
+                             static_cast<const double*>(dev_b_data), static_cast<double*>(dev_c_data), m_max, n_max, k_max, bt,
+                             stream_of(stack_stream));
+  }
+  if (datatype == dbcsr_type_real_4) {
+    return process_stack_f32(dev_param_stack, stack_size, static_cast<const float*>(dev_a_data),
+                             static_cast<const float*>(dev_b_data), static_cast<float*>(dev_c_data), m_max, n_max, k_max, false,
+                             stream_of(stack_stream));
+  }
+  return -10;  // complex types: host path
+}
+
+int c_calculate_norms(const double* mat, int nblks, const int* offsets, const int* nelems, float* norms, void* stream_ptr) {
+  if (nblks <= 0) return 0;
+  hipLaunchKernelGGL(block_norms_f64, dim3((nblks + 3) / 4), dim3(256), 0, stream_of(stream_ptr), mat, nblks, offsets, nelems,
+                     norms);
+  return dbcsr_amd::check(hipGetLastError(), "block_norms_f64 launch", __FILE__, __LINE__);
+}
+
+}  // extern "C"

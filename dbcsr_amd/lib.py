@@ -1,0 +1,99 @@
+"""ctypes binding of libdbcsr_acc_amd.so (include/*.h).  Fails loudly when the
+library has not been built -- there is no fallback path."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+# DBCSR data type codes (reference src/data/dbcsr_data_types.F:122-133)
+dbcsr_type_real_4 = 1
+dbcsr_type_real_8 = 3
+dbcsr_type_complex_4 = 5
+dbcsr_type_complex_8 = 7
+
+ACC_SYMBOLS = [
+    "c_dbcsr_acc_init", "c_dbcsr_acc_finalize", "c_dbcsr_acc_clear_errors", "c_dbcsr_acc_get_ndevices",
+    "c_dbcsr_acc_set_active_device", "c_dbcsr_acc_device_synchronize", "c_dbcsr_acc_stream_priority_range",
+    "c_dbcsr_acc_stream_create", "c_dbcsr_acc_stream_destroy", "c_dbcsr_acc_stream_sync", "c_dbcsr_acc_stream_wait_event",
+    "c_dbcsr_acc_event_create", "c_dbcsr_acc_event_destroy", "c_dbcsr_acc_event_record", "c_dbcsr_acc_event_query",
+    "c_dbcsr_acc_event_synchronize", "c_dbcsr_acc_dev_mem_allocate", "c_dbcsr_acc_dev_mem_deallocate",
+    "c_dbcsr_acc_dev_mem_set_ptr", "c_dbcsr_acc_host_mem_allocate", "c_dbcsr_acc_host_mem_deallocate",
+    "c_dbcsr_acc_memcpy_h2d", "c_dbcsr_acc_memcpy_d2h", "c_dbcsr_acc_memcpy_d2d", "c_dbcsr_acc_memset_zero",
+    "c_dbcsr_acc_dev_mem_info", "c_dbcsr_timeset", "c_dbcsr_timestop",
+]
+LIBSMM_SYMBOLS = [
+    "libsmm_acc_init", "libsmm_acc_finalize", "libsmm_acc_is_thread_safe", "libsmm_acc_transpose", "libsmm_acc_process",
+    "c_calculate_norms", "libsmm_acc_gpu_warp_size",
+]
+MM_SYMBOLS = [
+    "dbcsr_amd_mm_create", "dbcsr_amd_mm_destroy", "dbcsr_amd_mm_symbolic", "dbcsr_amd_mm_numeric", "dbcsr_amd_bcsr_transpose",
+    "dbcsr_amd_bcsr_checksum", "dbcsr_amd_bcsr_fill_random", "dbcsr_amd_mm_kernel_name",
+]
+
+
+class BcsrDesc(C.Structure):
+    """struct dbcsr_amd_bcsr (include/dbcsr_amd_mm.h); device pointers."""
+    _fields_ = [("nblkrows", C.c_int32), ("nblkcols", C.c_int32), ("row_blk_size", C.c_void_p), ("col_blk_size", C.c_void_p),
+                ("row_p", C.c_void_p), ("col_i", C.c_void_p), ("blk_p", C.c_void_p), ("data", C.c_void_p), ("nblks", C.c_int64)]
+
+
+class MmCounts(C.Structure):
+    _fields_ = [("c_nblks", C.c_int64), ("c_nze", C.c_int64), ("nproducts", C.c_int64), ("flop", C.c_int64)]
+
+
+def library_path():
+    return os.path.join(_HERE, "libdbcsr_acc_amd.so")
+
+
+def load_library():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            "dbcsr_amd: native library %s not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C dbcsr_amd/csrc`. There is no CPU fallback." % path)
+    L = C.CDLL(path)
+    vp, i32, i64, sz = C.c_void_p, C.c_int, C.c_int64, C.c_size_t
+    L.c_dbcsr_acc_init.restype = i32
+    L.c_dbcsr_acc_finalize.restype = i32
+    L.c_dbcsr_acc_clear_errors.restype = None
+    L.c_dbcsr_acc_get_ndevices.argtypes = [C.POINTER(i32)]
+    L.c_dbcsr_acc_set_active_device.argtypes = [i32]
+    L.c_dbcsr_acc_stream_priority_range.argtypes = [C.POINTER(i32), C.POINTER(i32)]
+    L.c_dbcsr_acc_stream_create.argtypes = [C.POINTER(vp), C.c_char_p, i32]
+    L.c_dbcsr_acc_stream_destroy.argtypes = [vp]
+    L.c_dbcsr_acc_stream_sync.argtypes = [vp]
+    L.c_dbcsr_acc_stream_wait_event.argtypes = [vp, vp]
+    L.c_dbcsr_acc_event_create.argtypes = [C.POINTER(vp)]
+    L.c_dbcsr_acc_event_destroy.argtypes = [vp]
+    L.c_dbcsr_acc_event_record.argtypes = [vp, vp]
+    L.c_dbcsr_acc_event_query.argtypes = [vp, C.POINTER(i32)]
+    L.c_dbcsr_acc_event_synchronize.argtypes = [vp]
+    L.c_dbcsr_acc_dev_mem_allocate.argtypes = [C.POINTER(vp), sz]
+    L.c_dbcsr_acc_dev_mem_deallocate.argtypes = [vp]
+    L.c_dbcsr_acc_dev_mem_set_ptr.argtypes = [C.POINTER(vp), vp, sz]
+    L.c_dbcsr_acc_host_mem_allocate.argtypes = [C.POINTER(vp), sz, vp]
+    L.c_dbcsr_acc_host_mem_deallocate.argtypes = [vp, vp]
+    L.c_dbcsr_acc_memcpy_h2d.argtypes = [vp, vp, sz, vp]
+    L.c_dbcsr_acc_memcpy_d2h.argtypes = [vp, vp, sz, vp]
+    L.c_dbcsr_acc_memcpy_d2d.argtypes = [vp, vp, sz, vp]
+    L.c_dbcsr_acc_memset_zero.argtypes = [vp, sz, sz, vp]
+    L.c_dbcsr_acc_dev_mem_info.argtypes = [C.POINTER(sz), C.POINTER(sz)]
+    L.libsmm_acc_transpose.argtypes = [vp, i32, i32, vp, i32, i32, i32, i32, vp]
+    L.libsmm_acc_process.argtypes = [vp, vp, i32, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]
+    L.c_calculate_norms.argtypes = [vp, i32, vp, vp, vp, vp]
+    L.dbcsr_amd_mm_create.argtypes = [C.POINTER(vp)]
+    L.dbcsr_amd_mm_destroy.argtypes = [vp]
+    BP = C.POINTER(BcsrDesc)
+    L.dbcsr_amd_mm_symbolic.argtypes = [vp, BP, BP, BP, i32, vp, C.POINTER(MmCounts), vp]
+    L.dbcsr_amd_mm_numeric.argtypes = [vp, i32, C.c_double, BP, BP, C.c_double, BP, BP, vp]
+    L.dbcsr_amd_bcsr_transpose.argtypes = [vp, i32, BP, BP, vp]
+    L.dbcsr_amd_bcsr_checksum.argtypes = [vp, i32, BP, C.POINTER(C.c_double), vp]
+    L.dbcsr_amd_bcsr_fill_random.argtypes = [vp, i32, BP, i32, vp]
+    L.dbcsr_amd_mm_kernel_name.argtypes = [i32]
+    L.dbcsr_amd_mm_kernel_name.restype = C.c_char_p
+    _LIB = L
+    return L

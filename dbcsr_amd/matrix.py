@@ -1,0 +1,84 @@
+"""Device-resident BCSR matrix: the host-side mirror of the reference's
+``dbcsr_type`` index (src/core/dbcsr_types.F:362-461: row_p / col_i / blk_p and
+one data area), 0-based, with every array living in HBM as a torch tensor.
+torch is only the allocator here; all arithmetic goes through the C-ABI."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import lib as _lib
+
+
+def _dtype_code(dt):
+    if dt == torch.float64:
+        return _lib.dbcsr_type_real_8
+    if dt == torch.float32:
+        return _lib.dbcsr_type_real_4
+    raise TypeError("dbcsr_amd supports real_8 and real_4 data, got %r" % (dt,))
+
+
+class StreamHandle:
+    """The C-ABI stream convention: a pointer to a hipStream_t (dbcsr_acc.h)."""
+
+    def __init__(self, torch_stream=None):
+        s = torch_stream if torch_stream is not None else torch.cuda.current_stream()
+        self._slot = C.c_void_p(s.cuda_stream)
+        self.ptr = C.cast(C.pointer(self._slot), C.c_void_p)
+
+
+class DbcsrMatrix:
+    def __init__(self, row_blk_size, col_blk_size, row_p, col_i, blk_p, data, name=""):
+        self.row_blk_size, self.col_blk_size = row_blk_size, col_blk_size
+        self.row_p, self.col_i, self.blk_p, self.data = row_p, col_i, blk_p, data
+        self.name = name
+
+    # -- construction -------------------------------------------------------
+    @classmethod
+    def from_host(cls, row_blk_size, col_blk_size, row_p, col_i, blk_p, data, device="cuda", name=""):
+        t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt).to(device)
+        data = np.ascontiguousarray(data)
+        return cls(t(row_blk_size, torch.int32), t(col_blk_size, torch.int32), t(row_p, torch.int32), t(col_i, torch.int32),
+                   t(blk_p, torch.int64), torch.as_tensor(data).to(device), name)
+
+    @classmethod
+    def empty_like_pattern(cls, row_blk_size, col_blk_size, dtype, device="cuda", name=""):
+        nbr = int(row_blk_size.numel())
+        return cls(row_blk_size, col_blk_size, torch.zeros(nbr + 1, dtype=torch.int32, device=device),
+                   torch.zeros(0, dtype=torch.int32, device=device), torch.zeros(0, dtype=torch.int64, device=device),
+                   torch.zeros(0, dtype=dtype, device=device), name)
+
+    # -- properties ---------------------------------------------------------
+    @property
+    def nblkrows(self):
+        return int(self.row_blk_size.numel())
+
+    @property
+    def nblkcols(self):
+        return int(self.col_blk_size.numel())
+
+    @property
+    def nblks(self):
+        return int(self.col_i.numel())
+
+    @property
+    def dtype(self):
+        return self.data.dtype
+
+    @property
+    def dtype_code(self):
+        return _dtype_code(self.data.dtype)
+
+    def desc(self):
+        p = lambda t: t.data_ptr() if t is not None and t.numel() > 0 else None
+        return _lib.BcsrDesc(self.nblkrows, self.nblkcols, p(self.row_blk_size), p(self.col_blk_size), self.row_p.data_ptr(),
+                             p(self.col_i), p(self.blk_p), p(self.data), self.nblks)
+
+    def to_host(self):
+        """(row_blk_size, col_blk_size, row_p, col_i, blk_p, data) as numpy arrays."""
+        g = lambda t: t.detach().cpu().numpy()
+        return g(self.row_blk_size), g(self.col_blk_size), g(self.row_p), g(self.col_i), g(self.blk_p), g(self.data)
+
+    def copy(self):
+        return DbcsrMatrix(self.row_blk_size, self.col_blk_size, self.row_p.clone(), self.col_i.clone(), self.blk_p.clone(),
+                           self.data.clone(), self.name)

@@ -1,0 +1,124 @@
+"""``dbcsr_multiply`` -- host-side mirror of the reference's operator for the
+hot path (src/dbcsr_api.F:1411-1433 -> src/mm/dbcsr_mm.F:336 dbcsr_multiply_generic):
+
+    C <- beta*C + alpha*op(A)*op(B)
+
+Same argument names, meaning and error behaviour; the work is done by the
+C-ABI engine (include/dbcsr_amd_mm.h) on the GPU.  One rank / one device here;
+the multi-GPU Cannon driver lives in dbcsr_amd/cannon.py."""
+import ctypes as C
+
+import torch
+
+from . import lib as _lib
+from .matrix import DbcsrMatrix, StreamHandle
+
+dbcsr_no_transpose = "N"
+dbcsr_transpose = "T"
+dbcsr_conjugate_transpose = "C"
+
+
+class MultiplyEngine:
+    """Owns the native workspace (bitmaps, product lists) across calls."""
+
+    def __init__(self):
+        self.L = _lib.load_library()
+        self.h = C.c_void_p()
+        rc = self.L.dbcsr_amd_mm_create(C.byref(self.h))
+        if rc != 0:
+            raise RuntimeError("dbcsr_amd_mm_create failed (%d)" % rc)
+
+    def close(self):
+        if self.h:
+            self.L.dbcsr_amd_mm_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------
+    def transposed(self, M, stream=None):
+        st = StreamHandle(stream)
+        out = DbcsrMatrix(M.col_blk_size, M.row_blk_size, torch.empty(M.nblkcols + 1, dtype=torch.int32, device=M.data.device),
+                          torch.empty_like(M.col_i), torch.empty_like(M.blk_p), torch.empty_like(M.data), M.name + "^T")
+        src, dst = M.desc(), out.desc()
+        rc = self.L.dbcsr_amd_bcsr_transpose(self.h, M.dtype_code, C.byref(src), C.byref(dst), st.ptr)
+        if rc != 0:
+            raise RuntimeError("dbcsr_amd_bcsr_transpose failed (%d)" % rc)
+        return out
+
+    def checksum(self, M, stream=None):
+        st = StreamHandle(stream)
+        out = (C.c_double * 2)()
+        d = M.desc()
+        rc = self.L.dbcsr_amd_bcsr_checksum(self.h, M.dtype_code, C.byref(d), out, st.ptr)
+        if rc != 0:
+            raise RuntimeError("dbcsr_amd_bcsr_checksum failed (%d)" % rc)
+        return out[0], out[1]
+
+    def fill_random(self, M, counter, stream=None):
+        st = StreamHandle(stream)
+        d = M.desc()
+        rc = self.L.dbcsr_amd_bcsr_fill_random(self.h, M.dtype_code, C.byref(d), int(counter), st.ptr)
+        if rc != 0:
+            raise RuntimeError("dbcsr_amd_bcsr_fill_random failed (%d)" % rc)
+
+    def multiply_local(self, alpha, A, B, beta, Cm, retain_sparsity=False, stream=None):
+        """C_out = beta*Cm + alpha*A*B for already-oriented operands; returns (C_out, counts)."""
+        st = StreamHandle(stream)
+        dev = A.data.device
+        a, b, cin = A.desc(), B.desc(), Cm.desc()
+        row_p = torch.empty(Cm.nblkrows + 1, dtype=torch.int32, device=dev)
+        counts = _lib.MmCounts()
+        rc = self.L.dbcsr_amd_mm_symbolic(self.h, C.byref(a), C.byref(b), C.byref(cin), 1 if retain_sparsity else 0,
+                                          row_p.data_ptr(), C.byref(counts), st.ptr)
+        if rc != 0:
+            raise RuntimeError("dbcsr_amd_mm_symbolic failed (%d)" % rc)
+        out = DbcsrMatrix(Cm.row_blk_size, Cm.col_blk_size, row_p, torch.empty(counts.c_nblks, dtype=torch.int32, device=dev),
+                          torch.empty(counts.c_nblks, dtype=torch.int64, device=dev),
+                          torch.empty(counts.c_nze, dtype=A.dtype, device=dev), Cm.name)
+        cout = out.desc()
+        rc = self.L.dbcsr_amd_mm_numeric(self.h, A.dtype_code, float(alpha), C.byref(a), C.byref(b), float(beta), C.byref(cin),
+                                         C.byref(cout), st.ptr)
+        if rc != 0:
+            raise RuntimeError("dbcsr_amd_mm_numeric failed (%d)" % rc)
+        return out, counts
+
+
+_default_engine = None
+
+
+def default_engine():
+    global _default_engine
+    if _default_engine is None:
+        _default_engine = MultiplyEngine()
+    return _default_engine
+
+
+def dbcsr_multiply(transa, transb, alpha, matrix_a, matrix_b, beta, matrix_c, first_row=None, last_row=None, first_column=None,
+                   last_column=None, first_k=None, last_k=None, retain_sparsity=False, filter_eps=None, flop=None, engine=None):
+    """Reference signature (src/dbcsr_api.F:1411-1433).  ``matrix_c`` is updated
+    in place (its index/data tensors are replaced); ``flop`` may be a one-element
+    list that receives the flop count, as the reference's optional INTENT(OUT)."""
+    if any(v is not None for v in (first_row, last_row, first_column, last_column, first_k, last_k)):
+        raise NotImplementedError("dbcsr_multiply: submatrix limits are not implemented on the device path yet")
+    if filter_eps is not None and filter_eps > 0:
+        raise NotImplementedError("dbcsr_multiply: filter_eps is not implemented on the device path yet")
+    for t in (transa, transb):
+        if t not in ("N", "T", "C"):
+            raise ValueError("dbcsr_multiply: invalid transpose flag %r" % (t,))
+    if matrix_a.dtype != matrix_b.dtype or matrix_a.dtype != matrix_c.dtype:
+        raise TypeError("dbcsr_multiply: data types of A, B and C differ")
+    E = engine or default_engine()
+    A = E.transposed(matrix_a) if transa != "N" else matrix_a
+    B = E.transposed(matrix_b) if transb != "N" else matrix_b
+    if A.nblkcols != B.nblkrows or A.nblkrows != matrix_c.nblkrows or B.nblkcols != matrix_c.nblkcols:
+        raise ValueError("dbcsr_multiply: incompatible block dimensions")
+    out, counts = E.multiply_local(alpha, A, B, beta, matrix_c, retain_sparsity=retain_sparsity)
+    matrix_c.row_p, matrix_c.col_i, matrix_c.blk_p, matrix_c.data = out.row_p, out.col_i, out.blk_p, out.data
+    if flop is not None:
+        flop[:] = [counts.flop]
+    return counts

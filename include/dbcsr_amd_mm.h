@@ -1,0 +1,98 @@
+/*
+ * dbcsr_amd_mm.h -- device-resident local multiply of DBCSR, C-ABI.
+ *
+ * Replaces, for one rank and one Cannon tick, the host-driven chain
+ *   dbcsr_mm_multrec_multiply -> dbcsr_mm_csr_multiply_low -> flush_stacks ->
+ *   dbcsr_mm_sched_process -> dbcsr_mm_accdrv_process -> libsmm_acc_process,
+ *   then dbcsr_mm_multrec_finalize / dbcsr_finalize
+ *   (/root/reference/src/mm/dbcsr_mm_multrec.F:263-335, dbcsr_mm_csr.F:178-359,
+ *    dbcsr_mm_sched.F:266-382, dbcsr_mm_accdrv.F:433-541,
+ *    src/work/dbcsr_work_operations.F:749+)
+ * by two calls that keep panels, index and result in HBM:
+ *   dbcsr_amd_mm_symbolic : the CSR x CSR symbolic product on the GPU
+ *                           (C index = sorted BCSR, what dbcsr_finalize emits)
+ *   dbcsr_amd_mm_numeric  : C_out = beta*C_in + alpha*A*B, one wavefront per
+ *                           C block, all its products summed in MFMA
+ *                           accumulators, each C block written once.
+ *
+ * A matrix is passed as the reference's BCSR index (core/dbcsr_types.F:376-385:
+ * row_p / col_i / blk_p + one data area), 0-based, 64-bit block offsets,
+ * blocks column-major.  ALL POINTERS ARE DEVICE POINTERS.
+ *
+ * Return: 0 ok, non-zero error (message on stderr).  Streams use the handle
+ * convention of dbcsr_acc.h (pointer to hipStream_t, NULL = null stream).
+ */
+#ifndef DBCSR_AMD_MM_H
+#define DBCSR_AMD_MM_H
+
+#include <stdint.h>
+
+#include "dbcsr_acc_libsmm.h"
+
+#if defined(__cplusplus)
+extern "C" {
+#endif
+
+typedef struct dbcsr_amd_bcsr {
+  int32_t nblkrows, nblkcols;
+  const int32_t* row_blk_size; /* [nblkrows] */
+  const int32_t* col_blk_size; /* [nblkcols] */
+  int32_t* row_p;              /* [nblkrows+1] */
+  int32_t* col_i;              /* [nblks], ascending inside a row */
+  int64_t* blk_p;              /* [nblks], element offset of each block in data */
+  void* data;                  /* fp64 or fp32 elements */
+  int64_t nblks;
+} dbcsr_amd_bcsr;
+
+typedef struct dbcsr_amd_mm_counts {
+  int64_t c_nblks;   /* blocks of C_out */
+  int64_t c_nze;     /* elements of C_out */
+  int64_t nproducts; /* block products A(i,k)*B(k,j) */
+  int64_t flop;      /* sum 2*m*n*k over products == dbcsr_multiply's flop (dbcsr_mm_csr.F:350) */
+} dbcsr_amd_mm_counts;
+
+int dbcsr_amd_mm_create(void** handle);
+int dbcsr_amd_mm_destroy(void* handle);
+
+/* Symbolic product.  c_in may have nblks == 0.  retain_sparsity: C_out keeps
+ * exactly C_in's pattern (dbcsr_mm_csr.F:319).  Writes c_out_row_p
+ * [nblkrows+1] (device) and *counts (host; the call synchronises `stream`
+ * once to deliver them).  The pattern is kept in the handle for the numeric
+ * call that must follow with the same A, B, C_in index arrays. */
+int dbcsr_amd_mm_symbolic(void* handle, const dbcsr_amd_bcsr* a, const dbcsr_amd_bcsr* b, const dbcsr_amd_bcsr* c_in,
+  int retain_sparsity, int32_t* c_out_row_p, dbcsr_amd_mm_counts* counts, void* stream);
+
+/* Numeric phase.  c_out->row_p is the array written by the symbolic call;
+ * col_i [c_nblks], blk_p [c_nblks] and data [c_nze] are allocated by the caller
+ * and filled here (blocks laid out in index order).  c_out->data may alias
+ * c_in->data only when retain_sparsity was set (same pattern, in place).
+ * datatype: dbcsr_type_real_8 or dbcsr_type_real_4.  Asynchronous on stream. */
+int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha, const dbcsr_amd_bcsr* a, const dbcsr_amd_bcsr* b,
+  double beta, const dbcsr_amd_bcsr* c_in, dbcsr_amd_bcsr* c_out, void* stream);
+
+/* Transposed copy of a BCSR matrix on the device (dbcsr_new_transposed,
+ * src/ops/dbcsr_transformations.F): dst index arrays/data are caller-allocated
+ * with src's nblks / nze; dst->row_blk_size/col_blk_size must already hold the
+ * swapped size arrays. */
+int dbcsr_amd_bcsr_transpose(void* handle, libsmm_acc_data_t datatype, const dbcsr_amd_bcsr* src, dbcsr_amd_bcsr* dst, void* stream);
+
+/* Checksums of dbcsr_checksum (src/dist/dbcsr_dist_util.F:432-577) on the
+ * device: out[0] = sum x^2, out[1] = sum x*ln|row*col| (1-based global element
+ * coordinates).  Synchronises stream. */
+int dbcsr_amd_bcsr_checksum(void* handle, libsmm_acc_data_t datatype, const dbcsr_amd_bcsr* m, double* out2, void* stream);
+
+/* Synthetic block values of the reference's test generator
+ * (src/ops/dbcsr_test_methods.F:423-429 + LAPACK dlarnv/slarnv idist=1): block b of the
+ * index gets larnv(seed(row+1, nblkrows, col+1, nblkcols, counter)).  Used by the
+ * benchmark to create inputs directly in HBM. */
+int dbcsr_amd_bcsr_fill_random(void* handle, libsmm_acc_data_t datatype, const dbcsr_amd_bcsr* m, int counter, void* stream);
+
+/* Time spent in the last numeric kernel launch is measured by the caller with
+ * events on `stream`; this returns the symbol name of the dominant kernel for
+ * profile look-up. */
+const char* dbcsr_amd_mm_kernel_name(libsmm_acc_data_t datatype);
+
+#if defined(__cplusplus)
+}
+#endif
+#endif

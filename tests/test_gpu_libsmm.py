@@ -1,0 +1,125 @@
+"""GPU parity of the libsmm_acc C-ABI (libsmm_acc_transpose + libsmm_acc_process +
+c_calculate_norms) against the CPU oracle.  Mirrors the reference's kernel
+validation (src/acc/libsmm_acc/libsmm_acc.cpp:55-87: integer-valued inputs,
+EXACT checksum equality) and acc_bench's tolerance test on random inputs."""
+import numpy as np
+import pytest
+import torch
+
+from dbcsr_amd import lib as L
+from oracle import oracle as O
+from tests.gpu_util import StreamHandle, rel_err, run_stack
+
+pytestmark = pytest.mark.gpu
+
+# tuned flagship triplets of the reference + GPU block mixes of tests/dbcsr_unittest3.F:79-120 + odd shapes
+TRIPLETS = [(23, 23, 23), (13, 13, 13), (32, 32, 32), (4, 4, 4), (5, 7, 9), (1, 3, 4), (13, 23, 32), (32, 13, 23), (23, 16, 23),
+            (16, 23, 16), (14, 29, 32), (4, 13, 25), (9, 8, 5), (24, 24, 24), (45, 67, 78), (78, 45, 67), (1, 1, 1), (7, 1, 33)]
+
+
+@pytest.mark.parametrize("m,n,k", TRIPLETS)
+def test_validate_kernel_exact(m, n, k):
+    # the reference's own validation inputs: n_a = n_b = 100, n_c = 10, stack 100 (libsmm_acc_benchmark.cpp:45-52)
+    na, nb, nc, nstack = 100, 100, 10, 100
+    a = O.mat_init(na, m, k, 42)
+    b = O.mat_init(nb, k, n, 24)
+    stack = O.stack_init(nstack, nc, na, nb, m, n, k, rseed=7)
+    c_ref = np.zeros(nc * m * n)
+    O.stack_calc(stack, c_ref, a, b, m, n, k, b_transposed=False)
+    rc, c = run_stack(stack, a, b, np.zeros(nc * m * n), m, n, k, L.dbcsr_type_real_8)
+    assert rc >= 0
+    assert O.lib().orc_check_sum(c, c.size) == O.lib().orc_check_sum(c_ref, c_ref.size)  # exact, as validate_kernel
+    assert np.array_equal(c, c_ref)
+
+
+def test_tuning_stack_23_random_values():
+    # tuner/timer configuration (libsmm_acc_benchmark.cpp:36-44) with U(0,1) values, stack sorted by c as accdrv does
+    m = n = k = 23
+    na, nb, nc, nstack = 10000, 10000, 1000, 16005
+    rng = np.random.default_rng(1)
+    a, b, c0 = rng.random(na * m * k), rng.random(nb * k * n), rng.random(nc * m * n)
+    stack = O.stack_init(nstack, nc, na, nb, m, n, k, rseed=3)
+    c_ref = c0.copy()
+    O.stack_calc(stack, c_ref, a, b, m, n, k, b_transposed=False)
+    rc, c = run_stack(stack, a, b, c0.copy(), m, n, k, L.dbcsr_type_real_8)
+    assert rc >= 0
+    assert rel_err(c, c_ref) <= 1e-10  # north-star tolerance on C values
+
+
+def test_unsorted_stack_and_large_blocks():
+    # c offsets in random order (runs of length 1) and a block above max_kernel_dim (B not transposed: libsmm_acc.cpp:485)
+    rng = np.random.default_rng(2)
+    for (m, n, k) in [(23, 23, 23), (100, 90, 85)]:
+        na, nb, nc, nstack = 50, 60, 7, 333
+        a, b, c0 = rng.random(na * m * k), rng.random(nb * k * n), rng.random(nc * m * n)
+        stack = np.empty(3 * nstack, np.int32)
+        stack[0::3] = rng.integers(0, na, nstack) * m * k + 1
+        stack[1::3] = rng.integers(0, nb, nstack) * k * n + 1
+        stack[2::3] = rng.integers(0, nc, nstack) * m * n + 1
+        c_ref = c0.copy()
+        O.stack_calc(stack, c_ref, a, b, m, n, k, b_transposed=False)
+        rc, c = run_stack(stack, a, b, c0.copy(), m, n, k, L.dbcsr_type_real_8)
+        assert rc >= 0
+        assert rel_err(c, c_ref) <= 1e-10
+
+
+def test_fp32_stack():
+    # the reference returns -10 for fp32 (libsmm_acc.cpp:338); this library runs it on the device
+    m = n = k = 32
+    na, nb, nc, nstack = 200, 200, 20, 2000
+    rng = np.random.default_rng(3)
+    a = rng.random(na * m * k, dtype=np.float32)
+    b = rng.random(nb * k * n, dtype=np.float32)
+    c0 = rng.random(nc * m * n, dtype=np.float32)
+    stack = O.stack_init(nstack, nc, na, nb, m, n, k, rseed=5)
+    c_ref = c0.astype(np.float64)
+    O.stack_calc(stack, c_ref, a.astype(np.float64), b.astype(np.float64), m, n, k, b_transposed=False)
+    rc, c = run_stack(stack, a, b, c0.copy(), m, n, k, L.dbcsr_type_real_4, transpose_b=True)  # transpose is a no-op for fp32
+    assert rc >= 0
+    assert rel_err(c, c_ref) <= 2e-3 * 1e-1  # acc_bench's fp32 epsilon is 2e-3 (acc_bench.c:69-71); we are far inside
+
+
+def test_return_codes():
+    lib = L.load_library()
+    st = StreamHandle()
+    z = torch.zeros(64, dtype=torch.float64, device="cuda")
+    s = torch.ones(3, dtype=torch.int32, device="cuda")
+    # inhomogeneous stack -> -1, complex -> -10 : "run this stack on the CPU", never abort
+    assert lib.libsmm_acc_process(None, s.data_ptr(), 1, L.dbcsr_type_real_8, z.data_ptr(), z.data_ptr(), z.data_ptr(), 4, 4, 4, 80, 0,
+                                  st.ptr, st.ptr) == -1
+    assert lib.libsmm_acc_process(None, s.data_ptr(), 1, L.dbcsr_type_complex_8, z.data_ptr(), z.data_ptr(), z.data_ptr(), 2, 2, 2, 80,
+                                  1, st.ptr, st.ptr) == -10
+    assert lib.libsmm_acc_process(None, s.data_ptr(), 0, L.dbcsr_type_real_8, z.data_ptr(), z.data_ptr(), z.data_ptr(), 4, 4, 4, 80, 1,
+                                  st.ptr, st.ptr) == 0  # empty stack
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("m,n", [(23, 23), (5, 9), (32, 13), (1, 7), (80, 80)])
+def test_transpose_matches_oracle(m, n):
+    lib = L.load_library()
+    st = StreamHandle()
+    nblk = 37
+    data = O.mat_init(nblk, m, n, 42)
+    trs = (np.arange(nblk, dtype=np.int32)[::-1] * m * n).copy()  # any order, 0-based offsets
+    ref = data.copy()
+    O.transpose(trs, ref, m, n)
+    d = torch.as_tensor(data).cuda()
+    t = torch.as_tensor(np.concatenate([[-1, -1], trs]).astype(np.int32)).cuda()  # exercise the `offset` argument
+    assert lib.libsmm_acc_transpose(t.data_ptr(), 2, nblk, d.data_ptr(), L.dbcsr_type_real_8, m, n, 80, st.ptr) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(d.cpu().numpy(), ref)
+
+
+def test_norms_match_oracle():
+    lib = L.load_library()
+    st = StreamHandle()
+    rng = np.random.default_rng(4)
+    sizes = rng.integers(1, 700, 300).astype(np.int32)
+    offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int32)
+    mat = rng.standard_normal(int(sizes.sum()))
+    ref = O.norms(mat, offs, sizes)
+    dm, do, dn = torch.as_tensor(mat).cuda(), torch.as_tensor(offs).cuda(), torch.as_tensor(sizes).cuda()
+    out = torch.zeros(len(sizes), dtype=torch.float32, device="cuda")
+    assert lib.c_calculate_norms(dm.data_ptr(), len(sizes), do.data_ptr(), dn.data_ptr(), out.data_ptr(), st.ptr) == 0
+    torch.cuda.synchronize()
+    assert np.allclose(out.cpu().numpy(), ref, rtol=1e-6)
