@@ -529,9 +529,7 @@ __global__ void __launch_bounds__(256) fill_random_f32(const int* __restrict__ r
   // bumps the chunk's base seed (LAPACK slaruv) -- so one thread walks one block.
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   (void)nbc;
-  const int row = (int)t;  // thread per block row is too coarse; use thread per block below
-  (void)row;
-  // thread per block: find row by binary search in row_p
+  // thread per block: find its row by binary search in row_p
   const int64_t nblks = row_p[nbr];
   if (t >= nblks) return;
   int lo = 0, hi = nbr;
@@ -638,6 +636,8 @@ struct Engine {
   DevBuf<double> row_sums;
   DevBuf<unsigned long long> dev_scalars;
   int64_t* host_scalars = nullptr;  // pinned: [0]=c_nblks [1]=c_nze [2]=nproducts [3]=flop
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};  // around fill_products and the numeric kernel
+  bool timed = false;
   // state carried from symbolic to numeric
   int nbr = 0, W = 0;
   int64_t c_nblks = 0, nproducts = 0;
@@ -676,7 +676,23 @@ int dbcsr_amd_mm_create(void** handle) {
     delete E;
     return check(e, "hipHostMalloc", __FILE__, __LINE__);
   }
+  for (int i = 0; i < 3; ++i) {
+    e = hipEventCreate(&E->ev[i]);
+    if (e != hipSuccess) return check(e, "hipEventCreate", __FILE__, __LINE__);
+  }
   *handle = E;
+  return 0;
+}
+
+int dbcsr_amd_mm_timing(void* handle, float* ms_fill, float* ms_numeric) {
+  Engine* E = static_cast<Engine*>(handle);
+  if (!E || !E->timed) return -1;
+  ACC_CHECK(hipEventSynchronize(E->ev[2]));
+  float f = 0.f, n = 0.f;
+  ACC_CHECK(hipEventElapsedTime(&f, E->ev[0], E->ev[1]));
+  ACC_CHECK(hipEventElapsedTime(&n, E->ev[1], E->ev[2]));
+  if (ms_fill) *ms_fill = f;
+  if (ms_numeric) *ms_numeric = n;
   return 0;
 }
 
@@ -689,6 +705,8 @@ int dbcsr_amd_mm_destroy(void* handle) {
   E->prod_start.release(); E->c_blk_p_ws.release(); E->partial.release(); E->off_a.release(); E->off_b.release();
   E->entries.release(); E->descs.release(); E->row_sums.release(); E->dev_scalars.release();
   if (E->host_scalars) (void)hipHostFree(E->host_scalars);
+  for (int i = 0; i < 3; ++i)
+    if (E->ev[i]) (void)hipEventDestroy(E->ev[i]);
   delete E;
   return 0;
 }
@@ -779,12 +797,14 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
   const int64_t nblk = E->c_nblks;
   if (nblk == 0) return 0;
   if (E->entries.ensure((size_t)E->nproducts + 1) || E->descs.ensure((size_t)nblk + 1)) return -1;
+  ACC_CHECK(hipEventRecord(E->ev[0], st));
   hipLaunchKernelGGL(fill_products, grid_for((int64_t)nbr * W), dim3(256), 0, st, a->row_p, a->col_i, a->blk_p, b->row_p, b->blk_p,
                      c_in->row_p, c_in->blk_p, a->row_blk_size, a->col_blk_size, b->col_blk_size, E->b_bm.p, E->b_pre.p,
                      E->have_cin ? E->cin_bm.p : (const uint32_t*)nullptr, E->have_cin ? E->cin_pre.p : (const int*)nullptr,
                      E->c_bm.p, E->c_pre.p, c_out->row_p, E->prod_start.p, E->c_blk_p_ws.p, nbr, W, c_out->col_i, c_out->blk_p,
                      E->descs.p, E->entries.p);
   const unsigned nwg = (unsigned)((nblk + 3) / 4);
+  ACC_CHECK(hipEventRecord(E->ev[1], st));
   if (datatype == dbcsr_type_real_8) {
     hipLaunchKernelGGL(mm_numeric_f64, dim3(nwg), dim3(256), 0, st, E->descs.p, nblk, E->entries.p,
                        static_cast<const double*>(a->data), static_cast<const double*>(b->data), static_cast<double*>(c_out->data),
@@ -794,6 +814,8 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
                        static_cast<const float*>(a->data), static_cast<const float*>(b->data), static_cast<float*>(c_out->data),
                        static_cast<const float*>(c_in->data), (float)alpha, (float)beta);
   }
+  ACC_CHECK(hipEventRecord(E->ev[2], st));
+  E->timed = true;
   c_out->nblks = nblk;
   return check(hipGetLastError(), "dbcsr_amd_mm_numeric", __FILE__, __LINE__);
 }

@@ -66,6 +66,14 @@ class MultiplyEngine:
         if rc != 0:
             raise RuntimeError("dbcsr_amd_bcsr_fill_random failed (%d)" % rc)
 
+    def last_timing(self):
+        """(ms_fill, ms_numeric) of the last numeric call, from HIP events on its stream."""
+        f, n = C.c_float(), C.c_float()
+        rc = self.L.dbcsr_amd_mm_timing(self.h, C.byref(f), C.byref(n))
+        if rc != 0:
+            raise RuntimeError("dbcsr_amd_mm_timing failed (%d)" % rc)
+        return f.value, n.value
+
     def multiply_local(self, alpha, A, B, beta, Cm, retain_sparsity=False, stream=None):
         """C_out = beta*Cm + alpha*A*B for already-oriented operands; returns (C_out, counts)."""
         st = StreamHandle(stream)

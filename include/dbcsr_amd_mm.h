@@ -87,9 +87,13 @@ int dbcsr_amd_bcsr_checksum(void* handle, libsmm_acc_data_t datatype, const dbcs
  * benchmark to create inputs directly in HBM. */
 int dbcsr_amd_bcsr_fill_random(void* handle, libsmm_acc_data_t datatype, const dbcsr_amd_bcsr* m, int counter, void* stream);
 
-/* Time spent in the last numeric kernel launch is measured by the caller with
- * events on `stream`; this returns the symbol name of the dominant kernel for
- * profile look-up. */
+/* HIP-event timing of the last dbcsr_amd_mm_numeric call on this handle, taken
+ * on the stream the kernels were launched on: ms_fill = product-list/index
+ * emission kernel, ms_numeric = the block-GEMM kernel.  Waits for that call to
+ * finish.  Used by bench.py for the roofline figure. */
+int dbcsr_amd_mm_timing(void* handle, float* ms_fill, float* ms_numeric);
+
+/* Symbol name of the dominant kernel, for profile look-up. */
 const char* dbcsr_amd_mm_kernel_name(libsmm_acc_data_t datatype);
 
 #if defined(__cplusplus)
