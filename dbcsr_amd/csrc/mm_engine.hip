@@ -21,6 +21,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <new>
 
 #include "../../include/dbcsr_amd_mm.h"
@@ -374,6 +375,129 @@ __global__ void __launch_bounds__(256) mm_numeric_f64(const Desc* __restrict__ d
   }
 }
 
+// ---- LDS-staged variant ----------------------------------------------------
+// Measured on v1 (profiles/r01_v1_direct_loads_rocprofv3_summary.txt): loading
+// MFMA fragments straight from global memory costs ~40 L1 accesses per wave
+// load (TA 86 % busy, MFMA 20 % busy).  Here each wave copies the whole A and B
+// block of a product with fully coalesced 16-byte loads into its private LDS
+// slice (no barrier: one wave, in-order LDS queue) and reads fragments with
+// ds_read_b64; the next product's blocks are already in flight in registers
+// while the current one is multiplied.
+typedef double dpair __attribute__((ext_vector_type(2), aligned(8)));
+typedef double dpair16 __attribute__((ext_vector_type(2), aligned(16)));
+
+template <int MA, int NC>
+__device__ __forceinline__ void cblock_f64_lds(const Desc& d, const Entry* __restrict__ entries, const double* __restrict__ a_data,
+                                               const double* __restrict__ b_data, double* __restrict__ c_out,
+                                               const double* __restrict__ c_in, double alpha, double beta, const LaneMap& L, int lane,
+                                               double* lds_a, double* lds_b) {
+  constexpr int CA = 2 * MA, CB = 2 * NC;  // 128-element chunks covering (8 MA) x 32 and 32 x (8 NC)
+  double acc[MA][NC];
+#pragma unroll
+  for (int a = 0; a < MA; ++a)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[a][c] = 0.0;
+  const int m = d.m, n = d.n;
+  const Entry* e = entries + d.prod_start;
+  const int cnt = d.prod_cnt;
+  dpair ra[CA], rb[CB];
+  auto issue = [&](int p) {
+    const double* A = a_data + e[p].a_off;
+    const double* B = b_data + e[p].b_off;
+    const int ks = (int)e[p].ks;
+    const int mk = m * ks, kn = ks * n;
+#pragma unroll
+    for (int c = 0; c < CA; ++c) {
+      const int idx = (c * 64 + lane) * 2;
+      dpair v = {0.0, 0.0};
+      if (idx + 1 < mk) v = *reinterpret_cast<const dpair*>(A + idx);
+      else if (idx < mk) v.x = A[idx];
+      ra[c] = v;
+    }
+#pragma unroll
+    for (int c = 0; c < CB; ++c) {
+      const int idx = (c * 64 + lane) * 2;
+      dpair v = {0.0, 0.0};
+      if (idx + 1 < kn) v = *reinterpret_cast<const dpair*>(B + idx);
+      else if (idx < kn) v.x = B[idx];
+      rb[c] = v;
+    }
+  };
+  if (cnt > 0) issue(0);
+  for (int p = 0; p < cnt; ++p) {
+    const int ks = (int)e[p].ks;
+    const int mk = m * ks, kn = ks * n;
+#pragma unroll
+    for (int c = 0; c < CA; ++c) {
+      const int idx = (c * 64 + lane) * 2;
+      if (idx < mk) *reinterpret_cast<dpair16*>(lds_a + idx) = ra[c];
+    }
+#pragma unroll
+    for (int c = 0; c < CB; ++c) {
+      const int idx = (c * 64 + lane) * 2;
+      if (idx < kn) *reinterpret_cast<dpair16*>(lds_b + idx) = rb[c];
+    }
+    if (p + 1 < cnt) issue(p + 1);
+    block_product_f64<MA, NC, false>(acc, lds_a, lds_b, m, n, ks, L, 0, 0);
+  }
+  double* C = c_out + d.c_off;
+  const bool has_in = d.cin_off >= 0;
+  const double* Ci = c_in + (has_in ? d.cin_off : 0);
+#pragma unroll
+  for (int a = 0; a < MA; ++a)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int row = 8 * a + L.rowd, col = 8 * c + L.coll;
+      if (row < m && col < n) {
+        double v = alpha * acc[a][c];
+        if (has_in) v += beta * Ci[row + (size_t)m * col];
+        C[row + (size_t)m * col] = v;
+      }
+    }
+}
+
+// all block dimensions of the launch are <= 8*MAXT (<= 32); lds_wave_doubles = per-wave LDS slice (A part then B part).
+// MAXT bounds the register allocation to what the largest block class present needs.
+template <int MAXT>
+__global__ void __launch_bounds__(256) mm_numeric_f64_lds(const Desc* __restrict__ descs, int64_t nblk, const Entry* __restrict__ entries,
+                                                          const double* __restrict__ a_data, const double* __restrict__ b_data,
+                                                          double* __restrict__ c_out, const double* __restrict__ c_in, double alpha,
+                                                          double beta, int lds_a_doubles, int lds_wave_doubles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int64_t cb = (int64_t)wg * 4 + wid;
+  if (cb >= nblk) return;
+  double* lds_a = reinterpret_cast<double*>(smem) + (size_t)wid * lds_wave_doubles;
+  double* lds_b = lds_a + lds_a_doubles;
+  const Desc d = descs[cb];
+  const LaneMap L(lane);
+  const int MA = (d.m + 7) >> 3, NC = (d.n + 7) >> 3;
+  switch (MA * 4 + NC) {
+#define DBCSR_CASE(A_, C_)                                                                                           \
+  case A_ * 4 + C_:                                                                                                  \
+    if constexpr (A_ <= MAXT && C_ <= MAXT)                                                                          \
+      cblock_f64_lds<A_, C_>(d, entries, a_data, b_data, c_out, c_in, alpha, beta, L, lane, lds_a, lds_b);          \
+    break;
+    DBCSR_CASE(1, 1) DBCSR_CASE(1, 2) DBCSR_CASE(1, 3) DBCSR_CASE(1, 4)
+    DBCSR_CASE(2, 1) DBCSR_CASE(2, 2) DBCSR_CASE(2, 3) DBCSR_CASE(2, 4)
+    DBCSR_CASE(3, 1) DBCSR_CASE(3, 2) DBCSR_CASE(3, 3) DBCSR_CASE(3, 4)
+    DBCSR_CASE(4, 1) DBCSR_CASE(4, 2) DBCSR_CASE(4, 3) DBCSR_CASE(4, 4)
+#undef DBCSR_CASE
+    default: break;
+  }
+}
+
+// max of an int array (block sizes) into out[slot]
+__global__ void __launch_bounds__(256) max_of(const int* __restrict__ v, int n, int* __restrict__ out) {
+  int mx = 0;
+  for (int i = threadIdx.x; i < n; i += 256) mx = max(mx, v[i]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = max(mx, __shfl_down(mx, off, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, mx);
+}
+
 __global__ void __launch_bounds__(256) mm_numeric_f32(const Desc* __restrict__ descs, int64_t nblk, const Entry* __restrict__ entries,
                                                       const float* __restrict__ a_data, const float* __restrict__ b_data,
                                                       float* __restrict__ c_out, const float* __restrict__ c_in, float alpha,
@@ -642,6 +766,8 @@ struct Engine {
   int nbr = 0, W = 0;
   int64_t c_nblks = 0, nproducts = 0;
   bool have_cin = false, retain = false, valid = false;
+  int max_m = 0, max_k = 0, max_n = 0;
+  int use_lds = 1;  // DBCSR_AMD_MM_KERNEL=direct selects the v1 kernel (A/B experiments)
 };
 
 template <typename TO>
@@ -676,6 +802,7 @@ int dbcsr_amd_mm_create(void** handle) {
     delete E;
     return check(e, "hipHostMalloc", __FILE__, __LINE__);
   }
+  if (const char* k = getenv("DBCSR_AMD_MM_KERNEL")) E->use_lds = strcmp(k, "direct") != 0;
   for (int i = 0; i < 3; ++i) {
     e = hipEventCreate(&E->ev[i]);
     if (e != hipSuccess) return check(e, "hipEventCreate", __FILE__, __LINE__);
@@ -766,14 +893,24 @@ int dbcsr_amd_mm_symbolic(void* handle, const dbcsr_amd_bcsr* a, const dbcsr_amd
   if (E->prod_cnt.ensure((size_t)c_nblks + 1) || E->blk_nze.ensure((size_t)c_nblks + 1) || E->prod_start.ensure((size_t)c_nblks + 1) ||
       E->c_blk_p_ws.ensure((size_t)c_nblks + 1))
     return -1;
+  // block-size maxima (LDS slice size / kernel choice of the numeric phase)
+  {
+    int* mx = reinterpret_cast<int*>(E->dev_scalars.p + 4);
+    hipLaunchKernelGGL(max_of, dim3(1), dim3(256), 0, st, a->row_blk_size, nbr, mx + 0);
+    hipLaunchKernelGGL(max_of, dim3(1), dim3(256), 0, st, a->col_blk_size, nbk, mx + 2);
+    hipLaunchKernelGGL(max_of, dim3(1), dim3(256), 0, st, b->col_blk_size, nbc, mx + 4);
+  }
   // 3. per C block: number of products, size; flop
   hipLaunchKernelGGL(count_products, grid_for((int64_t)nbr * W), dim3(256), 0, st, a->row_p, a->col_i, a->row_blk_size,
                      a->col_blk_size, b->col_blk_size, E->b_bm.p, E->c_bm.p, E->c_pre.p, c_out_row_p, nbr, W, E->prod_cnt.p,
                      E->blk_nze.p, E->dev_scalars.p + 3);
   if (exclusive_scan<int64_t>(E, E->prod_cnt.p, c_nblks, E->prod_start.p, dsc + 2, false, st)) return -1;
   if (exclusive_scan<int64_t>(E, E->blk_nze.p, c_nblks, E->c_blk_p_ws.p, dsc + 1, false, st)) return -1;
-  ACC_CHECK(hipMemcpyAsync(E->host_scalars, dsc, 4 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+  ACC_CHECK(hipMemcpyAsync(E->host_scalars, dsc, 7 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
   ACC_CHECK(hipStreamSynchronize(st));
+  E->max_m = (int)E->host_scalars[4];
+  E->max_k = (int)E->host_scalars[5];
+  E->max_n = (int)E->host_scalars[6];
   counts->c_nblks = E->host_scalars[0];
   counts->c_nze = E->host_scalars[1];
   counts->nproducts = E->host_scalars[2];
@@ -806,9 +943,28 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
   const unsigned nwg = (unsigned)((nblk + 3) / 4);
   ACC_CHECK(hipEventRecord(E->ev[1], st));
   if (datatype == dbcsr_type_real_8) {
-    hipLaunchKernelGGL(mm_numeric_f64, dim3(nwg), dim3(256), 0, st, E->descs.p, nblk, E->entries.p,
-                       static_cast<const double*>(a->data), static_cast<const double*>(b->data), static_cast<double*>(c_out->data),
-                       static_cast<const double*>(c_in->data), alpha, beta);
+    const bool small = E->max_m <= 32 && E->max_k <= 32 && E->max_n <= 32;
+    if (small && E->use_lds) {
+      const int lds_a = (E->max_m * E->max_k + 1) & ~1, lds_b = (E->max_k * E->max_n + 1) & ~1;
+      const int lds_wave = lds_a + lds_b;
+      const int maxt = (std::max(E->max_m, E->max_n) + 7) / 8;
+      const size_t lds_bytes = (size_t)4 * lds_wave * sizeof(double);
+#define DBCSR_LAUNCH(T_)                                                                                                        \
+  hipLaunchKernelGGL(mm_numeric_f64_lds<T_>, dim3(nwg), dim3(256), lds_bytes, st, E->descs.p, nblk, E->entries.p,               \
+                     static_cast<const double*>(a->data), static_cast<const double*>(b->data), static_cast<double*>(c_out->data), \
+                     static_cast<const double*>(c_in->data), alpha, beta, lds_a, lds_wave)
+      switch (maxt) {
+        case 1: DBCSR_LAUNCH(1); break;
+        case 2: DBCSR_LAUNCH(2); break;
+        case 3: DBCSR_LAUNCH(3); break;
+        default: DBCSR_LAUNCH(4); break;
+      }
+#undef DBCSR_LAUNCH
+    } else {
+      hipLaunchKernelGGL(mm_numeric_f64, dim3(nwg), dim3(256), 0, st, E->descs.p, nblk, E->entries.p,
+                         static_cast<const double*>(a->data), static_cast<const double*>(b->data),
+                         static_cast<double*>(c_out->data), static_cast<const double*>(c_in->data), alpha, beta);
+    }
   } else {
     hipLaunchKernelGGL(mm_numeric_f32, dim3(nwg), dim3(256), 0, st, E->descs.p, nblk, E->entries.p,
                        static_cast<const float*>(a->data), static_cast<const float*>(b->data), static_cast<float*>(c_out->data),
