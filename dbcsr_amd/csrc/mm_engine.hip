@@ -311,6 +311,174 @@ fill_products(const int* __restrict__ a_row_p, const int* __restrict__ a_col_i, 
   }
 }
 
+
+
+// ---- dense-grid variants: one lane per (row i, column j) candidate ------------
+// The per-word kernels above expose only nbr*W threads, each walking up to 32 C
+// blocks x |A-row| serially (v1 profile: 1.6 + 4.0 ms for config 2).  When C is not
+// extremely sparse it is much faster to give every candidate (i, j) its own lane:
+// a wavefront covers 64 consecutive columns of one row, so the walk over A's row
+// is wave-uniform (scalar loads) and the B bitmap words are two broadcast loads.
+__global__ void __launch_bounds__(256) count_products_grid(const int* __restrict__ a_row_p, const int* __restrict__ a_col_i,
+                                                           const int* __restrict__ rs, const int* __restrict__ ks,
+                                                           const int* __restrict__ cs, const uint32_t* __restrict__ b_bm,
+                                                           const uint32_t* __restrict__ c_bm, const int* __restrict__ c_pre,
+                                                           const int* __restrict__ c_row_p, int nbr, int nbc, int W, int nJ,
+                                                           int* __restrict__ prod_cnt, int* __restrict__ blk_nze,
+                                                           unsigned long long* __restrict__ flop_out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wv = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  unsigned long long flop = 0;
+  if (wv < (int64_t)nbr * nJ) {
+    const int i = (int)(wv / nJ), jb = (int)(wv % nJ);
+    const int j = jb * 64 + lane, w = j >> 5, bit = j & 31;
+    const uint32_t cw = w < W ? c_bm[(size_t)i * W + w] : 0u;
+    const bool present = (cw >> bit) & 1u;
+    if (__ballot(present)) {
+      const int a0 = a_row_p[i], a1 = a_row_p[i + 1];
+      int cnt = 0;
+      long long ksum = 0;
+      for (int ab = a0; ab < a1; ++ab) {
+        const int k = a_col_i[ab];
+        const uint32_t bw = w < W ? b_bm[(size_t)k * W + w] : 0u;
+        if ((bw >> bit) & 1u) {
+          ++cnt;
+          ksum += ks[k];
+        }
+      }
+      if (present) {
+        const int cb = c_row_p[i] + c_pre[(size_t)i * W + w] + __popc(cw & ((1u << bit) - 1u));
+        const int m = rs[i], n = cs[j];
+        prod_cnt[cb] = cnt;
+        blk_nze[cb] = m * n;
+        flop = 2ull * (unsigned long long)m * n * (unsigned long long)ksum;
+      }
+    }
+  }
+  __shared__ unsigned long long red[4];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) flop += __shfl_down(flop, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = flop;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long t = red[0] + red[1] + red[2] + red[3];
+    if (t) atomicAdd(flop_out, t);
+  }
+}
+
+__global__ void __launch_bounds__(256)
+fill_products_grid(const int* __restrict__ a_row_p, const int* __restrict__ a_col_i, const int64_t* __restrict__ a_blk_p,
+                   const int* __restrict__ b_row_p, const int64_t* __restrict__ b_blk_p, const int* __restrict__ cin_row_p,
+                   const int64_t* __restrict__ cin_blk_p, const int* __restrict__ rs, const int* __restrict__ ks,
+                   const int* __restrict__ cs, const uint32_t* __restrict__ b_bm, const int* __restrict__ b_pre,
+                   const uint32_t* __restrict__ cin_bm, const int* __restrict__ cin_pre, const uint32_t* __restrict__ c_bm,
+                   const int* __restrict__ c_pre, const int* __restrict__ c_row_p, const int64_t* __restrict__ prod_start,
+                   const int64_t* __restrict__ c_blk_p_ws, int nbr, int nbc, int W, int nJ, int* __restrict__ c_col_i,
+                   int64_t* __restrict__ c_blk_p, Desc* __restrict__ descs, Entry* __restrict__ entries) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wv = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (wv >= (int64_t)nbr * nJ) return;
+  const int i = (int)(wv / nJ), jb = (int)(wv % nJ);
+  const int j = jb * 64 + lane, w = j >> 5, bit = j & 31;
+  const uint32_t cw = w < W ? c_bm[(size_t)i * W + w] : 0u;
+  const bool present = (cw >> bit) & 1u;
+  if (!__ballot(present)) return;
+  const uint32_t below = (1u << bit) - 1u;
+  const int cb = present ? c_row_p[i] + c_pre[(size_t)i * W + w] + __popc(cw & below) : 0;
+  const int64_t p0 = present ? prod_start[cb] : 0;
+  const int a0 = a_row_p[i], a1 = a_row_p[i + 1];
+  int cnt = 0;
+  for (int ab = a0; ab < a1; ++ab) {
+    const int k = a_col_i[ab];
+    const uint32_t bw = w < W ? b_bm[(size_t)k * W + w] : 0u;
+    if (present && ((bw >> bit) & 1u)) {
+      const int bidx = b_row_p[k] + b_pre[(size_t)k * W + w] + __popc(bw & below);
+      Entry e;
+      e.a_off = (uint32_t)a_blk_p[ab];
+      e.b_off = (uint32_t)b_blk_p[bidx];
+      e.ks = (uint32_t)ks[k];
+      entries[p0 + cnt] = e;
+      ++cnt;
+    }
+  }
+  if (present) {
+    Desc d;
+    d.c_off = c_blk_p_ws[cb];
+    d.cin_off = -1;
+    if (cin_bm) {
+      const uint32_t cinw = cin_bm[(size_t)i * W + w];
+      if ((cinw >> bit) & 1u) d.cin_off = cin_blk_p[cin_row_p[i] + cin_pre[(size_t)i * W + w] + __popc(cinw & below)];
+    }
+    d.prod_start = p0;
+    d.prod_cnt = cnt;
+    d.m = (int16_t)rs[i];
+    d.n = (int16_t)cs[j];
+    descs[cb] = d;
+    c_col_i[cb] = j;
+    c_blk_p[cb] = d.c_off;
+  }
+}
+
+// ----------------------------------------------------------------------------
+// processing order of the C blocks (speed only; results do not depend on it)
+//
+// v2 measurement (profiles/r01_v2_*): with C swept row by row every B block is
+// fetched from HBM once per A block-row that needs it (L2 miss rate 50 %,
+// ~127 GB of HBM reads for 1.7 GB of operands, kernel HBM-bound at 5.5 TB/s).
+// Order used instead: C is swept in COLUMN PANELS narrow enough that the B panel
+// (all rows x panel columns) stays resident in the 256 MB Infinity Cache; inside
+// a panel, block row i belongs to XCD (i mod 8), so its A block-row is fetched
+// into exactly one private L2 and reused by all C blocks of that row-panel.
+// order[] holds, for each XCD, its (panel-major, row-minor) list of C block
+// indices, padded with -1 to a common length so that the contiguous workgroup
+// ranges xcd_remap() hands to each XCD coincide with these lists.
+// ----------------------------------------------------------------------------
+// key = (x * NP + p) * R + r  with block row i = 8 r + x ; counts of C blocks of row i in panel p
+__global__ void __launch_bounds__(256) order_count(const int* __restrict__ c_pre, const int* __restrict__ row_nnz, int nbr, int W, int PW,
+                                                   int NP, int R, int* __restrict__ cnt) {
+  const int key = blockIdx.x * blockDim.x + threadIdx.x;
+  if (key >= 8 * NP * R) return;
+  const int r = key % R, p = (key / R) % NP, x = key / (R * NP);
+  const int i = 8 * r + x;
+  int c = 0;
+  if (i < nbr) {
+    const int w0 = p * PW, w1 = (p + 1) * PW;
+    const int lo = w0 < W ? c_pre[(size_t)i * W + w0] : row_nnz[i];
+    const int hi = w1 < W ? c_pre[(size_t)i * W + w1] : row_nnz[i];
+    c = hi - lo;
+  }
+  cnt[key] = c;
+}
+
+// one wavefront per key: order[x * len + (base[key] - base[x's first key]) + t] = first C block of (i, p) + t
+__global__ void __launch_bounds__(256) order_fill(const int* __restrict__ c_pre, const int* __restrict__ row_nnz,
+                                                  const int* __restrict__ c_row_p, const int64_t* __restrict__ base, int nbr, int W, int PW,
+                                                  int NP, int R, int64_t len, int* __restrict__ order) {
+  const int lane = threadIdx.x & 63;
+  const int key = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (key >= 8 * NP * R) return;
+  const int r = key % R, p = (key / R) % NP, x = key / (R * NP);
+  const int i = 8 * r + x;
+  if (i >= nbr) return;
+  const int w0 = p * PW, w1 = (p + 1) * PW;
+  const int lo = w0 < W ? c_pre[(size_t)i * W + w0] : row_nnz[i];
+  const int hi = w1 < W ? c_pre[(size_t)i * W + w1] : row_nnz[i];
+  const int64_t dst = (int64_t)x * len + (base[key] - base[(size_t)x * NP * R]);
+  const int first = c_row_p[i] + lo;
+  for (int t = lane; t < hi - lo; t += 64) order[dst + t] = first + t;
+}
+
+// per-XCD totals -> common padded length (multiple of 4), written to out[0]
+__global__ void order_len(const int64_t* __restrict__ base, int64_t total, int NP, int R, int64_t* __restrict__ out) {
+  int64_t mx = 0;
+  for (int x = 0; x < 8; ++x) {
+    const int64_t b0 = base[(size_t)x * NP * R];
+    const int64_t b1 = x < 7 ? base[(size_t)(x + 1) * NP * R] : total;
+    mx = b1 - b0 > mx ? b1 - b0 : mx;
+  }
+  out[0] = (mx + 3) & ~(int64_t)3;
+}
+
 // ----------------------------------------------------------------------------
 // numeric kernels
 // ----------------------------------------------------------------------------
@@ -383,15 +551,19 @@ __global__ void __launch_bounds__(256) mm_numeric_f64(const Desc* __restrict__ d
 // slice (no barrier: one wave, in-order LDS queue) and reads fragments with
 // ds_read_b64; the next product's blocks are already in flight in registers
 // while the current one is multiplied.
-typedef double dpair __attribute__((ext_vector_type(2), aligned(8)));
-typedef double dpair16 __attribute__((ext_vector_type(2), aligned(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 template <int MA, int NC>
 __device__ __forceinline__ void cblock_f64_lds(const Desc& d, const Entry* __restrict__ entries, const double* __restrict__ a_data,
                                                const double* __restrict__ b_data, double* __restrict__ c_out,
                                                const double* __restrict__ c_in, double alpha, double beta, const LaneMap& L, int lane,
-                                               double* lds_a, double* lds_b) {
-  constexpr int CA = 2 * MA, CB = 2 * NC;  // 128-element chunks covering (8 MA) x 32 and 32 x (8 NC)
+                                               char* lds_a, char* lds_b, int dbg) {
+  // Staging in 1 KiB chunks (64 lanes x 16 B).  The loads are RAW BUFFER loads whose
+  // descriptor covers exactly one block: the hardware bounds check returns zeros past
+  // the block end, which (a) needs no address arithmetic or tail fix-up on the VALU
+  // (v3 profile: 284 VALU instructions per product against 54 MFMAs) and (b) zero-pads
+  // A's k dimension in LDS for free.  Chunk counts are wave-uniform.
+  constexpr int CA = 2 * MA, CB = 2 * NC;  // enough for (8 MA) x 32 and 32 x (8 NC) doubles
   double acc[MA][NC];
 #pragma unroll
   for (int a = 0; a < MA; ++a)
@@ -400,45 +572,43 @@ __device__ __forceinline__ void cblock_f64_lds(const Desc& d, const Entry* __res
   const int m = d.m, n = d.n;
   const Entry* e = entries + d.prod_start;
   const int cnt = d.prod_cnt;
-  dpair ra[CA], rb[CB];
+  u32x4 ra[CA], rb[CB];
+  const int voff = lane * 16;
   auto issue = [&](int p) {
-    const double* A = a_data + e[p].a_off;
-    const double* B = b_data + e[p].b_off;
     const int ks = (int)e[p].ks;
-    const int mk = m * ks, kn = ks * n;
+    const int abytes = m * ks * 8, bbytes = ks * n * 8;
+    const int nca = (m * ((ks + 3) & ~3) * 8 + 1023) >> 10, ncb = (bbytes + 1023) >> 10;
+    const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)(a_data + e[p].a_off), 0, abytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)(b_data + e[p].b_off), 0, bbytes, 0x00020000);
 #pragma unroll
-    for (int c = 0; c < CA; ++c) {
-      const int idx = (c * 64 + lane) * 2;
-      dpair v = {0.0, 0.0};
-      if (idx + 1 < mk) v = *reinterpret_cast<const dpair*>(A + idx);
-      else if (idx < mk) v.x = A[idx];
-      ra[c] = v;
-    }
+    for (int c = 0; c < CA; ++c)
+      if (c < nca) ra[c] = __builtin_amdgcn_raw_buffer_load_b128(rsa, voff, c * 1024, 0);
 #pragma unroll
-    for (int c = 0; c < CB; ++c) {
-      const int idx = (c * 64 + lane) * 2;
-      dpair v = {0.0, 0.0};
-      if (idx + 1 < kn) v = *reinterpret_cast<const dpair*>(B + idx);
-      else if (idx < kn) v.x = B[idx];
-      rb[c] = v;
-    }
+    for (int c = 0; c < CB; ++c)
+      if (c < ncb) rb[c] = __builtin_amdgcn_raw_buffer_load_b128(rsb, voff, c * 1024, 0);
   };
-  if (cnt > 0) issue(0);
+  // dbg (ablation switches for profiling, 0 in production): 1 = no global loads, 2 = no MFMA/LDS reads, 4 = no LDS writes
+  if (dbg & 1) {
+#pragma unroll
+    for (int c = 0; c < CA; ++c) ra[c] = u32x4{0u, 0x3ff00000u, 0u, 0x3ff00000u};
+#pragma unroll
+    for (int c = 0; c < CB; ++c) rb[c] = u32x4{0u, 0x3ff00000u, 0u, 0x3ff00000u};
+  }
+  if (cnt > 0 && !(dbg & 1)) issue(0);
   for (int p = 0; p < cnt; ++p) {
     const int ks = (int)e[p].ks;
-    const int mk = m * ks, kn = ks * n;
+    if (!(dbg & 4)) {
+      const int nca = (m * ((ks + 3) & ~3) * 8 + 1023) >> 10, ncb = (ks * n * 8 + 1023) >> 10;
 #pragma unroll
-    for (int c = 0; c < CA; ++c) {
-      const int idx = (c * 64 + lane) * 2;
-      if (idx < mk) *reinterpret_cast<dpair16*>(lds_a + idx) = ra[c];
-    }
+      for (int c = 0; c < CA; ++c)
+        if (c < nca) *reinterpret_cast<u32x4*>(lds_a + c * 1024 + voff) = ra[c];
 #pragma unroll
-    for (int c = 0; c < CB; ++c) {
-      const int idx = (c * 64 + lane) * 2;
-      if (idx < kn) *reinterpret_cast<dpair16*>(lds_b + idx) = rb[c];
+      for (int c = 0; c < CB; ++c)
+        if (c < ncb) *reinterpret_cast<u32x4*>(lds_b + c * 1024 + voff) = rb[c];
     }
-    if (p + 1 < cnt) issue(p + 1);
-    block_product_f64<MA, NC, false>(acc, lds_a, lds_b, m, n, ks, L, 0, 0);
+    if (p + 1 < cnt && !(dbg & 1)) issue(p + 1);
+    if (!(dbg & 2))
+      block_product_f64_lds<MA, NC>(acc, reinterpret_cast<const double*>(lds_a), reinterpret_cast<const double*>(lds_b), m, n, ks, L);
   }
   double* C = c_out + d.c_off;
   const bool has_in = d.cin_off >= 0;
@@ -451,7 +621,7 @@ __device__ __forceinline__ void cblock_f64_lds(const Desc& d, const Entry* __res
       if (row < m && col < n) {
         double v = alpha * acc[a][c];
         if (has_in) v += beta * Ci[row + (size_t)m * col];
-        C[row + (size_t)m * col] = v;
+        __builtin_nontemporal_store(v, &C[row + (size_t)m * col]);  // C is written once and not re-read here
       }
     }
 }
@@ -462,15 +632,16 @@ template <int MAXT>
 __global__ void __launch_bounds__(256) mm_numeric_f64_lds(const Desc* __restrict__ descs, int64_t nblk, const Entry* __restrict__ entries,
                                                           const double* __restrict__ a_data, const double* __restrict__ b_data,
                                                           double* __restrict__ c_out, const double* __restrict__ c_in, double alpha,
-                                                          double beta, int lds_a_doubles, int lds_wave_doubles) {
+                                                          double beta, int lds_a_doubles, int lds_wave_doubles, int dbg, const int* __restrict__ order) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int64_t cb = (int64_t)wg * 4 + wid;
-  if (cb >= nblk) return;
-  double* lds_a = reinterpret_cast<double*>(smem) + (size_t)wid * lds_wave_doubles;
-  double* lds_b = lds_a + lds_a_doubles;
+  const int64_t pos = (int64_t)wg * 4 + wid;  // gridDim.x * 4 == padded length of order[]
+  const int64_t cb = order[pos];
+  if (cb < 0 || cb >= nblk) return;
+  char* lds_a = smem + (size_t)wid * lds_wave_doubles * 8;
+  char* lds_b = lds_a + (size_t)lds_a_doubles * 8;
   const Desc d = descs[cb];
   const LaneMap L(lane);
   const int MA = (d.m + 7) >> 3, NC = (d.n + 7) >> 3;
@@ -478,7 +649,7 @@ __global__ void __launch_bounds__(256) mm_numeric_f64_lds(const Desc* __restrict
 #define DBCSR_CASE(A_, C_)                                                                                           \
   case A_ * 4 + C_:                                                                                                  \
     if constexpr (A_ <= MAXT && C_ <= MAXT)                                                                          \
-      cblock_f64_lds<A_, C_>(d, entries, a_data, b_data, c_out, c_in, alpha, beta, L, lane, lds_a, lds_b);          \
+      cblock_f64_lds<A_, C_>(d, entries, a_data, b_data, c_out, c_in, alpha, beta, L, lane, lds_a, lds_b, dbg);          \
     break;
     DBCSR_CASE(1, 1) DBCSR_CASE(1, 2) DBCSR_CASE(1, 3) DBCSR_CASE(1, 4)
     DBCSR_CASE(2, 1) DBCSR_CASE(2, 2) DBCSR_CASE(2, 3) DBCSR_CASE(2, 4)
@@ -489,13 +660,22 @@ __global__ void __launch_bounds__(256) mm_numeric_f64_lds(const Desc* __restrict
   }
 }
 
-// max of an int array (block sizes) into out[slot]
+// max and (negated) min of an int array (block sizes): out[0] = max v, out[1] = max -v
 __global__ void __launch_bounds__(256) max_of(const int* __restrict__ v, int n, int* __restrict__ out) {
-  int mx = 0;
-  for (int i = threadIdx.x; i < n; i += 256) mx = max(mx, v[i]);
+  int mx = 0, mn = -0x7fffffff;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    mx = max(mx, v[i]);
+    mn = max(mn, -v[i]);
+  }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) mx = max(mx, __shfl_down(mx, off, 64));
-  if ((threadIdx.x & 63) == 0) atomicMax(out, mx);
+  for (int off = 32; off > 0; off >>= 1) {
+    mx = max(mx, __shfl_down(mx, off, 64));
+    mn = max(mn, __shfl_down(mn, off, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMax(out, mx);
+    atomicMax(out + 1, mn);
+  }
 }
 
 __global__ void __launch_bounds__(256) mm_numeric_f32(const Desc* __restrict__ descs, int64_t nblk, const Entry* __restrict__ entries,
@@ -758,6 +938,10 @@ struct Engine {
   DevBuf<Entry> entries;
   DevBuf<Desc> descs;
   DevBuf<double> row_sums;
+  DevBuf<int> order, order_cnt;
+  DevBuf<int64_t> order_base;
+  int64_t order_len = 0;
+  int64_t panel_bytes = 96ll << 20;  // DBCSR_AMD_MM_PANEL_MB: target size of a B column panel
   DevBuf<unsigned long long> dev_scalars;
   int64_t* host_scalars = nullptr;  // pinned: [0]=c_nblks [1]=c_nze [2]=nproducts [3]=flop
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};  // around fill_products and the numeric kernel
@@ -766,7 +950,9 @@ struct Engine {
   int nbr = 0, W = 0;
   int64_t c_nblks = 0, nproducts = 0;
   bool have_cin = false, retain = false, valid = false;
-  int max_m = 0, max_k = 0, max_n = 0;
+  int max_m = 0, max_k = 0, max_n = 0, min_m = 0, min_k = 0, min_n = 0;
+  bool grid_kernels = false, force_word_kernels = false;  // DBCSR_AMD_MM_SYMBOLIC=word forces the per-word symbolic kernels
+  int dbg = 0;      // DBCSR_AMD_MM_DBG: ablation switches of the LDS kernel (profiling only)
   int use_lds = 1;  // DBCSR_AMD_MM_KERNEL=direct selects the v1 kernel (A/B experiments)
 };
 
@@ -797,12 +983,15 @@ int dbcsr_amd_mm_create(void** handle) {
   if (!handle) return -1;
   Engine* E = new (std::nothrow) Engine();
   if (!E) return -1;
-  hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&E->host_scalars), 8 * sizeof(int64_t), hipHostMallocDefault);
+  hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&E->host_scalars), 16 * sizeof(int64_t), hipHostMallocDefault);
   if (e != hipSuccess) {
     delete E;
     return check(e, "hipHostMalloc", __FILE__, __LINE__);
   }
   if (const char* k = getenv("DBCSR_AMD_MM_KERNEL")) E->use_lds = strcmp(k, "direct") != 0;
+  if (const char* k = getenv("DBCSR_AMD_MM_DBG")) E->dbg = atoi(k);
+  if (const char* k = getenv("DBCSR_AMD_MM_SYMBOLIC")) E->force_word_kernels = strcmp(k, "word") == 0;
+  if (const char* k = getenv("DBCSR_AMD_MM_PANEL_MB")) E->panel_bytes = (int64_t)atoll(k) << 20;
   for (int i = 0; i < 3; ++i) {
     e = hipEventCreate(&E->ev[i]);
     if (e != hipSuccess) return check(e, "hipEventCreate", __FILE__, __LINE__);
@@ -831,6 +1020,7 @@ int dbcsr_amd_mm_destroy(void* handle) {
   E->blk_nze.release(); E->tmp_i32.release();
   E->prod_start.release(); E->c_blk_p_ws.release(); E->partial.release(); E->off_a.release(); E->off_b.release();
   E->entries.release(); E->descs.release(); E->row_sums.release(); E->dev_scalars.release();
+  E->order.release(); E->order_cnt.release(); E->order_base.release();
   if (E->host_scalars) (void)hipHostFree(E->host_scalars);
   for (int i = 0; i < 3; ++i)
     if (E->ev[i]) (void)hipEventDestroy(E->ev[i]);
@@ -855,10 +1045,14 @@ int dbcsr_amd_mm_symbolic(void* handle, const dbcsr_amd_bcsr* a, const dbcsr_amd
   E->retain = retain_sparsity != 0;
   E->have_cin = c_in->nblks > 0;
   if (E->b_bm.ensure((size_t)nbk * W + 1) || E->b_pre.ensure((size_t)nbk * W + 1) || E->c_bm.ensure((size_t)nbr * W + 1) ||
-      E->c_pre.ensure((size_t)nbr * W + 1) || E->row_nnz.ensure((size_t)nbr + 1) || E->dev_scalars.ensure(8))
+      E->c_pre.ensure((size_t)nbr * W + 1) || E->row_nnz.ensure((size_t)nbr + 1) || E->dev_scalars.ensure(16))
     return -1;
   if (E->have_cin && (E->cin_bm.ensure((size_t)nbr * W + 1) || E->cin_pre.ensure((size_t)nbr * W + 1))) return -1;
-  ACC_CHECK(hipMemsetAsync(E->dev_scalars.p, 0, 8 * sizeof(unsigned long long), st));
+  ACC_CHECK(hipMemsetAsync(E->dev_scalars.p, 0, 16 * sizeof(unsigned long long), st));
+  {  // the "negated min" slots start at the most negative value
+    static const int init[6] = {0, -0x7fffffff, 0, -0x7fffffff, 0, -0x7fffffff};
+    ACC_CHECK(hipMemcpyAsync(E->dev_scalars.p + 4, init, sizeof(init), hipMemcpyHostToDevice, st));
+  }
   if (nbr == 0 || nbc == 0) {
     ACC_CHECK(hipMemsetAsync(c_out_row_p, 0, sizeof(int32_t) * ((size_t)nbr + 1), st));
     ACC_CHECK(hipStreamSynchronize(st));
@@ -886,13 +1080,6 @@ int dbcsr_amd_mm_symbolic(void* handle, const dbcsr_amd_bcsr* a, const dbcsr_amd
   hipLaunchKernelGGL(row_prefix, grid_for((int64_t)nbr * 64), dim3(256), 0, st, E->c_bm.p, nbr, W, E->c_pre.p, E->row_nnz.p);
   int64_t* dsc = reinterpret_cast<int64_t*>(E->dev_scalars.p);
   if (exclusive_scan<int32_t>(E, E->row_nnz.p, nbr, c_out_row_p, dsc + 0, true, st)) return -1;
-  // need c_nblks on the host to size per-block work arrays
-  ACC_CHECK(hipMemcpyAsync(E->host_scalars, dsc, sizeof(int64_t), hipMemcpyDeviceToHost, st));
-  ACC_CHECK(hipStreamSynchronize(st));
-  const int64_t c_nblks = E->host_scalars[0];
-  if (E->prod_cnt.ensure((size_t)c_nblks + 1) || E->blk_nze.ensure((size_t)c_nblks + 1) || E->prod_start.ensure((size_t)c_nblks + 1) ||
-      E->c_blk_p_ws.ensure((size_t)c_nblks + 1))
-    return -1;
   // block-size maxima (LDS slice size / kernel choice of the numeric phase)
   {
     int* mx = reinterpret_cast<int*>(E->dev_scalars.p + 4);
@@ -900,17 +1087,54 @@ int dbcsr_amd_mm_symbolic(void* handle, const dbcsr_amd_bcsr* a, const dbcsr_amd
     hipLaunchKernelGGL(max_of, dim3(1), dim3(256), 0, st, a->col_blk_size, nbk, mx + 2);
     hipLaunchKernelGGL(max_of, dim3(1), dim3(256), 0, st, b->col_blk_size, nbc, mx + 4);
   }
+  // need c_nblks (and the block-size extrema) on the host to size per-block work arrays
+  ACC_CHECK(hipMemcpyAsync(E->host_scalars, dsc, 8 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+  ACC_CHECK(hipStreamSynchronize(st));
+  const int64_t c_nblks = E->host_scalars[0];
+  {
+    const int* mx = reinterpret_cast<const int*>(E->host_scalars + 4);
+    E->max_m = mx[0]; E->min_m = -mx[1];
+    E->max_k = mx[2]; E->min_k = -mx[3];
+    E->max_n = mx[4]; E->min_n = -mx[5];
+  }
+  // processing order of the numeric phase: column panels sized for the Infinity Cache, rows dealt to XCDs
+  const int64_t b_bytes_est = b->nblks * (int64_t)E->max_k * E->max_n * (int64_t)sizeof(double);
+  int NP = (int)std::min<int64_t>((b_bytes_est + E->panel_bytes - 1) / E->panel_bytes, (int64_t)W);
+  if (NP < 1) NP = 1;
+  const int PW = (W + NP - 1) / NP;
+  NP = (W + PW - 1) / PW;
+  const int R = (nbr + 7) / 8;
+  const int nkeys = 8 * NP * R;
+  if (E->order_cnt.ensure((size_t)nkeys + 1) || E->order_base.ensure((size_t)nkeys + 1)) return -1;
+  hipLaunchKernelGGL(order_count, grid_for(nkeys), dim3(256), 0, st, E->c_pre.p, E->row_nnz.p, nbr, W, PW, NP, R, E->order_cnt.p);
+  if (exclusive_scan<int64_t>(E, E->order_cnt.p, nkeys, E->order_base.p, nullptr, false, st)) return -1;
+  hipLaunchKernelGGL(order_len, dim3(1), dim3(1), 0, st, E->order_base.p, c_nblks, NP, R, dsc + 7);
+  if (E->prod_cnt.ensure((size_t)c_nblks + 1) || E->blk_nze.ensure((size_t)c_nblks + 1) || E->prod_start.ensure((size_t)c_nblks + 1) ||
+      E->c_blk_p_ws.ensure((size_t)c_nblks + 1))
+    return -1;
   // 3. per C block: number of products, size; flop
-  hipLaunchKernelGGL(count_products, grid_for((int64_t)nbr * W), dim3(256), 0, st, a->row_p, a->col_i, a->row_blk_size,
-                     a->col_blk_size, b->col_blk_size, E->b_bm.p, E->c_bm.p, E->c_pre.p, c_out_row_p, nbr, W, E->prod_cnt.p,
-                     E->blk_nze.p, E->dev_scalars.p + 3);
+  // one lane per (row, column) candidate unless C is extremely sparse (then one thread per bitmap word)
+  const int nJ = (nbc + 63) / 64;
+  E->grid_kernels = ((int64_t)nbr * nJ * 64 <= 256 * std::max<int64_t>(c_nblks, 1)) && !E->force_word_kernels;
+  if (E->grid_kernels)
+    hipLaunchKernelGGL(count_products_grid, grid_for((int64_t)nbr * nJ * 64), dim3(256), 0, st, a->row_p, a->col_i, a->row_blk_size,
+                       a->col_blk_size, b->col_blk_size, E->b_bm.p, E->c_bm.p, E->c_pre.p, c_out_row_p, nbr, nbc, W, nJ,
+                       E->prod_cnt.p, E->blk_nze.p, E->dev_scalars.p + 3);
+  else
+    hipLaunchKernelGGL(count_products, grid_for((int64_t)nbr * W), dim3(256), 0, st, a->row_p, a->col_i, a->row_blk_size,
+                       a->col_blk_size, b->col_blk_size, E->b_bm.p, E->c_bm.p, E->c_pre.p, c_out_row_p, nbr, W, E->prod_cnt.p,
+                       E->blk_nze.p, E->dev_scalars.p + 3);
   if (exclusive_scan<int64_t>(E, E->prod_cnt.p, c_nblks, E->prod_start.p, dsc + 2, false, st)) return -1;
   if (exclusive_scan<int64_t>(E, E->blk_nze.p, c_nblks, E->c_blk_p_ws.p, dsc + 1, false, st)) return -1;
-  ACC_CHECK(hipMemcpyAsync(E->host_scalars, dsc, 7 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+  ACC_CHECK(hipMemcpyAsync(E->host_scalars, dsc, 8 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
   ACC_CHECK(hipStreamSynchronize(st));
-  E->max_m = (int)E->host_scalars[4];
-  E->max_k = (int)E->host_scalars[5];
-  E->max_n = (int)E->host_scalars[6];
+  E->order_len = E->host_scalars[7];
+  if (E->order.ensure((size_t)(8 * E->order_len) + 64)) return -1;
+  if (E->order_len > 0) {
+    ACC_CHECK(hipMemsetAsync(E->order.p, 0xff, sizeof(int) * (size_t)(8 * E->order_len), st));
+    hipLaunchKernelGGL(order_fill, grid_for((int64_t)nkeys * 64), dim3(256), 0, st, E->c_pre.p, E->row_nnz.p, c_out_row_p,
+                       E->order_base.p, nbr, W, PW, NP, R, E->order_len, E->order.p);
+  }
   counts->c_nblks = E->host_scalars[0];
   counts->c_nze = E->host_scalars[1];
   counts->nproducts = E->host_scalars[2];
@@ -935,24 +1159,36 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
   if (nblk == 0) return 0;
   if (E->entries.ensure((size_t)E->nproducts + 1) || E->descs.ensure((size_t)nblk + 1)) return -1;
   ACC_CHECK(hipEventRecord(E->ev[0], st));
-  hipLaunchKernelGGL(fill_products, grid_for((int64_t)nbr * W), dim3(256), 0, st, a->row_p, a->col_i, a->blk_p, b->row_p, b->blk_p,
-                     c_in->row_p, c_in->blk_p, a->row_blk_size, a->col_blk_size, b->col_blk_size, E->b_bm.p, E->b_pre.p,
-                     E->have_cin ? E->cin_bm.p : (const uint32_t*)nullptr, E->have_cin ? E->cin_pre.p : (const int*)nullptr,
-                     E->c_bm.p, E->c_pre.p, c_out->row_p, E->prod_start.p, E->c_blk_p_ws.p, nbr, W, c_out->col_i, c_out->blk_p,
-                     E->descs.p, E->entries.p);
+  if (E->grid_kernels) {
+    const int nbc = b->nblkcols, nJ = (nbc + 63) / 64;
+    hipLaunchKernelGGL(fill_products_grid, grid_for((int64_t)nbr * nJ * 64), dim3(256), 0, st, a->row_p, a->col_i, a->blk_p, b->row_p,
+                       b->blk_p, c_in->row_p, c_in->blk_p, a->row_blk_size, a->col_blk_size, b->col_blk_size, E->b_bm.p, E->b_pre.p,
+                       E->have_cin ? E->cin_bm.p : (const uint32_t*)nullptr, E->have_cin ? E->cin_pre.p : (const int*)nullptr,
+                       E->c_bm.p, E->c_pre.p, c_out->row_p, E->prod_start.p, E->c_blk_p_ws.p, nbr, nbc, W, nJ, c_out->col_i,
+                       c_out->blk_p, E->descs.p, E->entries.p);
+  } else {
+    hipLaunchKernelGGL(fill_products, grid_for((int64_t)nbr * W), dim3(256), 0, st, a->row_p, a->col_i, a->blk_p, b->row_p, b->blk_p,
+                       c_in->row_p, c_in->blk_p, a->row_blk_size, a->col_blk_size, b->col_blk_size, E->b_bm.p, E->b_pre.p,
+                       E->have_cin ? E->cin_bm.p : (const uint32_t*)nullptr, E->have_cin ? E->cin_pre.p : (const int*)nullptr,
+                       E->c_bm.p, E->c_pre.p, c_out->row_p, E->prod_start.p, E->c_blk_p_ws.p, nbr, W, c_out->col_i, c_out->blk_p,
+                       E->descs.p, E->entries.p);
+  }
   const unsigned nwg = (unsigned)((nblk + 3) / 4);
   ACC_CHECK(hipEventRecord(E->ev[1], st));
   if (datatype == dbcsr_type_real_8) {
-    const bool small = E->max_m <= 32 && E->max_k <= 32 && E->max_n <= 32;
+    // LDS path: blocks of at most 32 x 32 (any smaller size: the staging loads are bounds-checked buffer loads)
+    const bool small = E->max_m <= 32 && E->max_k <= 32 && E->max_n <= 32 && E->min_m >= 1 && E->min_k >= 1 && E->min_n >= 1;
     if (small && E->use_lds) {
-      const int lds_a = (E->max_m * E->max_k + 1) & ~1, lds_b = (E->max_k * E->max_n + 1) & ~1;
+      // per-wave LDS slice: whole 1 KiB staging chunks (128 doubles) for the largest A (k padded to 4) and B block
+      const int lds_a = ((E->max_m * ((E->max_k + 3) & ~3) + 127) / 128) * 128, lds_b = ((E->max_k * E->max_n + 127) / 128) * 128;
       const int lds_wave = lds_a + lds_b;
       const int maxt = (std::max(E->max_m, E->max_n) + 7) / 8;
       const size_t lds_bytes = (size_t)4 * lds_wave * sizeof(double);
+      const unsigned nwg_o = (unsigned)(8 * E->order_len / 4);
 #define DBCSR_LAUNCH(T_)                                                                                                        \
-  hipLaunchKernelGGL(mm_numeric_f64_lds<T_>, dim3(nwg), dim3(256), lds_bytes, st, E->descs.p, nblk, E->entries.p,               \
+  hipLaunchKernelGGL(mm_numeric_f64_lds<T_>, dim3(nwg_o), dim3(256), lds_bytes, st, E->descs.p, nblk, E->entries.p,               \
                      static_cast<const double*>(a->data), static_cast<const double*>(b->data), static_cast<double*>(c_out->data), \
-                     static_cast<const double*>(c_in->data), alpha, beta, lds_a, lds_wave)
+                     static_cast<const double*>(c_in->data), alpha, beta, lds_a, lds_wave, E->dbg, E->order.p)
       switch (maxt) {
         case 1: DBCSR_LAUNCH(1); break;
         case 2: DBCSR_LAUNCH(2); break;

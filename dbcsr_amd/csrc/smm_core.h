@@ -102,6 +102,56 @@ __device__ __forceinline__ void block_product_f64(double (&acc)[MA][NC], const d
   }
 }
 
+// Same product with both operands already staged in LDS: A as an m x k4 column-major
+// block whose columns k..k4-1 (k4 = k rounded up to 4) are EXACT ZEROS, B as stored
+// (k x n column-major).  Lanes whose k index is past the end read A's zero padding and
+// a clamped (valid, finite) B element, so they contribute exact zeros without any
+// select on loaded values -- which lets the operand fetches of step s+1 stay in flight
+// under the MFMAs of step s (two-stage software pipeline).
+template <int MA, int NC>
+__device__ __forceinline__ void block_product_f64_lds(double (&acc)[MA][NC], const double* lds_a, const double* lds_b, int m,
+                                                      int n, int k, const LaneMap& L) {
+  int aoff[MA], boff[NC];
+#pragma unroll
+  for (int a = 0; a < MA; ++a) {
+    int row = 8 * a + L.rowl;
+    row = row < m ? row : m - 1;
+    aoff[a] = row + m * L.kq;
+  }
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    int col = 8 * c + L.coll;
+    col = col < n ? col : n - 1;
+    boff[c] = L.kq + k * col;
+  }
+  const int nsteps = (k + 3) >> 2;
+  const int astep = 4 * m;
+  const int klast = k - 1 - L.kq;  // 4*s <= klast  <=>  this lane's k index is inside the block
+  auto fetch = [&](int s, double (&av)[MA], double (&bv)[NC]) {
+#pragma unroll
+    for (int a = 0; a < MA; ++a) av[a] = lds_a[aoff[a] + s * astep];
+    const int bs = 4 * s <= klast ? 4 * s : -L.kq;  // past the end: element (0, col), always valid
+#pragma unroll
+    for (int c = 0; c < NC; ++c) bv[c] = lds_b[boff[c] + bs];
+  };
+  auto mma = [&](const double (&av)[MA], const double (&bv)[NC]) {
+#pragma unroll
+    for (int a = 0; a < MA; ++a)
+#pragma unroll
+      for (int c = 0; c < NC; ++c) acc[a][c] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[a], bv[c], acc[a][c], 0, 0, 0);
+  };
+  double av0[MA], bv0[NC], av1[MA], bv1[NC];
+  fetch(0, av0, bv0);
+  int s = 0;
+  for (; s + 2 <= nsteps; s += 2) {
+    fetch(s + 1, av1, bv1);
+    mma(av0, bv0);
+    if (s + 2 < nsteps) fetch(s + 2, av0, bv0);
+    mma(av1, bv1);
+  }
+  if (s < nsteps) mma(av0, bv0);
+}
+
 // fp32 core on v_mfma_f32_32x32x2_f32: one instruction covers a whole block of
 // up to 32 x 32 for 2 k.  lane l: A[i = l & 31][k = l >> 5], B[k = l >> 5][j = l & 31];
 // result register r (0..15): col = l & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5).
