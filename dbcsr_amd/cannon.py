@@ -1,0 +1,261 @@
+"""Multi-GPU block-sparse multiply: the 2-D distributed algorithm of
+``multiply_cannon`` (reference src/mm/dbcsr_mm_cannon.F:839-1771, image
+distributions of src/dist/dbcsr_dist_methods.F:423-454), one process per GPU.
+
+What is kept from the reference: the 2-D block distribution of C over an
+``nprows x npcols`` grid (block rows/columns binned by size, dbcsr_dist_bin,
+src/dist/dbcsr_dist_operations.F:708-745), C stationary, A and B cut into
+``nvirt = lcm(nprows, npcols)`` virtual k-images, the skewed schedule (rank (r, c)
+multiplies image ``v = (r + c + t) mod nvirt`` at tick t) so that every tick each
+rank needs exactly one A image from its process row and one B image from its
+process column, and double buffering of the next tick's panels against the
+current tick's local multiply.
+
+What is MI355X-native: panels are fetched DIRECTLY FROM THEIR OWNER with RCCL
+send/recv (every GPU pair of a node has its own xGMI link, so a ring that forwards
+panels hop by hop would only add hops), on the communication stream of
+torch.distributed while the local multiply runs on the compute stream; index
+metadata never travels (every rank derives all image indices from the replicated
+block pattern), only block data does; C's structure for all ticks is computed
+once on the GPU and the ticks accumulate in place.
+
+The local engine is duck-typed (``symbolic``, ``init_c``, ``accumulate``,
+``fill_random_dist`` of dbcsr_amd.multiply.MultiplyEngine) so that the
+distribution / schedule / communication logic can be exercised on CPU with the
+``gloo`` backend in tests.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import randmat
+from .matrix import DbcsrMatrix
+
+
+def dims_create(n):
+    """MPI_Dims_create-like 2-D factorisation, non-increasing (8 -> 4 x 2), as the reference's
+    default grid (src/mpi/dbcsr_mpiwrap.F:1107)."""
+    d = int(math.isqrt(n))
+    while n % d:
+        d -= 1
+    return n // d, d
+
+
+def dist_bin(sizes, nbins):
+    """Greedy least-loaded binning of elements in order (dbcsr_dist_bin); ties go to the lowest bin."""
+    load = np.zeros(nbins, np.int64)
+    out = np.empty(len(sizes), np.int32)
+    for i, s in enumerate(sizes):
+        b = int(np.argmin(load))
+        out[i] = b
+        load[b] += int(s)
+    return out
+
+
+class Grid:
+    def __init__(self, world, rank, nprows=None, npcols=None, nvirt=None):
+        if nprows is None:
+            nprows, npcols = dims_create(world)
+        assert nprows * npcols == world
+        self.world, self.rank, self.nprows, self.npcols = world, rank, nprows, npcols
+        self.myprow, self.mypcol = divmod(rank, npcols)
+        lcm = nprows * npcols // math.gcd(nprows, npcols)
+        self.nvirt = lcm if nvirt is None else nvirt  # any multiple of lcm works (more, thinner k-images)
+        assert self.nvirt % lcm == 0
+
+    def rank_of(self, prow, pcol):
+        return prow * self.npcols + pcol
+
+    def v_at(self, prow, pcol, tick):
+        return (prow + pcol + tick) % self.nvirt
+
+    def a_owner(self, prow, v):
+        return self.rank_of(prow, v % self.npcols)
+
+    def b_owner(self, v, pcol):
+        return self.rank_of(v % self.nprows, pcol)
+
+
+class Partition:
+    """Block rows/columns/k-blocks -> process rows/columns/virtual images, with local numbering."""
+
+    def __init__(self, row_sizes, k_sizes, col_sizes, grid):
+        self.row_sizes, self.k_sizes, self.col_sizes = (np.asarray(x, np.int32) for x in (row_sizes, k_sizes, col_sizes))
+        self.row_dist = dist_bin(self.row_sizes, grid.nprows)
+        self.col_dist = dist_bin(self.col_sizes, grid.npcols)
+        self.k_dist = dist_bin(self.k_sizes, grid.nvirt)
+        self.rows_of = [np.nonzero(self.row_dist == r)[0].astype(np.int32) for r in range(grid.nprows)]
+        self.cols_of = [np.nonzero(self.col_dist == c)[0].astype(np.int32) for c in range(grid.npcols)]
+        self.ks_of = [np.nonzero(self.k_dist == v)[0].astype(np.int32) for v in range(grid.nvirt)]
+        self.row_local = self._local(self.row_dist, self.rows_of)
+        self.col_local = self._local(self.col_dist, self.cols_of)
+        self.k_local = self._local(self.k_dist, self.ks_of)
+
+    @staticmethod
+    def _local(dist_arr, groups):
+        loc = np.empty(len(dist_arr), np.int32)
+        for g in groups:
+            loc[g] = np.arange(len(g), dtype=np.int32)
+        return loc
+
+
+def _sub_index(rows, cols, keep, row_local, col_local, nrows_local, row_sizes, col_sizes):
+    """BCSR index (row_p, col_i, blk_p, nze) of the kept blocks in local numbering.  The global
+    pattern is sorted by (row, col) and local ids are monotone in global ids, so order is kept."""
+    r, c = row_local[rows[keep]], col_local[cols[keep]]
+    nze = row_sizes[rows[keep]].astype(np.int64) * col_sizes[cols[keep]].astype(np.int64)
+    blk_p = np.zeros(len(r), np.int64)
+    if len(r):
+        blk_p[1:] = np.cumsum(nze)[:-1]
+    row_p = np.zeros(nrows_local + 1, np.int64)
+    np.add.at(row_p, r.astype(np.int64) + 1, 1)
+    return np.cumsum(row_p).astype(np.int32), c.astype(np.int32), blk_p, int(nze.sum())
+
+
+class CannonMultiply:
+    """Distributed C <- beta*C + alpha*A*B on synthetic matrices of the reference's generator.
+
+    Every rank builds the same global block patterns (host, O(nblks)) and materialises only its
+    own part: its C tile, its A images (process row r, images v = c mod npcols) and its B images
+    (process column c, images v = r mod nprows); values are generated in HBM."""
+
+    def __init__(self, M, N, K, sparsities, mix, dtype=torch.float64, engine=None, device=None, grid=None, mix_n=None, mix_k=None):
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        self.grid = grid or Grid(world, rank)
+        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.dtype = dtype
+        if engine is None:
+            from .multiply import default_engine
+            engine = default_engine()
+        self.eng = engine
+        g = self.grid
+        sm = randmat.make_random_block_sizes(M, mix)
+        sn = randmat.make_random_block_sizes(N, mix_n or mix)
+        sk = randmat.make_random_block_sizes(K, mix_k or mix)
+        self.part = P = Partition(sm, sk, sn, g)
+        c0 = randmat.RANDMAT_SEED_INIT
+        # global patterns, identical on every rank (C, A, B in the reference driver's order)
+        self.pat = {"C": randmat.random_pattern(len(sm), len(sn), sparsities[2], c0 + 1),
+                    "A": randmat.random_pattern(len(sm), len(sk), sparsities[0], c0 + 2),
+                    "B": randmat.random_pattern(len(sk), len(sn), sparsities[1], c0 + 3)}
+        self.counters = {"C": c0 + 1, "A": c0 + 2, "B": c0 + 3}
+        self.nbr_g, self.nbk_g, self.nbc_g = len(sm), len(sk), len(sn)
+        r, c = g.myprow, g.mypcol
+        t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt).to(self.device)
+        self._rs = t(sm[P.rows_of[r]], torch.int32)
+        self._cs = t(sn[P.cols_of[c]], torch.int32)
+        self._ks = [t(sk[P.ks_of[v]], torch.int32) for v in range(g.nvirt)]
+        self._ks_all = t(sk, torch.int32)
+        self._row_gid = t(P.rows_of[r], torch.int32)
+        self._col_gid = t(P.cols_of[c], torch.int32)
+        self._k_gid = [t(P.ks_of[v], torch.int32) for v in range(g.nvirt)]
+        self._k_gid_all = t(np.arange(len(sk), dtype=np.int32), torch.int32)
+        # my C tile
+        self.C_in = self._make("C", P.row_dist, r, P.col_dist, c, P.row_local, P.col_local, len(P.rows_of[r]), self._rs, self._cs,
+                               sm, sn, self._row_gid, self._col_gid, self.nbr_g, fill=True)
+        # index of every image this rank will ever multiply with; data only for the owned ones
+        self.A_img, self.B_img = {}, {}
+        for v in range(g.nvirt):
+            own_a = g.a_owner(r, v) == g.rank
+            self.A_img[v] = self._make("A", P.row_dist, r, P.k_dist, v, P.row_local, P.k_local, len(P.rows_of[r]), self._rs,
+                                       self._ks[v], sm, sk, self._row_gid, self._k_gid[v], self.nbr_g, fill=own_a)
+            own_b = g.b_owner(v, c) == g.rank
+            self.B_img[v] = self._make("B", P.k_dist, v, P.col_dist, c, P.k_local, P.col_local, len(P.ks_of[v]), self._ks[v],
+                                       self._cs, sk, sn, self._k_gid[v], self._col_gid, self.nbk_g, fill=own_b)
+        # full-panel patterns (no data) for the one-off symbolic product that fixes C's structure
+        all_k_local = np.arange(len(sk), dtype=np.int32)
+        self.A_panel = self._make("A", P.row_dist, r, np.zeros(len(sk), np.int32), 0, P.row_local, all_k_local, len(P.rows_of[r]),
+                                  self._rs, self._ks_all, sm, sk, None, None, 0, fill=None)
+        self.B_panel = self._make("B", np.zeros(len(sk), np.int32), 0, P.col_dist, c, all_k_local, P.col_local, len(sk), self._ks_all,
+                                  self._cs, sk, sn, None, None, 0, fill=None)
+        # double-buffered receive space for A and B panels
+        amax = max([m.data_numel for v, m in self.A_img.items() if g.a_owner(r, v) != g.rank] + [0])
+        bmax = max([m.data_numel for v, m in self.B_img.items() if g.b_owner(v, c) != g.rank] + [0])
+        self._abuf = [torch.empty(amax, dtype=dtype, device=self.device) for _ in range(2)]
+        self._bbuf = [torch.empty(bmax, dtype=dtype, device=self.device) for _ in range(2)]
+
+    def _make(self, which, rdist, rsel, cdist, csel, rloc, cloc, nrows_local, rs_t, cs_t, rsizes, csizes, rgid, cgid, nrow_global, fill):
+        rows, cols = self.pat[which]
+        keep = (rdist[rows] == rsel) & (cdist[cols] == csel)
+        row_p, col_i, blk_p, nze = _sub_index(rows, cols, keep, rloc, cloc, nrows_local, rsizes, csizes)
+        t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt).to(self.device)
+        data = torch.empty(nze if fill else 0, dtype=self.dtype, device=self.device)
+        M = DbcsrMatrix(rs_t, cs_t, t(row_p, torch.int32), t(col_i, torch.int32), t(blk_p, torch.int64), data, which)
+        M.data_numel = nze
+        if fill and nze:
+            self.eng.fill_random_dist(M, self.counters[which], rgid, cgid, nrow_global)
+        return M
+
+    # ------------------------------------------------------------------
+    def _post(self, tick, parity):
+        """Send/receive the panels of `tick`.  Returns (ops work handles, A data, B data)."""
+        g, r, c = self.grid, self.grid.myprow, self.grid.mypcol
+        ops = []
+        v = g.v_at(r, c, tick)
+        a_src, b_src = g.a_owner(r, v), g.b_owner(v, c)
+        a_data = self.A_img[v].data if a_src == g.rank else self._abuf[parity][:self.A_img[v].data_numel]
+        b_data = self.B_img[v].data if b_src == g.rank else self._bbuf[parity][:self.B_img[v].data_numel]
+        # what the others need from me at this tick
+        for pc in range(g.npcols):  # my process row: A images I own
+            if pc == c:
+                continue
+            vv = g.v_at(r, pc, tick)
+            if g.a_owner(r, vv) == g.rank and self.A_img[vv].data_numel:
+                ops.append(dist.P2POp(dist.isend, self.A_img[vv].data, g.rank_of(r, pc)))
+        for pr in range(g.nprows):  # my process column: B images I own
+            if pr == r:
+                continue
+            vv = g.v_at(pr, c, tick)
+            if g.b_owner(vv, c) == g.rank and self.B_img[vv].data_numel:
+                ops.append(dist.P2POp(dist.isend, self.B_img[vv].data, g.rank_of(pr, c)))
+        if a_src != g.rank and self.A_img[v].data_numel:
+            ops.append(dist.P2POp(dist.irecv, a_data, a_src))
+        if b_src != g.rank and self.B_img[v].data_numel:
+            ops.append(dist.P2POp(dist.irecv, b_data, b_src))
+        works = dist.batch_isend_irecv(ops) if ops else []
+        return works, v, a_data, b_data
+
+    def multiply(self, alpha=1.0, beta=1.0):
+        """One distributed multiply; returns (local C_out, counts with this rank's flop)."""
+        g, eng = self.grid, self.eng
+        # C's structure for all ticks at once (pattern-only symbolic product of the full panels)
+        row_p, counts0 = eng.symbolic(self.A_panel, self.B_panel, self.C_in, retain_sparsity=False)
+        Cout = eng.init_c(beta, self.C_in, row_p, counts0, self.dtype)
+        works, v, a_data, b_data = self._post(0, 0)
+        flop = nprod = 0
+        self.last_tick_flop = 0
+        for tick in range(g.nvirt):
+            for w in works:
+                w.wait()
+            cur = (v, a_data, b_data)
+            if tick + 1 < g.nvirt:  # next tick's panels travel while this tick multiplies
+                works, v, a_data, b_data = self._post(tick + 1, (tick + 1) & 1)
+            cv, ca, cb = cur
+            Ai, Bi = self.A_img[cv], self.B_img[cv]
+            A = DbcsrMatrix(Ai.row_blk_size, Ai.col_blk_size, Ai.row_p, Ai.col_i, Ai.blk_p, ca, "A")
+            B = DbcsrMatrix(Bi.row_blk_size, Bi.col_blk_size, Bi.row_p, Bi.col_i, Bi.blk_p, cb, "B")
+            if Ai.nblks and Bi.nblks:
+                cnt = eng.accumulate(alpha, A, B, Cout)
+                flop += cnt.flop
+                nprod += cnt.nproducts
+                self.last_tick_flop = cnt.flop
+        counts0.flop, counts0.nproducts = flop, nprod
+        return Cout, counts0
+
+    # ------------------------------------------------------------------
+    def gather_global(self, Cloc):
+        """(rows, cols, blocks) of the whole C on rank 0 (tests only): global block coordinates and dense blocks."""
+        P, g = self.part, self.grid
+        rs, cs, row_p, col_i, blk_p, data = Cloc.to_host()
+        rows = np.repeat(np.arange(len(rs)), np.diff(row_p))
+        grow, gcol = P.rows_of[g.myprow][rows], P.cols_of[g.mypcol][col_i]
+        blocks = [data[blk_p[b]:blk_p[b] + int(rs[rows[b]]) * int(cs[col_i[b]])].copy() for b in range(len(col_i))]
+        mine = (grow, gcol, blocks)
+        if g.world == 1:
+            return [mine]
+        out = [None] * g.world if g.rank == 0 else None
+        dist.gather_object(mine, out, dst=0)
+        return out

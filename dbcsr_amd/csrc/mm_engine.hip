@@ -419,6 +419,60 @@ fill_products_grid(const int* __restrict__ a_row_p, const int* __restrict__ a_co
   }
 }
 
+
+// ---- C structure only (multi-tick / Cannon use): emit the sorted index of the pattern
+// computed by the symbolic phase and describe where each block's initial value comes from.
+__global__ void __launch_bounds__(256)
+emit_index(const int* __restrict__ cin_row_p, const int64_t* __restrict__ cin_blk_p, const int* __restrict__ rs,
+           const int* __restrict__ cs, const uint32_t* __restrict__ cin_bm, const int* __restrict__ cin_pre,
+           const uint32_t* __restrict__ c_bm, const int* __restrict__ c_pre, const int* __restrict__ c_row_p,
+           const int64_t* __restrict__ c_blk_p_ws, int nbr, int W, int* __restrict__ c_col_i, int64_t* __restrict__ c_blk_p,
+           Desc* __restrict__ descs) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (int64_t)nbr * W) return;
+  const int i = (int)(t / W), w = (int)(t % W);
+  uint32_t v = c_bm[t];
+  if (!v) return;
+  int cb = c_row_p[i] + c_pre[t];
+  const uint32_t cinw = cin_bm ? cin_bm[t] : 0u;
+  while (v) {
+    const int bit = __ffs(v) - 1;
+    v &= v - 1;
+    const uint32_t below = (1u << bit) - 1u;
+    const int j = 32 * w + bit;
+    Desc d;
+    d.c_off = c_blk_p_ws[cb];
+    d.cin_off = -1;
+    if ((cinw >> bit) & 1u) d.cin_off = cin_blk_p[cin_row_p[i] + cin_pre[t] + __popc(cinw & below)];
+    d.prod_start = 0;
+    d.prod_cnt = 0;
+    d.m = (int16_t)rs[i];
+    d.n = (int16_t)cs[j];
+    descs[cb] = d;
+    c_col_i[cb] = j;
+    c_blk_p[cb] = d.c_off;
+    ++cb;
+  }
+}
+
+// one wavefront per C block: C_out = beta * C_in where the block existed, 0 elsewhere
+template <typename T>
+__global__ void __launch_bounds__(256) init_c_blocks(const Desc* __restrict__ descs, int64_t nblk, T* __restrict__ c_out,
+                                                     const T* __restrict__ c_in, T beta) {
+  const int lane = threadIdx.x & 63;
+  const int64_t cb = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (cb >= nblk) return;
+  const Desc d = descs[cb];
+  const int ne = (int)d.m * (int)d.n;
+  T* C = c_out + d.c_off;
+  if (d.cin_off >= 0) {
+    const T* Ci = c_in + d.cin_off;
+    for (int e = lane; e < ne; e += 64) C[e] = beta * Ci[e];
+  } else {
+    for (int e = lane; e < ne; e += 64) C[e] = (T)0;
+  }
+}
+
 // ----------------------------------------------------------------------------
 // processing order of the C blocks (speed only; results do not depend on it)
 //
@@ -517,12 +571,13 @@ __device__ __forceinline__ void cblock_f64(const Desc& d, const Entry* __restric
 __global__ void __launch_bounds__(256) mm_numeric_f64(const Desc* __restrict__ descs, int64_t nblk, const Entry* __restrict__ entries,
                                                       const double* __restrict__ a_data, const double* __restrict__ b_data,
                                                       double* __restrict__ c_out, const double* __restrict__ c_in, double alpha,
-                                                      double beta) {
+                                                      double beta, int skip_empty) {
   const int lane = threadIdx.x & 63;
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
   const int64_t cb = __builtin_amdgcn_readfirstlane(wg * 4 + (int)(threadIdx.x >> 6));
   if (cb >= nblk) return;
   const Desc d = descs[cb];
+  if (skip_empty && d.prod_cnt == 0) return;
   const LaneMap L(lane);
   const int m = d.m, n = d.n;
   if (m <= 32 && n <= 32) {
@@ -640,6 +695,7 @@ __global__ void __launch_bounds__(256) mm_numeric_f64_lds(const Desc* __restrict
   const int64_t pos = (int64_t)wg * 4 + wid;  // gridDim.x * 4 == padded length of order[]
   const int64_t cb = order[pos];
   if (cb < 0 || cb >= nblk) return;
+  if ((dbg & 32) && descs[cb].prod_cnt == 0) return;  // in-place accumulation (beta = 1): untouched blocks stay as they are
   char* lds_a = smem + (size_t)wid * lds_wave_doubles * 8;
   char* lds_b = lds_a + (size_t)lds_a_doubles * 8;
   const Desc d = descs[cb];
@@ -681,12 +737,13 @@ __global__ void __launch_bounds__(256) max_of(const int* __restrict__ v, int n, 
 __global__ void __launch_bounds__(256) mm_numeric_f32(const Desc* __restrict__ descs, int64_t nblk, const Entry* __restrict__ entries,
                                                       const float* __restrict__ a_data, const float* __restrict__ b_data,
                                                       float* __restrict__ c_out, const float* __restrict__ c_in, float alpha,
-                                                      float beta) {
+                                                      float beta, int skip_empty) {
   const int lane = threadIdx.x & 63;
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
   const int64_t cb = __builtin_amdgcn_readfirstlane(wg * 4 + (int)(threadIdx.x >> 6));
   if (cb >= nblk) return;
   const Desc d = descs[cb];
+  if (skip_empty && d.prod_cnt == 0) return;
   const int m = d.m, n = d.n;
   const Entry* e = entries + d.prod_start;
   const bool has_in = d.cin_off >= 0;
@@ -804,7 +861,8 @@ __device__ __forceinline__ uint64_t pow48(uint64_t base, uint64_t e) {
 __global__ void __launch_bounds__(256) fill_random_f64(const int* __restrict__ row_p, const int* __restrict__ col_i,
                                                        const int64_t* __restrict__ blk_p, double* __restrict__ data,
                                                        const int* __restrict__ rs, const int* __restrict__ cs, int nbr, int nbc,
-                                                       int counter) {
+                                                       int counter, const int* __restrict__ row_gid, const int* __restrict__ col_gid,
+                                                       int nrow_global) {
   // one wavefront per block row, lanes over the elements of each block
   const int lane = threadIdx.x & 63;
   const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -815,7 +873,7 @@ __global__ void __launch_bounds__(256) fill_random_f64(const int* __restrict__ r
   for (int b = row_p[row]; b < row_p[row + 1]; ++b) {
     const int c = col_i[b];
     const int ne = rs[row] * cs[c];
-    const uint64_t seed = larnv_block_seed(row + 1, nbr, c + 1, counter);
+    const uint64_t seed = larnv_block_seed((row_gid ? row_gid[row] : row) + 1, nrow_global, (col_gid ? col_gid[c] : c) + 1, counter);
     uint64_t x = (seed * pow48(A, (uint64_t)lane + 1)) & mask;
     double* d = data + blk_p[b];
     for (int e = lane; e < ne; e += 64) {
@@ -828,7 +886,8 @@ __global__ void __launch_bounds__(256) fill_random_f64(const int* __restrict__ r
 __global__ void __launch_bounds__(256) fill_random_f32(const int* __restrict__ row_p, const int* __restrict__ col_i,
                                                        const int64_t* __restrict__ blk_p, float* __restrict__ data,
                                                        const int* __restrict__ rs, const int* __restrict__ cs, int nbr, int nbc,
-                                                       int counter) {
+                                                       int counter, const int* __restrict__ row_gid, const int* __restrict__ col_gid,
+                                                       int nrow_global) {
   // slarnv draws in chunks of 64 and, inside a chunk, a value that rounds to 1.0f
   // bumps the chunk's base seed (LAPACK slaruv) -- so one thread walks one block.
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -844,7 +903,7 @@ __global__ void __launch_bounds__(256) fill_random_f32(const int* __restrict__ r
   const int r = lo, c = col_i[t];
   const int ne = rs[r] * cs[c];
   const uint64_t mask = (1ull << 48) - 1, A = 33952834046453ull;
-  uint64_t seed = larnv_block_seed(r + 1, nbr, c + 1, counter);
+  uint64_t seed = larnv_block_seed((row_gid ? row_gid[r] : r) + 1, nrow_global, (col_gid ? col_gid[c] : c) + 1, counter);
   float* d = data + blk_p[t];
   const float rr = 1.0f / 4096.0f;
   for (int done = 0; done < ne; done += 64) {
@@ -1174,6 +1233,8 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
                        E->descs.p, E->entries.p);
   }
   const unsigned nwg = (unsigned)((nblk + 3) / 4);
+  // in-place accumulation (Cannon ticks after the first): C blocks without products in this call are left untouched
+  const int skip_empty = (c_out->data == c_in->data && E->retain && beta == 1.0) ? 1 : 0;
   ACC_CHECK(hipEventRecord(E->ev[1], st));
   if (datatype == dbcsr_type_real_8) {
     // LDS path: blocks of at most 32 x 32 (any smaller size: the staging loads are bounds-checked buffer loads)
@@ -1188,7 +1249,7 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
 #define DBCSR_LAUNCH(T_)                                                                                                        \
   hipLaunchKernelGGL(mm_numeric_f64_lds<T_>, dim3(nwg_o), dim3(256), lds_bytes, st, E->descs.p, nblk, E->entries.p,               \
                      static_cast<const double*>(a->data), static_cast<const double*>(b->data), static_cast<double*>(c_out->data), \
-                     static_cast<const double*>(c_in->data), alpha, beta, lds_a, lds_wave, E->dbg, E->order.p)
+                     static_cast<const double*>(c_in->data), alpha, beta, lds_a, lds_wave, E->dbg | (skip_empty ? 32 : 0), E->order.p)
       switch (maxt) {
         case 1: DBCSR_LAUNCH(1); break;
         case 2: DBCSR_LAUNCH(2); break;
@@ -1199,17 +1260,45 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
     } else {
       hipLaunchKernelGGL(mm_numeric_f64, dim3(nwg), dim3(256), 0, st, E->descs.p, nblk, E->entries.p,
                          static_cast<const double*>(a->data), static_cast<const double*>(b->data),
-                         static_cast<double*>(c_out->data), static_cast<const double*>(c_in->data), alpha, beta);
+                         static_cast<double*>(c_out->data), static_cast<const double*>(c_in->data), alpha, beta, skip_empty);
     }
   } else {
     hipLaunchKernelGGL(mm_numeric_f32, dim3(nwg), dim3(256), 0, st, E->descs.p, nblk, E->entries.p,
                        static_cast<const float*>(a->data), static_cast<const float*>(b->data), static_cast<float*>(c_out->data),
-                       static_cast<const float*>(c_in->data), (float)alpha, (float)beta);
+                       static_cast<const float*>(c_in->data), (float)alpha, (float)beta, skip_empty);
   }
   ACC_CHECK(hipEventRecord(E->ev[2], st));
   E->timed = true;
   c_out->nblks = nblk;
   return check(hipGetLastError(), "dbcsr_amd_mm_numeric", __FILE__, __LINE__);
+}
+
+
+int dbcsr_amd_mm_init_c(void* handle, libsmm_acc_data_t datatype, double beta, const dbcsr_amd_bcsr* c_in, dbcsr_amd_bcsr* c_out,
+                        void* stream) {
+  Engine* E = static_cast<Engine*>(handle);
+  if (!E || !E->valid || !c_in || !c_out) {
+    fprintf(stderr, "dbcsr_amd_mm_init_c: no valid symbolic phase for this handle\n");
+    return -1;
+  }
+  if (datatype != dbcsr_type_real_8 && datatype != dbcsr_type_real_4) return -10;
+  hipStream_t st = stream_of(stream);
+  const int nbr = E->nbr, W = E->W;
+  const int64_t nblk = E->c_nblks;
+  c_out->nblks = nblk;
+  if (nblk == 0) return 0;
+  if (E->descs.ensure((size_t)nblk + 1)) return -1;
+  hipLaunchKernelGGL(emit_index, grid_for((int64_t)nbr * W), dim3(256), 0, st, c_in->row_p, c_in->blk_p, c_out->row_blk_size,
+                     c_out->col_blk_size, E->have_cin ? E->cin_bm.p : (const uint32_t*)nullptr,
+                     E->have_cin ? E->cin_pre.p : (const int*)nullptr, E->c_bm.p, E->c_pre.p, c_out->row_p, E->c_blk_p_ws.p, nbr, W,
+                     c_out->col_i, c_out->blk_p, E->descs.p);
+  if (datatype == dbcsr_type_real_8)
+    hipLaunchKernelGGL((init_c_blocks<double>), grid_for(nblk * 64), dim3(256), 0, st, E->descs.p, nblk,
+                       static_cast<double*>(c_out->data), static_cast<const double*>(c_in->data), beta);
+  else
+    hipLaunchKernelGGL((init_c_blocks<float>), grid_for(nblk * 64), dim3(256), 0, st, E->descs.p, nblk,
+                       static_cast<float*>(c_out->data), static_cast<const float*>(c_in->data), (float)beta);
+  return check(hipGetLastError(), "dbcsr_amd_mm_init_c", __FILE__, __LINE__);
 }
 
 static int element_offsets(Engine* E, const int* sizes, int n, DevBuf<int64_t>& off, hipStream_t st) {
@@ -1245,15 +1334,22 @@ int dbcsr_amd_bcsr_checksum(void* handle, libsmm_acc_data_t datatype, const dbcs
 }
 
 int dbcsr_amd_bcsr_fill_random(void* handle, libsmm_acc_data_t datatype, const dbcsr_amd_bcsr* m, int counter, void* stream) {
+  return dbcsr_amd_bcsr_fill_random_dist(handle, datatype, m, counter, nullptr, nullptr, m ? m->nblkrows : 0, stream);
+}
+
+int dbcsr_amd_bcsr_fill_random_dist(void* handle, libsmm_acc_data_t datatype, const dbcsr_amd_bcsr* m, int counter,
+                                    const int32_t* row_gid, const int32_t* col_gid, int32_t nblkrows_global, void* stream) {
   if (!handle || !m) return -1;
   hipStream_t st = stream_of(stream);
   if (m->nblks == 0) return 0;
   if (datatype == dbcsr_type_real_8)
     hipLaunchKernelGGL(fill_random_f64, grid_for((int64_t)m->nblkrows * 64), dim3(256), 0, st, m->row_p, m->col_i, m->blk_p,
-                       static_cast<double*>(m->data), m->row_blk_size, m->col_blk_size, m->nblkrows, m->nblkcols, counter);
+                       static_cast<double*>(m->data), m->row_blk_size, m->col_blk_size, m->nblkrows, m->nblkcols, counter, row_gid, col_gid,
+                       nblkrows_global);
   else if (datatype == dbcsr_type_real_4)
     hipLaunchKernelGGL(fill_random_f32, grid_for(m->nblks), dim3(256), 0, st, m->row_p, m->col_i, m->blk_p,
-                       static_cast<float*>(m->data), m->row_blk_size, m->col_blk_size, m->nblkrows, m->nblkcols, counter);
+                       static_cast<float*>(m->data), m->row_blk_size, m->col_blk_size, m->nblkrows, m->nblkcols, counter, row_gid, col_gid,
+                       nblkrows_global);
   else
     return -10;
   return check(hipGetLastError(), "dbcsr_amd_bcsr_fill_random", __FILE__, __LINE__);

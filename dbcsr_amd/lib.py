@@ -28,7 +28,7 @@ LIBSMM_SYMBOLS = [
 ]
 MM_SYMBOLS = [
     "dbcsr_amd_mm_create", "dbcsr_amd_mm_destroy", "dbcsr_amd_mm_symbolic", "dbcsr_amd_mm_numeric", "dbcsr_amd_bcsr_transpose",
-    "dbcsr_amd_bcsr_checksum", "dbcsr_amd_bcsr_fill_random", "dbcsr_amd_mm_kernel_name", "dbcsr_amd_mm_timing",
+    "dbcsr_amd_bcsr_checksum", "dbcsr_amd_bcsr_fill_random", "dbcsr_amd_mm_kernel_name", "dbcsr_amd_mm_timing", "dbcsr_amd_mm_init_c", "dbcsr_amd_bcsr_fill_random_dist",
 ]
 
 
@@ -93,6 +93,8 @@ def load_library():
     L.dbcsr_amd_bcsr_transpose.argtypes = [vp, i32, BP, BP, vp]
     L.dbcsr_amd_bcsr_checksum.argtypes = [vp, i32, BP, C.POINTER(C.c_double), vp]
     L.dbcsr_amd_bcsr_fill_random.argtypes = [vp, i32, BP, i32, vp]
+    L.dbcsr_amd_mm_init_c.argtypes = [vp, i32, C.c_double, BP, BP, vp]
+    L.dbcsr_amd_bcsr_fill_random_dist.argtypes = [vp, i32, BP, i32, vp, vp, i32, vp]
     L.dbcsr_amd_mm_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.dbcsr_amd_mm_kernel_name.argtypes = [i32]
     L.dbcsr_amd_mm_kernel_name.restype = C.c_char_p

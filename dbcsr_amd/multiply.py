@@ -74,6 +74,57 @@ class MultiplyEngine:
             raise RuntimeError("dbcsr_amd_mm_timing failed (%d)" % rc)
         return f.value, n.value
 
+    def fill_random_dist(self, M, counter, row_gid, col_gid, nblkrows_global, stream=None):
+        st = StreamHandle(stream)
+        d = M.desc()
+        rc = self.L.dbcsr_amd_bcsr_fill_random_dist(self.h, M.dtype_code, C.byref(d), int(counter), row_gid.data_ptr(),
+                                                    col_gid.data_ptr(), int(nblkrows_global), st.ptr)
+        if rc != 0:
+            raise RuntimeError("dbcsr_amd_bcsr_fill_random_dist failed (%d)" % rc)
+
+    # -- the phases of a multiply, separately (used by the Cannon driver) -------------
+    def symbolic(self, A, B, Cm, retain_sparsity=False, stream=None):
+        """Returns (row_p of C_out, counts)."""
+        st = StreamHandle(stream)
+        a, b, cin = A.desc(), B.desc(), Cm.desc()
+        row_p = torch.empty(Cm.nblkrows + 1, dtype=torch.int32, device=Cm.row_p.device)
+        counts = _lib.MmCounts()
+        rc = self.L.dbcsr_amd_mm_symbolic(self.h, C.byref(a), C.byref(b), C.byref(cin), 1 if retain_sparsity else 0,
+                                          row_p.data_ptr(), C.byref(counts), st.ptr)
+        if rc != 0:
+            raise RuntimeError("dbcsr_amd_mm_symbolic failed (%d)" % rc)
+        return row_p, counts
+
+    def init_c(self, beta, Cm, row_p, counts, dtype, stream=None):
+        """C_out with the pattern of the last symbolic call, = beta*Cm on Cm's blocks, 0 elsewhere."""
+        st = StreamHandle(stream)
+        dev = Cm.row_p.device
+        out = DbcsrMatrix(Cm.row_blk_size, Cm.col_blk_size, row_p, torch.empty(counts.c_nblks, dtype=torch.int32, device=dev),
+                          torch.empty(counts.c_nblks, dtype=torch.int64, device=dev),
+                          torch.empty(counts.c_nze, dtype=dtype, device=dev), Cm.name)
+        cin, cout = Cm.desc(), out.desc()
+        rc = self.L.dbcsr_amd_mm_init_c(self.h, _lib.dbcsr_type_real_8 if dtype == torch.float64 else _lib.dbcsr_type_real_4,
+                                        float(beta), C.byref(cin), C.byref(cout), st.ptr)
+        if rc != 0:
+            raise RuntimeError("dbcsr_amd_mm_init_c failed (%d)" % rc)
+        return out
+
+    def accumulate(self, alpha, A, B, Cacc, stream=None):
+        """Cacc += alpha*A*B restricted to Cacc's pattern, in place; returns counts of this pass."""
+        st = StreamHandle(stream)
+        a, b, c = A.desc(), B.desc(), Cacc.desc()
+        row_p = torch.empty(Cacc.nblkrows + 1, dtype=torch.int32, device=Cacc.row_p.device)
+        counts = _lib.MmCounts()
+        rc = self.L.dbcsr_amd_mm_symbolic(self.h, C.byref(a), C.byref(b), C.byref(c), 1, row_p.data_ptr(), C.byref(counts), st.ptr)
+        if rc != 0:
+            raise RuntimeError("dbcsr_amd_mm_symbolic failed (%d)" % rc)
+        cout = _lib.BcsrDesc(c.nblkrows, c.nblkcols, c.row_blk_size, c.col_blk_size, row_p.data_ptr(), c.col_i, c.blk_p, c.data, c.nblks)
+        rc = self.L.dbcsr_amd_mm_numeric(self.h, Cacc.dtype_code, float(alpha), C.byref(a), C.byref(b), 1.0, C.byref(c), C.byref(cout),
+                                         st.ptr)
+        if rc != 0:
+            raise RuntimeError("dbcsr_amd_mm_numeric failed (%d)" % rc)
+        return counts
+
     def multiply_local(self, alpha, A, B, beta, Cm, retain_sparsity=False, stream=None):
         """C_out = beta*Cm + alpha*A*B for already-oriented operands; returns (C_out, counts)."""
         st = StreamHandle(stream)

@@ -70,6 +70,15 @@ int dbcsr_amd_mm_symbolic(void* handle, const dbcsr_amd_bcsr* a, const dbcsr_amd
 int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha, const dbcsr_amd_bcsr* a, const dbcsr_amd_bcsr* b,
   double beta, const dbcsr_amd_bcsr* c_in, dbcsr_amd_bcsr* c_out, void* stream);
 
+/* Structure-only companion of the symbolic call, for multiplies whose products arrive in
+ * several passes (the Cannon ticks of dbcsr_mm_cannon.F:1347-1704): emits C_out's index
+ * (col_i, blk_p; row_p came from the symbolic call) and sets C_out = beta*C_in on the
+ * blocks C_in has, 0 on the new ones.  The passes then call symbolic(retain_sparsity=1) +
+ * numeric with c_out aliasing c_in and beta = 1: blocks that get no product in a pass are
+ * not touched. */
+int dbcsr_amd_mm_init_c(void* handle, libsmm_acc_data_t datatype, double beta, const dbcsr_amd_bcsr* c_in, dbcsr_amd_bcsr* c_out,
+  void* stream);
+
 /* Transposed copy of a BCSR matrix on the device (dbcsr_new_transposed,
  * src/ops/dbcsr_transformations.F): dst index arrays/data are caller-allocated
  * with src's nblks / nze; dst->row_blk_size/col_blk_size must already hold the
@@ -86,6 +95,13 @@ int dbcsr_amd_bcsr_checksum(void* handle, libsmm_acc_data_t datatype, const dbcs
  * index gets larnv(seed(row+1, nblkrows, col+1, nblkcols, counter)).  Used by the
  * benchmark to create inputs directly in HBM. */
 int dbcsr_amd_bcsr_fill_random(void* handle, libsmm_acc_data_t datatype, const dbcsr_amd_bcsr* m, int counter, void* stream);
+
+/* Same for one rank's part of a distributed matrix: row_gid/col_gid (device, may be NULL)
+ * map local block rows/columns to global ones, nblkrows_global is the global row count
+ * that enters the seed (values are a pure function of the GLOBAL block coordinates, as in
+ * the reference, so any process grid generates the same matrix). */
+int dbcsr_amd_bcsr_fill_random_dist(void* handle, libsmm_acc_data_t datatype, const dbcsr_amd_bcsr* m, int counter,
+  const int32_t* row_gid, const int32_t* col_gid, int32_t nblkrows_global, void* stream);
 
 /* HIP-event timing of the last dbcsr_amd_mm_numeric call on this handle, taken
  * on the stream the kernels were launched on: ms_fill = product-list/index

@@ -137,3 +137,20 @@ def test_checksum_matches_oracle():
     A, _, _ = O.perf_case(500, 300, 400, 0.7, 0.7, 0.7, [1, 23, 1, 5], [1, 13], [1, 32])
     cs, csp = eng.checksum(to_dev(A))
     assert abs(cs / O.checksum(A) - 1) < 1e-13 and abs(csp / O.checksum(A, True) - 1) < 1e-13
+
+
+@pytest.mark.parametrize("nvirt", [1, 3])
+def test_cannon_driver_single_gpu_ticks(nvirt):
+    # the multi-GPU driver on one rank: structure-once + in-place tick accumulation + distributed generator
+    from dbcsr_amd import cannon
+    M, N, K, sp = 23 * 30 + 16, 23 * 25 + 16, 23 * 28 + 16, (0.8, 0.8, 0.85)
+    grid = cannon.Grid(1, 0, 1, 1, nvirt=nvirt)
+    plan = cannon.CannonMultiply(M, N, K, sp, [1, 23], dtype=torch.float64, engine=MultiplyEngine(), grid=grid)
+    Cout, counts = plan.multiply(0.5, 2.0)
+    torch.cuda.synchronize()
+    A, B, Cm = O.perf_case(M, N, K, *sp, [1, 23], [1, 23], [1, 23])
+    ref, info = O.multiply("N", "N", 0.5, A, B, 2.0, Cm)
+    out = dev_to_bcsr(Cout)
+    assert np.array_equal(out.row_p, ref.row_p) and np.array_equal(out.col_i, ref.col_i) and np.array_equal(out.blk_p, ref.blk_p)
+    assert counts.flop == info["flop"]
+    assert rel_err(out.data, ref.data) <= TOL
