@@ -192,6 +192,8 @@ class CannonMultiply:
     # ------------------------------------------------------------------
     def _post(self, tick, parity):
         """Send/receive the panels of `tick`.  Returns (ops work handles, A data, B data)."""
+        if self.grid.world > 1 and self.device.type == "cuda" and dist.get_backend() != "nccl":
+            return self._post_host_staged(tick, parity)
         g, r, c = self.grid, self.grid.myprow, self.grid.mypcol
         ops = []
         v = g.v_at(r, c, tick)
@@ -217,6 +219,38 @@ class CannonMultiply:
             ops.append(dist.P2POp(dist.irecv, b_data, b_src))
         works = dist.batch_isend_irecv(ops) if ops else []
         return works, v, a_data, b_data
+
+    def _post_host_staged(self, tick, parity):
+        """Debug transport (non-RCCL backends with device tensors, e.g. several ranks sharing one GPU under
+        gloo): same schedule, payloads staged through host memory, blocking.  Not a performance path."""
+        g, r, c = self.grid, self.grid.myprow, self.grid.mypcol
+        v = g.v_at(r, c, tick)
+        a_src, b_src = g.a_owner(r, v), g.b_owner(v, c)
+        a_data = self.A_img[v].data if a_src == g.rank else self._abuf[parity][:self.A_img[v].data_numel]
+        b_data = self.B_img[v].data if b_src == g.rank else self._bbuf[parity][:self.B_img[v].data_numel]
+        torch.cuda.synchronize()
+        ops, keep, recvs = [], [], []
+        for pc in range(g.npcols):
+            vv = g.v_at(r, pc, tick)
+            if pc != c and g.a_owner(r, vv) == g.rank and self.A_img[vv].data_numel:
+                keep.append(self.A_img[vv].data.cpu())
+                ops.append(dist.P2POp(dist.isend, keep[-1], g.rank_of(r, pc)))
+        for pr in range(g.nprows):
+            vv = g.v_at(pr, c, tick)
+            if pr != r and g.b_owner(vv, c) == g.rank and self.B_img[vv].data_numel:
+                keep.append(self.B_img[vv].data.cpu())
+                ops.append(dist.P2POp(dist.isend, keep[-1], g.rank_of(pr, c)))
+        if a_src != g.rank and self.A_img[v].data_numel:
+            recvs.append((torch.empty(a_data.numel(), dtype=self.dtype), a_data))
+            ops.append(dist.P2POp(dist.irecv, recvs[-1][0], a_src))
+        if b_src != g.rank and self.B_img[v].data_numel:
+            recvs.append((torch.empty(b_data.numel(), dtype=self.dtype), b_data))
+            ops.append(dist.P2POp(dist.irecv, recvs[-1][0], b_src))
+        for w in (dist.batch_isend_irecv(ops) if ops else []):
+            w.wait()
+        for host, dev in recvs:
+            dev.copy_(host)
+        return [], v, a_data, b_data
 
     def multiply(self, alpha=1.0, beta=1.0):
         """One distributed multiply; returns (local C_out, counts with this rank's flop)."""

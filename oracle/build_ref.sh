@@ -1,0 +1,26 @@
+#!/bin/bash
+# Builds, from the reference sources WHERE THEY LIE under /root/reference (nothing is copied
+# into the repo), the two pieces of the reference that compile from their own few files:
+#   oracle/_ref/dbcsr_acc_test    the reference's C-ABI specification test
+#                                 (tests/dbcsr_acc_test.c, pure C, only needs acc.h) linked
+#                                 against THIS repo's libdbcsr_acc_amd.so
+#   oracle/_ref/ref_stack_driver  the reference's kernel-validator host functions
+#                                 (src/acc/libsmm_acc/libsmm_acc_benchmark.cpp: matInit,
+#                                 stackInit, stackCalc, stackTransp, checkSum...) behind a small
+#                                 driver of ours; used to validate the oracle's restatement.
+# The full library (Fortran + fypp + generated parameters.h/smm_acc_kernels.h) is NOT
+# buildable in this image and is not attempted.
+set -e
+REF=/root/reference
+HERE="$(cd "$(dirname "$0")" && pwd)"
+OUT="$HERE/_ref"
+[ -d "$REF" ] || { echo "no reference checkout: keeping prebuilt oracle/_ref"; exit 0; }
+mkdir -p "$OUT"
+gcc -O2 -fopenmp -DNDEBUG -I"$REF/src" "$REF/tests/dbcsr_acc_test.c" -L"$HERE/../dbcsr_amd" -ldbcsr_acc_amd \
+    -Wl,-rpath,'$ORIGIN/../../dbcsr_amd' -o "$OUT/dbcsr_acc_test"
+g++ -O2 -D__HIP -D__HIP_PLATFORM_AMD__ -ffunction-sections -fdata-sections -I/opt/rocm/include -I"$REF/src/acc/libsmm_acc" \
+    -c "$REF/src/acc/libsmm_acc/libsmm_acc_benchmark.cpp" -o "$OUT/libsmm_acc_benchmark.o"
+g++ -O2 "$HERE/ref_stack_driver.cpp" "$OUT/libsmm_acc_benchmark.o" -Wl,--gc-sections -L/opt/rocm/lib -lamdhip64 \
+    -Wl,-rpath,/opt/rocm/lib -o "$OUT/ref_stack_driver"
+rm -f "$OUT/libsmm_acc_benchmark.o"
+echo "built $OUT/dbcsr_acc_test $OUT/ref_stack_driver"

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""End-to-end check of the multi-rank driver on the HIP engine (development tool):
+  python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 tools/run_dist_check.py [backend]
+Every rank runs dbcsr_amd.cannon.CannonMultiply on the GPU given by LOCAL_RANK modulo the
+device count (so N ranks can share one GPU with backend=gloo), rank 0 compares the gathered C
+with the CPU oracle's global multiply."""
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def main():
+    backend = sys.argv[1] if len(sys.argv) > 1 else "nccl"
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    from dbcsr_amd import cannon
+    from dbcsr_amd.multiply import MultiplyEngine
+    M, N, K, sp = 23 * 60 + 16, 23 * 50 + 16, 23 * 70 + 16, (0.8, 0.8, 0.85)
+    plan = cannon.CannonMultiply(M, N, K, sp, [1, 23], dtype=torch.float64, engine=MultiplyEngine())
+    for _ in range(2):
+        Cout, counts = plan.multiply(0.5, 2.0)
+    torch.cuda.synchronize()
+    parts = plan.gather_global(Cout)
+    fl = torch.tensor([counts.flop], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+    dist.all_reduce(fl)
+    ok = True
+    if rank == 0:
+        from oracle import oracle as O
+        A, B, Cm = O.perf_case(M, N, K, *sp, [1, 23], [1, 23], [1, 23])
+        ref, info = O.multiply("N", "N", 0.5, A, B, 2.0, Cm)
+        got = {}
+        for grow, gcol, blocks in parts:
+            for r, c, blk in zip(grow, gcol, blocks):
+                got[(int(r), int(c))] = blk
+        rows = ref.rows()
+        ok = len(got) == ref.nblks and int(fl.item()) == info["flop"]
+        err = 0.0
+        for b in range(ref.nblks):
+            ne = int(ref.row_sizes[rows[b]]) * int(ref.col_sizes[ref.col_i[b]])
+            exp = ref.data[ref.blk_p[b]:ref.blk_p[b] + ne]
+            g = got.get((int(rows[b]), int(ref.col_i[b])))
+            if g is None:
+                ok = False
+                break
+            err = max(err, float(np.max(np.abs(g - exp) / np.maximum(np.abs(exp), 1e-300))))
+        ok = ok and err <= 1e-10
+        print("dist check world=%d grid=%dx%d nvirt=%d blocks=%d max_rel_err=%.2e flop_ok=%s -> %s" %
+              (world, plan.grid.nprows, plan.grid.npcols, plan.grid.nvirt, ref.nblks, err, int(fl.item()) == info["flop"],
+               "OK" if ok else "FAIL"))
+    dist.destroy_process_group()
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()
