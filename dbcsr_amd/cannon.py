@@ -19,6 +19,15 @@ metadata never travels (every rank derives all image indices from the replicated
 block pattern), only block data does; C's structure for all ticks is computed
 once on the GPU and the ticks accumulate in place.
 
+Two schedules are offered:
+  * ``mode="gather"`` (default): every rank posts ONE batch that fetches all the images it does not own
+    -- all peers, hence all xGMI links, at the same time -- while the GPU already runs the symbolic phase
+    (which needs index metadata only); then one device-resident multiply over the full row/column panels.
+    With 288 GB per GPU the panels always fit, C is written exactly once, and there is one symbolic pass
+    instead of one per tick.
+  * ``mode="ticks"``: the reference's tick-by-tick pipeline (one A and one B image per tick, next tick's
+    images in flight during the current tick's multiply, in-place accumulation into C).
+
 The local engine is duck-typed (``symbolic``, ``init_c``, ``accumulate``,
 ``fill_random_dist`` of dbcsr_amd.multiply.MultiplyEngine) so that the
 distribution / schedule / communication logic can be exercised on CPU with the
@@ -121,7 +130,9 @@ class CannonMultiply:
     own part: its C tile, its A images (process row r, images v = c mod npcols) and its B images
     (process column c, images v = r mod nprows); values are generated in HBM."""
 
-    def __init__(self, M, N, K, sparsities, mix, dtype=torch.float64, engine=None, device=None, grid=None, mix_n=None, mix_k=None):
+    def __init__(self, M, N, K, sparsities, mix, dtype=torch.float64, engine=None, device=None, grid=None, mix_n=None, mix_k=None,
+                 mode="gather"):
+        self.mode = mode
         world = dist.get_world_size() if dist.is_initialized() else 1
         rank = dist.get_rank() if dist.is_initialized() else 0
         self.grid = grid or Grid(world, rank)
@@ -171,6 +182,22 @@ class CannonMultiply:
                                   self._rs, self._ks_all, sm, sk, None, None, 0, fill=None)
         self.B_panel = self._make("B", np.zeros(len(sk), np.int32), 0, P.col_dist, c, all_k_local, P.col_local, len(sk), self._ks_all,
                                   self._cs, sk, sn, None, None, 0, fill=None)
+        # gather mode: one buffer per panel = the images back to back; the panel index points into it
+        self._a_base, self._b_base, oa, ob = {}, {}, 0, 0
+        for v in range(g.nvirt):
+            self._a_base[v], self._b_base[v] = oa, ob
+            oa += self.A_img[v].data_numel
+            ob += self.B_img[v].data_numel
+        self._a_all = torch.empty(oa, dtype=dtype, device=self.device)
+        self._b_all = torch.empty(ob, dtype=dtype, device=self.device)
+        self.A_panel.blk_p = self._panel_blk_p("A", P.row_dist, r, None, P.k_dist, self._a_base, self.A_img, P.row_local, P.k_local, rows_are_k=False)
+        self.B_panel.blk_p = self._panel_blk_p("B", None, None, (P.col_dist, c), P.k_dist, self._b_base, self.B_img, P.k_local, P.col_local, rows_are_k=True)
+        self.A_panel.data, self.B_panel.data = self._a_all, self._b_all
+        for v in range(g.nvirt):  # owned images live inside the panel buffers (no copy at multiply time)
+            for img, base, buf in ((self.A_img[v], self._a_base[v], self._a_all), (self.B_img[v], self._b_base[v], self._b_all)):
+                if img.data.numel():
+                    buf[base:base + img.data_numel].copy_(img.data)
+                    img.data = buf[base:base + img.data_numel]
         # double-buffered receive space for A and B panels
         amax = max([m.data_numel for v, m in self.A_img.items() if g.a_owner(r, v) != g.rank] + [0])
         bmax = max([m.data_numel for v, m in self.B_img.items() if g.b_owner(v, c) != g.rank] + [0])
@@ -188,6 +215,80 @@ class CannonMultiply:
         if fill and nze:
             self.eng.fill_random_dist(M, self.counters[which], rgid, cgid, nrow_global)
         return M
+
+    def _panel_blk_p(self, which, rdist, rsel, csel, k_dist, bases, imgs, rloc, cloc, rows_are_k):
+        """Offsets of the panel's blocks inside the concatenated image buffer (image base + offset in image)."""
+        rows, cols = self.pat[which]
+        if rows_are_k:   # B panel: rows are k blocks (image = k_dist[row]), columns restricted to my process column
+            cdist, cc = csel
+            keep = cdist[cols] == cc
+            img_of = k_dist[rows[keep]]
+        else:            # A panel: rows restricted to my process row, columns are k blocks (image = k_dist[col])
+            keep = rdist[rows] == rsel
+            img_of = k_dist[cols[keep]]
+        out = np.zeros(int(keep.sum()), np.int64)
+        kept = np.nonzero(keep)[0]
+        for v, img in imgs.items():
+            sel = img_of == v
+            blk = img.blk_p.detach().cpu().numpy()
+            assert int(sel.sum()) == len(blk)
+            out[sel] = bases[v] + blk  # both enumerate the image's blocks in global (row, col) order
+        return torch.as_tensor(out, dtype=torch.int64).to(self.device)
+
+    def _post_all(self):
+        """gather mode: one batch with every image this rank misses (and every send the others expect)."""
+        g, r, c = self.grid, self.grid.myprow, self.grid.mypcol
+        ops, staged = [], []
+        host = g.world > 1 and self.device.type == "cuda" and dist.get_backend() != "nccl"  # debug transport
+        if host:
+            torch.cuda.synchronize()
+
+        def send(t, peer):
+            if host:
+                t = t.cpu()
+                staged.append(t)
+            ops.append(dist.P2POp(dist.isend, t, peer))
+
+        def recv(t, peer):
+            if host:
+                h = torch.empty(t.numel(), dtype=t.dtype)
+                staged.append((h, t))
+                ops.append(dist.P2POp(dist.irecv, h, peer))
+            else:
+                ops.append(dist.P2POp(dist.irecv, t, peer))
+
+        for v in range(g.nvirt):
+            na, nb = self.A_img[v].data_numel, self.B_img[v].data_numel
+            a_own, b_own = g.a_owner(r, v), g.b_owner(v, c)
+            if na:
+                if a_own == g.rank:
+                    for pc in range(g.npcols):
+                        if pc != c:
+                            send(self.A_img[v].data, g.rank_of(r, pc))
+                else:
+                    recv(self._a_all[self._a_base[v]:self._a_base[v] + na], a_own)
+            if nb:
+                if b_own == g.rank:
+                    for pr in range(g.nprows):
+                        if pr != r:
+                            send(self.B_img[v].data, g.rank_of(pr, c))
+                else:
+                    recv(self._b_all[self._b_base[v]:self._b_base[v] + nb], b_own)
+        works = dist.batch_isend_irecv(ops) if ops else []
+        return works, staged
+
+    def _multiply_gather(self, alpha, beta):
+        eng = self.eng
+        works, staged = self._post_all()                       # panels travel over all links ...
+        row_p, counts = eng.symbolic(self.A_panel, self.B_panel, self.C_in, retain_sparsity=False)  # ... during the symbolic phase
+        for w in works:
+            w.wait()
+        for item in staged:
+            if isinstance(item, tuple):
+                item[1].copy_(item[0])
+        Cout = eng.numeric_after_symbolic(alpha, self.A_panel, self.B_panel, beta, self.C_in, row_p, counts, self.dtype)
+        self.last_tick_flop = counts.flop
+        return Cout, counts
 
     # ------------------------------------------------------------------
     def _post(self, tick, parity):
@@ -254,6 +355,8 @@ class CannonMultiply:
 
     def multiply(self, alpha=1.0, beta=1.0):
         """One distributed multiply; returns (local C_out, counts with this rank's flop)."""
+        if self.mode == "gather":
+            return self._multiply_gather(alpha, beta)
         g, eng = self.grid, self.eng
         # C's structure for all ticks at once (pattern-only symbolic product of the full panels)
         row_p, counts0 = eng.symbolic(self.A_panel, self.B_panel, self.C_in, retain_sparsity=False)

@@ -676,7 +676,7 @@ __device__ __forceinline__ void cblock_f64_lds(const Desc& d, const Entry* __res
       if (row < m && col < n) {
         double v = alpha * acc[a][c];
         if (has_in) v += beta * Ci[row + (size_t)m * col];
-        __builtin_nontemporal_store(v, &C[row + (size_t)m * col]);  // C is written once and not re-read here
+        C[row + (size_t)m * col] = v;  // plain store: non-temporal stores doubled WRITE_SIZE here (8-byte scattered lanes are not combined)
       }
     }
 }
@@ -714,6 +714,207 @@ __global__ void __launch_bounds__(256) mm_numeric_f64_lds(const Desc* __restrict
 #undef DBCSR_CASE
     default: break;
   }
+}
+
+
+// ---- pipelined variant: a wave walks a RANGE of C blocks --------------------------
+// v4 measurements: with one C block per wave, every wave pays the dependent chain
+// order -> descriptor -> entry -> operand loads -> LDS before its first MFMA (about 5 us);
+// at 14 products per block that is ~10 % of a wave's life, at 1-4 products per block
+// (configs 3 and 4) it dominates.  Here a wave owns G consecutive positions of order[] and
+// the product pipeline runs ACROSS C-block boundaries: while the last product of block b is
+// multiplied, the first product of block b+1 is already in flight, and the descriptor of
+// block b+2 has been requested.
+struct PipeCtx {
+  const Desc* __restrict__ descs;
+  const Entry* __restrict__ entries;
+  const double* __restrict__ a_data;
+  const double* __restrict__ b_data;
+  double* __restrict__ c_out;
+  const double* __restrict__ c_in;
+  double alpha, beta;
+  char* lds_a;
+  char* lds_b;
+  int lane, voff;
+};
+
+__device__ __forceinline__ int64_t uniform64(int64_t v) {
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
+  return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
+// descriptor held in scalar registers
+__device__ __forceinline__ Desc load_desc_uniform(const Desc* __restrict__ descs, int cb) {
+  const Desc t = descs[cb];
+  Desc d;
+  d.c_off = uniform64(t.c_off);
+  d.cin_off = uniform64(t.cin_off);
+  d.prod_start = uniform64(t.prod_start);
+  d.prod_cnt = __builtin_amdgcn_readfirstlane(t.prod_cnt);
+  const int mn = __builtin_amdgcn_readfirstlane(((int)(uint16_t)t.m) | (((int)(uint16_t)t.n) << 16));
+  d.m = (int16_t)(mn & 0xffff);
+  d.n = (int16_t)(mn >> 16);
+  return d;
+}
+
+// prefetch product `pidx` (index into entries) of a C block of size m x n into the staging registers
+template <int CMAX>
+__device__ __forceinline__ void pipe_issue(const PipeCtx& X, int64_t pidx, int m, int n, u32x4 (&ra)[CMAX], u32x4 (&rb)[CMAX]) {
+  const Entry e = X.entries[pidx];
+  const uint32_t ao = __builtin_amdgcn_readfirstlane(e.a_off), bo = __builtin_amdgcn_readfirstlane(e.b_off);
+  const int ks = __builtin_amdgcn_readfirstlane((int)e.ks);
+  const int abytes = m * ks * 8, bbytes = ks * n * 8;
+  const int nca = (m * ((ks + 3) & ~3) * 8 + 1023) >> 10, ncb = (bbytes + 1023) >> 10;
+  const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)(X.a_data + ao), 0, abytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)(X.b_data + bo), 0, bbytes, 0x00020000);
+#pragma unroll
+  for (int c = 0; c < CMAX; ++c)
+    if (c < nca) ra[c] = __builtin_amdgcn_raw_buffer_load_b128(rsa, X.voff, c * 1024, 0);
+#pragma unroll
+  for (int c = 0; c < CMAX; ++c)
+    if (c < ncb) rb[c] = __builtin_amdgcn_raw_buffer_load_b128(rsb, X.voff, c * 1024, 0);
+}
+
+// multiply the staged product into the accumulators of the current block.  acc is the launch-wide
+// [MAXT][MAXT] array; class (MA, NC) uses a corner of it.
+template <int MA, int NC, int MAXT>
+__device__ __forceinline__ void pipe_compute(const PipeCtx& X, int m, int n, int ks, double (&acc)[MAXT][MAXT], const LaneMap& L) {
+  double t[MA][NC];
+#pragma unroll
+  for (int a = 0; a < MA; ++a)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) t[a][c] = acc[a][c];
+  block_product_f64_lds<MA, NC>(t, reinterpret_cast<const double*>(X.lds_a), reinterpret_cast<const double*>(X.lds_b), m, n, ks, L);
+#pragma unroll
+  for (int a = 0; a < MA; ++a)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[a][c] = t[a][c];
+}
+
+// write a finished block (any class: rows/columns outside the block are masked) and clear the accumulators
+template <int MAXT>
+__device__ __forceinline__ void pipe_flush(const PipeCtx& X, const Desc& d, double (&acc)[MAXT][MAXT], const LaneMap& L) {
+  const int m = d.m, n = d.n;
+  double* C = X.c_out + d.c_off;
+  const bool has_in = d.cin_off >= 0;
+  const double* Ci = X.c_in + (has_in ? d.cin_off : 0);
+#pragma unroll
+  for (int a = 0; a < MAXT; ++a)
+#pragma unroll
+    for (int c = 0; c < MAXT; ++c) {
+      const int row = 8 * a + L.rowd, col = 8 * c + L.coll;
+      if (row < m && col < n) {
+        double v = X.alpha * acc[a][c];
+        if (has_in) v += X.beta * Ci[row + (size_t)m * col];
+        C[row + (size_t)m * col] = v;
+      }
+      acc[a][c] = 0.0;
+    }
+}
+
+template <int MAXT>
+__global__ void __launch_bounds__(256) mm_numeric_f64_pipe(const Desc* __restrict__ descs, int64_t nblk, const Entry* __restrict__ entries,
+                                                           const double* __restrict__ a_data, const double* __restrict__ b_data,
+                                                           double* __restrict__ c_out, const double* __restrict__ c_in, double alpha,
+                                                           double beta, int lds_a_doubles, int lds_wave_doubles, int skip_empty,
+                                                           const int* __restrict__ order, int64_t npos, int G) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int CMAX = 2 * MAXT;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  int64_t pos = ((int64_t)wg * 4 + wid) * G;
+  const int64_t pos_end = min(pos + G, npos);
+  if (pos >= npos) return;
+  PipeCtx X;
+  X.descs = descs; X.entries = entries; X.a_data = a_data; X.b_data = b_data; X.c_out = c_out; X.c_in = c_in;
+  X.alpha = alpha; X.beta = beta;
+  X.lds_a = smem + (size_t)wid * lds_wave_doubles * 8;
+  X.lds_b = X.lds_a + (size_t)lds_a_doubles * 8;
+  X.lane = lane; X.voff = lane * 16;
+  const LaneMap L(lane);
+  // Next C block of this wave's range that has products.  Blocks without products are finished on the spot
+  // (C = beta*C_in or 0), or left untouched when accumulating in place (skip_empty).
+  auto next_block = [&](Desc& d) -> bool {
+    while (pos < pos_end) {
+      const int cb = __builtin_amdgcn_readfirstlane(order[pos]);
+      ++pos;
+      if (cb < 0 || cb >= nblk) continue;
+      d = load_desc_uniform(descs, cb);
+      if (d.prod_cnt > 0) return true;
+      if (!skip_empty) {
+        double* C = c_out + d.c_off;
+        const int ne = (int)d.m * (int)d.n;
+        if (d.cin_off >= 0) {
+          const double* Ci = c_in + d.cin_off;
+          for (int e = lane; e < ne; e += 64) C[e] = beta * Ci[e];
+        } else {
+          for (int e = lane; e < ne; e += 64) C[e] = 0.0;
+        }
+      }
+    }
+    return false;
+  };
+  u32x4 ra[CMAX], rb[CMAX];
+  double acc[MAXT][MAXT];
+#pragma unroll
+  for (int a = 0; a < MAXT; ++a)
+#pragma unroll
+    for (int c = 0; c < MAXT; ++c) acc[a][c] = 0.0;
+  Desc cur, nxt, done;
+  if (!next_block(cur)) return;
+  bool have_nxt = next_block(nxt);
+  bool pending = false;  // `done` is finished and still sits in acc, waiting to be written
+  // Flat product loop.  p = -1: nothing staged yet (the first trip only issues the first prefetch), so there is
+  // exactly ONE prefetch site and ONE LDS-write site in the kernel (one set of staging registers).
+  // Order inside a trip: [wait for the prefetched operands, copy them to LDS] [write out the block finished in
+  // the previous trip] [prefetch] [multiply].  The finished block's stores are issued BEFORE the next prefetch,
+  // so the in-order vmcnt wait of the following trip never has to drain stores that were issued after loads.
+  int p = -1, ks = 0;
+  for (;;) {
+    if (p >= 0) {
+      ks = __builtin_amdgcn_readfirstlane((int)entries[cur.prod_start + p].ks);
+      const int nca = (cur.m * ((ks + 3) & ~3) * 8 + 1023) >> 10, ncb = (ks * cur.n * 8 + 1023) >> 10;
+#pragma unroll
+      for (int c = 0; c < CMAX; ++c)
+        if (c < nca) *reinterpret_cast<u32x4*>(X.lds_a + c * 1024 + X.voff) = ra[c];
+#pragma unroll
+      for (int c = 0; c < CMAX; ++c)
+        if (c < ncb) *reinterpret_cast<u32x4*>(X.lds_b + c * 1024 + X.voff) = rb[c];
+    }
+    if (pending) {
+      pipe_flush<MAXT>(X, done, acc, L);
+      pending = false;
+    }
+    const bool more = p + 1 < cur.prod_cnt;
+    if (more || have_nxt) pipe_issue<CMAX>(X, more ? cur.prod_start + p + 1 : nxt.prod_start, more ? cur.m : nxt.m, more ? cur.n : nxt.n, ra, rb);
+    if (p >= 0) {
+      const int MA = (cur.m + 7) >> 3, NC = (cur.n + 7) >> 3;
+      switch (MA * 4 + NC) {
+#define DBCSR_CASE(A_, C_)                                                                               \
+  case A_ * 4 + C_:                                                                                      \
+    if constexpr (A_ <= MAXT && C_ <= MAXT) pipe_compute<A_, C_, MAXT>(X, cur.m, cur.n, ks, acc, L);     \
+    break;
+        DBCSR_CASE(1, 1) DBCSR_CASE(1, 2) DBCSR_CASE(1, 3) DBCSR_CASE(1, 4)
+        DBCSR_CASE(2, 1) DBCSR_CASE(2, 2) DBCSR_CASE(2, 3) DBCSR_CASE(2, 4)
+        DBCSR_CASE(3, 1) DBCSR_CASE(3, 2) DBCSR_CASE(3, 3) DBCSR_CASE(3, 4)
+        DBCSR_CASE(4, 1) DBCSR_CASE(4, 2) DBCSR_CASE(4, 3) DBCSR_CASE(4, 4)
+#undef DBCSR_CASE
+        default: break;
+      }
+      if (!more) {  // block complete: it is written at the start of the next trip (or after the loop)
+        done = cur;
+        pending = true;
+        if (!have_nxt) break;
+        cur = nxt;
+        have_nxt = next_block(nxt);
+        p = 0;
+        continue;
+      }
+    }
+    ++p;
+  }
+  if (pending) pipe_flush<MAXT>(X, done, acc, L);
 }
 
 // max and (negated) min of an int array (block sizes): out[0] = max v, out[1] = max -v
@@ -1012,6 +1213,7 @@ struct Engine {
   int max_m = 0, max_k = 0, max_n = 0, min_m = 0, min_k = 0, min_n = 0;
   bool grid_kernels = false, force_word_kernels = false;  // DBCSR_AMD_MM_SYMBOLIC=word forces the per-word symbolic kernels
   int dbg = 0;      // DBCSR_AMD_MM_DBG: ablation switches of the LDS kernel (profiling only)
+  int use_pipe = 0, pipe_g = 8;  // DBCSR_AMD_MM_KERNEL=pipe selects the multi-block pipelined kernel (measured slower); DBCSR_AMD_MM_PIPE_G = blocks per wave
   int use_lds = 1;  // DBCSR_AMD_MM_KERNEL=direct selects the v1 kernel (A/B experiments)
 };
 
@@ -1047,7 +1249,11 @@ int dbcsr_amd_mm_create(void** handle) {
     delete E;
     return check(e, "hipHostMalloc", __FILE__, __LINE__);
   }
-  if (const char* k = getenv("DBCSR_AMD_MM_KERNEL")) E->use_lds = strcmp(k, "direct") != 0;
+  if (const char* k = getenv("DBCSR_AMD_MM_KERNEL")) {
+    E->use_lds = strcmp(k, "direct") != 0;
+    E->use_pipe = strcmp(k, "pipe") == 0;
+  }
+  if (const char* k = getenv("DBCSR_AMD_MM_PIPE_G")) E->pipe_g = std::max(1, atoi(k));
   if (const char* k = getenv("DBCSR_AMD_MM_DBG")) E->dbg = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_SYMBOLIC")) E->force_word_kernels = strcmp(k, "word") == 0;
   if (const char* k = getenv("DBCSR_AMD_MM_PANEL_MB")) E->panel_bytes = (int64_t)atoll(k) << 20;
@@ -1250,11 +1456,28 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
   hipLaunchKernelGGL(mm_numeric_f64_lds<T_>, dim3(nwg_o), dim3(256), lds_bytes, st, E->descs.p, nblk, E->entries.p,               \
                      static_cast<const double*>(a->data), static_cast<const double*>(b->data), static_cast<double*>(c_out->data), \
                      static_cast<const double*>(c_in->data), alpha, beta, lds_a, lds_wave, E->dbg | (skip_empty ? 32 : 0), E->order.p)
-      switch (maxt) {
-        case 1: DBCSR_LAUNCH(1); break;
-        case 2: DBCSR_LAUNCH(2); break;
-        case 3: DBCSR_LAUNCH(3); break;
-        default: DBCSR_LAUNCH(4); break;
+      if (E->use_pipe) {
+        const int64_t npos = 8 * E->order_len;
+        const int G = E->pipe_g;
+        const unsigned nwg_p = (unsigned)((npos + 4 * (int64_t)G - 1) / (4 * (int64_t)G));
+#define DBCSR_LAUNCH_P(T_)                                                                                                       \
+  hipLaunchKernelGGL(mm_numeric_f64_pipe<T_>, dim3(nwg_p), dim3(256), lds_bytes, st, E->descs.p, nblk, E->entries.p,             \
+                     static_cast<const double*>(a->data), static_cast<const double*>(b->data), static_cast<double*>(c_out->data), \
+                     static_cast<const double*>(c_in->data), alpha, beta, lds_a, lds_wave, skip_empty, E->order.p, npos, G)
+        switch (maxt) {
+          case 1: DBCSR_LAUNCH_P(1); break;
+          case 2: DBCSR_LAUNCH_P(2); break;
+          case 3: DBCSR_LAUNCH_P(3); break;
+          default: DBCSR_LAUNCH_P(4); break;
+        }
+#undef DBCSR_LAUNCH_P
+      } else {
+        switch (maxt) {
+          case 1: DBCSR_LAUNCH(1); break;
+          case 2: DBCSR_LAUNCH(2); break;
+          case 3: DBCSR_LAUNCH(3); break;
+          default: DBCSR_LAUNCH(4); break;
+        }
       }
 #undef DBCSR_LAUNCH
     } else {

@@ -125,6 +125,20 @@ class MultiplyEngine:
             raise RuntimeError("dbcsr_amd_mm_numeric failed (%d)" % rc)
         return counts
 
+    def numeric_after_symbolic(self, alpha, A, B, beta, Cm, row_p, counts, dtype, stream=None):
+        """Second half of multiply_local for a symbolic() call made earlier on the same operands."""
+        st = StreamHandle(stream)
+        dev = Cm.row_p.device
+        out = DbcsrMatrix(Cm.row_blk_size, Cm.col_blk_size, row_p, torch.empty(counts.c_nblks, dtype=torch.int32, device=dev),
+                          torch.empty(counts.c_nblks, dtype=torch.int64, device=dev),
+                          torch.empty(counts.c_nze, dtype=dtype, device=dev), Cm.name)
+        a, b, cin, cout = A.desc(), B.desc(), Cm.desc(), out.desc()
+        rc = self.L.dbcsr_amd_mm_numeric(self.h, out.dtype_code, float(alpha), C.byref(a), C.byref(b), float(beta), C.byref(cin),
+                                         C.byref(cout), st.ptr)
+        if rc != 0:
+            raise RuntimeError("dbcsr_amd_mm_numeric failed (%d)" % rc)
+        return out
+
     def multiply_local(self, alpha, A, B, beta, Cm, retain_sparsity=False, stream=None):
         """C_out = beta*Cm + alpha*A*B for already-oriented operands; returns (C_out, counts)."""
         st = StreamHandle(stream)

@@ -64,6 +64,18 @@ class OracleBackend:
         return DbcsrMatrix(Cm.row_blk_size, Cm.col_blk_size, row_p, torch.from_numpy(s.col_i.copy()), torch.from_numpy(s.blk_p.copy()),
                            torch.from_numpy(data), "C")
 
+    def numeric_after_symbolic(self, alpha, A, B, beta, Cm, row_p, counts, dtype, stream=None):
+        def gathered(M):  # panel matrices point into a concatenated buffer: re-pack to the oracle's compact layout
+            rs, cs, rp, ci, bp, d = M.to_host()
+            rows = np.repeat(np.arange(len(rs)), np.diff(rp))
+            nze = rs[rows].astype(np.int64) * cs[ci].astype(np.int64)
+            nbp = np.concatenate([[0], np.cumsum(nze)[:-1]]).astype(np.int64) if len(nze) else np.zeros(0, np.int64)
+            nd = np.concatenate([d[bp[b]:bp[b] + nze[b]] for b in range(len(ci))]) if len(ci) else np.zeros(0)
+            return O.Bcsr(rs, cs, rp, ci, nbp, nd)
+        out, _ = O.multiply("N", "N", alpha, gathered(A), gathered(B), beta, _to_oracle(Cm))
+        return DbcsrMatrix(Cm.row_blk_size, Cm.col_blk_size, torch.from_numpy(out.row_p.copy()), torch.from_numpy(out.col_i.copy()),
+                           torch.from_numpy(out.blk_p.copy()), torch.from_numpy(out.data.copy()), "C")
+
     def accumulate(self, alpha, A, B, Cacc, stream=None):
         out, info = O.multiply("N", "N", alpha, _to_oracle(A), _to_oracle(B), 1.0, _to_oracle(Cacc), retain_sparsity=True)
         assert np.array_equal(out.col_i, Cacc.col_i.numpy())

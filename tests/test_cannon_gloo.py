@@ -26,7 +26,7 @@ def _free_port():
 CASE = dict(M=23 * 9 + 16, N=13 * 14 + 5, K=17 * 8 + 3, sp=(0.6, 0.65, 0.8), mix=[1, 23], mix_n=[1, 13], mix_k=[2, 17, 1, 5])
 
 
-def _worker(rank, world, port, alpha, beta, q):
+def _worker(rank, world, port, alpha, beta, q, mode):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -34,7 +34,7 @@ def _worker(rank, world, port, alpha, beta, q):
         from dbcsr_amd import cannon
         from tests.cpu_backend import OracleBackend
         plan = cannon.CannonMultiply(CASE["M"], CASE["N"], CASE["K"], CASE["sp"], CASE["mix"], dtype=torch.float64,
-                                     engine=OracleBackend(), device=torch.device("cpu"), mix_n=CASE["mix_n"], mix_k=CASE["mix_k"])
+                                     engine=OracleBackend(), device=torch.device("cpu"), mix_n=CASE["mix_n"], mix_k=CASE["mix_k"], mode=mode)
         Cout, counts = plan.multiply(alpha, beta)
         parts = plan.gather_global(Cout)
         fl = torch.tensor([counts.flop], dtype=torch.int64)
@@ -45,13 +45,13 @@ def _worker(rank, world, port, alpha, beta, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4, 6])
-def test_cannon_matches_global_oracle(world):
+@pytest.mark.parametrize("world,mode", [(2, "gather"), (4, "gather"), (6, "gather"), (4, "ticks"), (6, "ticks")])
+def test_cannon_matches_global_oracle(world, mode):
     alpha, beta = 0.75, -1.25
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, alpha, beta, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, alpha, beta, q, mode)) for r in range(world)]
     for p in procs:
         p.start()
     parts, flop, pr, pc, nvirt = q.get(timeout=240)

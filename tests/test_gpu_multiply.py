@@ -139,13 +139,13 @@ def test_checksum_matches_oracle():
     assert abs(cs / O.checksum(A) - 1) < 1e-13 and abs(csp / O.checksum(A, True) - 1) < 1e-13
 
 
-@pytest.mark.parametrize("nvirt", [1, 3])
-def test_cannon_driver_single_gpu_ticks(nvirt):
+@pytest.mark.parametrize("nvirt,mode", [(1, "ticks"), (3, "ticks"), (3, "gather")])
+def test_cannon_driver_single_gpu_ticks(nvirt, mode):
     # the multi-GPU driver on one rank: structure-once + in-place tick accumulation + distributed generator
     from dbcsr_amd import cannon
     M, N, K, sp = 23 * 30 + 16, 23 * 25 + 16, 23 * 28 + 16, (0.8, 0.8, 0.85)
     grid = cannon.Grid(1, 0, 1, 1, nvirt=nvirt)
-    plan = cannon.CannonMultiply(M, N, K, sp, [1, 23], dtype=torch.float64, engine=MultiplyEngine(), grid=grid)
+    plan = cannon.CannonMultiply(M, N, K, sp, [1, 23], dtype=torch.float64, engine=MultiplyEngine(), grid=grid, mode=mode)
     Cout, counts = plan.multiply(0.5, 2.0)
     torch.cuda.synchronize()
     A, B, Cm = O.perf_case(M, N, K, *sp, [1, 23], [1, 23], [1, 23])

@@ -15,13 +15,14 @@ import torch.distributed as dist
 
 def main():
     backend = sys.argv[1] if len(sys.argv) > 1 else "nccl"
+    mode = sys.argv[2] if len(sys.argv) > 2 else "gather"
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
     dist.init_process_group(backend, rank=rank, world_size=world)
     from dbcsr_amd import cannon
     from dbcsr_amd.multiply import MultiplyEngine
     M, N, K, sp = 23 * 60 + 16, 23 * 50 + 16, 23 * 70 + 16, (0.8, 0.8, 0.85)
-    plan = cannon.CannonMultiply(M, N, K, sp, [1, 23], dtype=torch.float64, engine=MultiplyEngine())
+    plan = cannon.CannonMultiply(M, N, K, sp, [1, 23], dtype=torch.float64, engine=MultiplyEngine(), mode=mode)
     for _ in range(2):
         Cout, counts = plan.multiply(0.5, 2.0)
     torch.cuda.synchronize()
@@ -49,8 +50,8 @@ def main():
                 break
             err = max(err, float(np.max(np.abs(g - exp) / np.maximum(np.abs(exp), 1e-300))))
         ok = ok and err <= 1e-10
-        print("dist check world=%d grid=%dx%d nvirt=%d blocks=%d max_rel_err=%.2e flop_ok=%s -> %s" %
-              (world, plan.grid.nprows, plan.grid.npcols, plan.grid.nvirt, ref.nblks, err, int(fl.item()) == info["flop"],
+        print("dist check mode=%s world=%d grid=%dx%d nvirt=%d blocks=%d max_rel_err=%.2e flop_ok=%s -> %s" %
+              (mode, world, plan.grid.nprows, plan.grid.npcols, plan.grid.nvirt, ref.nblks, err, int(fl.item()) == info["flop"],
                "OK" if ok else "FAIL"))
     dist.destroy_process_group()
     sys.exit(0 if ok else 1)
