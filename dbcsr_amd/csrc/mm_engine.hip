@@ -313,6 +313,81 @@ fill_products(const int* __restrict__ a_row_p, const int* __restrict__ a_col_i, 
 
 
 
+// ---- on-the-fly filtering (dbcsr_mm_csr.F:276, dbcsr_mm_cannon.F:1040-1113) ------------------------
+// A product A(i,k)*B(k,j) is skipped when ||A(i,k)||^2 * ||alpha B(k,j)||^2 < (eps / max(1, #blocks in A row i))^2,
+// all in single precision as the reference (norms are fp32 values of fp64 sums).  a_norms == nullptr: no filter.
+struct FilterArgs {
+  const float* a_norms;
+  const float* b_norms;
+  float eps;
+};
+
+__device__ __forceinline__ float row_filter_eps(const FilterArgs& F, int nblks_in_a_row) {
+  const float e = F.eps / (float)(nblks_in_a_row > 1 ? nblks_in_a_row : 1);
+  return e * e;
+}
+
+// one wavefront per block row: norms[b] = (float) sum (scale * x)^2 over block b
+template <typename T>
+__global__ void __launch_bounds__(256) bcsr_block_norms(const int* __restrict__ row_p, const int* __restrict__ col_i,
+                                                        const int64_t* __restrict__ blk_p, const T* __restrict__ data,
+                                                        const int* __restrict__ rs, const int* __restrict__ cs, int nbr, double scale,
+                                                        float* __restrict__ norms, double* __restrict__ norms64) {
+  const int lane = threadIdx.x & 63;
+  const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (row >= nbr) return;
+  const int m = rs[row];
+  for (int b = row_p[row]; b < row_p[row + 1]; ++b) {
+    const int ne = m * cs[col_i[b]];
+    const T* d = data + blk_p[b];
+    double s = 0.0;
+    for (int e = lane; e < ne; e += 64) {
+      const double x = scale * (double)d[e];
+      s += x * x;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) {
+      if (norms) norms[b] = (float)s;
+      if (norms64) norms64[b] = s;
+    }
+  }
+}
+
+// C pattern under filtering: one lane per (row i, column j) candidate, bit set iff C_in has the block or at
+// least one product survives the filter (a new C block is only created by a product that is executed)
+__global__ void __launch_bounds__(256) c_bitmap_filtered(const int* __restrict__ a_row_p, const int* __restrict__ a_col_i,
+                                                         const int* __restrict__ b_row_p, const uint32_t* __restrict__ b_bm,
+                                                         const int* __restrict__ b_pre, const uint32_t* __restrict__ cin_bm, int nbr,
+                                                         int nbc, int W, int nJ, int retain, FilterArgs F, uint32_t* __restrict__ c_bm) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wv = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (wv >= (int64_t)nbr * nJ) return;
+  const int i = (int)(wv / nJ), jb = (int)(wv % nJ);
+  const int j = jb * 64 + lane, w = j >> 5, bit = j & 31;
+  bool any = false;
+  if (!retain && j < nbc) {
+    const int a0 = a_row_p[i], a1 = a_row_p[i + 1];
+    const float reps = row_filter_eps(F, a1 - a0);
+    const uint32_t below = (1u << bit) - 1u;
+    for (int ab = a0; ab < a1; ++ab) {
+      const int k = a_col_i[ab];
+      const uint32_t bw = b_bm[(size_t)k * W + w];
+      if ((bw >> bit) & 1u) {
+        const int bidx = b_row_p[k] + b_pre[(size_t)k * W + w] + __popc(bw & below);
+        if (!(F.a_norms[ab] * F.b_norms[bidx] < reps)) any = true;
+      }
+    }
+  }
+  const unsigned long long mask = __ballot(any);
+  if (lane == 0) {
+    const int w0 = 2 * jb;
+    c_bm[(size_t)i * W + w0] = (uint32_t)mask | (cin_bm ? cin_bm[(size_t)i * W + w0] : 0u);
+    if (w0 + 1 < W) c_bm[(size_t)i * W + w0 + 1] = (uint32_t)(mask >> 32) | (cin_bm ? cin_bm[(size_t)i * W + w0 + 1] : 0u);
+  }
+}
+
+
 // ---- dense-grid variants: one lane per (row i, column j) candidate ------------
 // The per-word kernels above expose only nbr*W threads, each walking up to 32 C
 // blocks x |A-row| serially (v1 profile: 1.6 + 4.0 ms for config 2).  When C is not
@@ -325,7 +400,8 @@ __global__ void __launch_bounds__(256) count_products_grid(const int* __restrict
                                                            const uint32_t* __restrict__ c_bm, const int* __restrict__ c_pre,
                                                            const int* __restrict__ c_row_p, int nbr, int nbc, int W, int nJ,
                                                            int* __restrict__ prod_cnt, int* __restrict__ blk_nze,
-                                                           unsigned long long* __restrict__ flop_out) {
+                                                           unsigned long long* __restrict__ flop_out, const int* __restrict__ b_row_p,
+                                                           const int* __restrict__ b_pre, FilterArgs F) {
   const int lane = threadIdx.x & 63;
   const int64_t wv = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   unsigned long long flop = 0;
@@ -336,12 +412,17 @@ __global__ void __launch_bounds__(256) count_products_grid(const int* __restrict
     const bool present = (cw >> bit) & 1u;
     if (__ballot(present)) {
       const int a0 = a_row_p[i], a1 = a_row_p[i + 1];
+      const float reps = F.a_norms ? row_filter_eps(F, a1 - a0) : 0.0f;
       int cnt = 0;
       long long ksum = 0;
       for (int ab = a0; ab < a1; ++ab) {
         const int k = a_col_i[ab];
         const uint32_t bw = w < W ? b_bm[(size_t)k * W + w] : 0u;
         if ((bw >> bit) & 1u) {
+          if (F.a_norms) {
+            const int bidx = b_row_p[k] + b_pre[(size_t)k * W + w] + __popc(bw & ((1u << bit) - 1u));
+            if (F.a_norms[ab] * F.b_norms[bidx] < reps) continue;
+          }
           ++cnt;
           ksum += ks[k];
         }
@@ -374,7 +455,7 @@ fill_products_grid(const int* __restrict__ a_row_p, const int* __restrict__ a_co
                    const uint32_t* __restrict__ cin_bm, const int* __restrict__ cin_pre, const uint32_t* __restrict__ c_bm,
                    const int* __restrict__ c_pre, const int* __restrict__ c_row_p, const int64_t* __restrict__ prod_start,
                    const int64_t* __restrict__ c_blk_p_ws, int nbr, int nbc, int W, int nJ, int* __restrict__ c_col_i,
-                   int64_t* __restrict__ c_blk_p, Desc* __restrict__ descs, Entry* __restrict__ entries) {
+                   int64_t* __restrict__ c_blk_p, Desc* __restrict__ descs, Entry* __restrict__ entries, FilterArgs F) {
   const int lane = threadIdx.x & 63;
   const int64_t wv = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (wv >= (int64_t)nbr * nJ) return;
@@ -387,12 +468,14 @@ fill_products_grid(const int* __restrict__ a_row_p, const int* __restrict__ a_co
   const int cb = present ? c_row_p[i] + c_pre[(size_t)i * W + w] + __popc(cw & below) : 0;
   const int64_t p0 = present ? prod_start[cb] : 0;
   const int a0 = a_row_p[i], a1 = a_row_p[i + 1];
+  const float reps = F.a_norms ? row_filter_eps(F, a1 - a0) : 0.0f;
   int cnt = 0;
   for (int ab = a0; ab < a1; ++ab) {
     const int k = a_col_i[ab];
     const uint32_t bw = w < W ? b_bm[(size_t)k * W + w] : 0u;
     if (present && ((bw >> bit) & 1u)) {
       const int bidx = b_row_p[k] + b_pre[(size_t)k * W + w] + __popc(bw & below);
+      if (F.a_norms && F.a_norms[ab] * F.b_norms[bidx] < reps) continue;
       Entry e;
       e.a_off = (uint32_t)a_blk_p[ab];
       e.b_off = (uint32_t)b_blk_p[bidx];
@@ -1209,6 +1292,54 @@ __global__ void __launch_bounds__(256) transpose_sizes(const uint32_t* __restric
   }
 }
 
+
+// ---- block filter (dbcsr_mm_multrec.F:694-748 multrec_filtering / dbcsr_filter): drop blocks with ||blk||^2 < eps^2
+__global__ void __launch_bounds__(256) filter_flags(const double* __restrict__ norms64, int64_t nblks, const int* __restrict__ row_p,
+                                                    const int* __restrict__ col_i, const int* __restrict__ rs, const int* __restrict__ cs,
+                                                    int nbr, double eps2, int* __restrict__ keep, int* __restrict__ blk_nze,
+                                                    int* __restrict__ row_keep) {
+  // one wavefront per block row
+  const int lane = threadIdx.x & 63;
+  const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (row >= nbr) return;
+  int cnt = 0;
+  for (int b = row_p[row] + lane; b < row_p[row + 1]; b += 64) {
+    const int k = norms64[b] >= eps2 ? 1 : 0;
+    keep[b] = k;
+    blk_nze[b] = k ? rs[row] * cs[col_i[b]] : 0;
+    cnt += k;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+  if (lane == 0) row_keep[row] = cnt;
+  (void)nblks;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) filter_compact(const int* __restrict__ row_p, const int* __restrict__ col_i,
+                                                      const int64_t* __restrict__ blk_p, const T* __restrict__ data,
+                                                      const int* __restrict__ rs, const int* __restrict__ cs, int nbr,
+                                                      const int* __restrict__ keep, const int64_t* __restrict__ newidx,
+                                                      const int64_t* __restrict__ newoff, int* __restrict__ d_col_i,
+                                                      int64_t* __restrict__ d_blk_p, T* __restrict__ d_data) {
+  const int lane = threadIdx.x & 63;
+  const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (row >= nbr) return;
+  const int m = rs[row];
+  for (int b = row_p[row]; b < row_p[row + 1]; ++b) {
+    if (!keep[b]) continue;
+    const int64_t t = newidx[b], off = newoff[b];
+    if (lane == 0) {
+      d_col_i[t] = col_i[b];
+      d_blk_p[t] = off;
+    }
+    const int ne = m * cs[col_i[b]];
+    const T* src = data + blk_p[b];
+    T* dst = d_data + off;
+    for (int e = lane; e < ne; e += 64) dst[e] = src[e];
+  }
+}
+
 // ----------------------------------------------------------------------------
 // host side
 // ----------------------------------------------------------------------------
@@ -1218,7 +1349,11 @@ struct Engine {
   DevBuf<int64_t> prod_start, c_blk_p_ws, partial, off_a, off_b;
   DevBuf<Entry> entries;
   DevBuf<Desc> descs;
-  DevBuf<double> row_sums;
+  DevBuf<double> row_sums, norms64;
+  DevBuf<float> a_norms, b_norms;
+  DevBuf<int> keep;
+  FilterArgs filter = {nullptr, nullptr, 0.0f};
+  int64_t flt_nblks = 0;
   DevBuf<int> order, order_cnt;
   DevBuf<int64_t> order_base;
   int64_t order_len = 0;
@@ -1309,6 +1444,7 @@ int dbcsr_amd_mm_destroy(void* handle) {
   E->prod_start.release(); E->c_blk_p_ws.release(); E->partial.release(); E->off_a.release(); E->off_b.release();
   E->entries.release(); E->descs.release(); E->row_sums.release(); E->dev_scalars.release();
   E->order.release(); E->order_cnt.release(); E->order_base.release();
+  E->norms64.release(); E->a_norms.release(); E->b_norms.release(); E->keep.release();
   if (E->host_scalars) (void)hipHostFree(E->host_scalars);
   for (int i = 0; i < 3; ++i)
     if (E->ev[i]) (void)hipEventDestroy(E->ev[i]);
@@ -1318,8 +1454,16 @@ int dbcsr_amd_mm_destroy(void* handle) {
 
 int dbcsr_amd_mm_symbolic(void* handle, const dbcsr_amd_bcsr* a, const dbcsr_amd_bcsr* b, const dbcsr_amd_bcsr* c_in,
                           int retain_sparsity, int32_t* c_out_row_p, dbcsr_amd_mm_counts* counts, void* stream) {
+  return dbcsr_amd_mm_symbolic_filtered(handle, dbcsr_type_real_8, 1.0, 0.0, a, b, c_in, retain_sparsity, c_out_row_p, counts, stream);
+}
+
+int dbcsr_amd_mm_symbolic_filtered(void* handle, libsmm_acc_data_t datatype, double alpha, double filter_eps, const dbcsr_amd_bcsr* a,
+                                   const dbcsr_amd_bcsr* b, const dbcsr_amd_bcsr* c_in, int retain_sparsity, int32_t* c_out_row_p,
+                                   dbcsr_amd_mm_counts* counts, void* stream) {
   Engine* E = static_cast<Engine*>(handle);
   if (!E || !a || !b || !c_in || !c_out_row_p || !counts) return -1;
+  const bool filtering = filter_eps > 0.0;
+  if (filtering && datatype != dbcsr_type_real_8 && datatype != dbcsr_type_real_4) return -10;
   if (a->nblkcols != b->nblkrows || a->nblkrows != c_in->nblkrows || b->nblkcols != c_in->nblkcols) {
     fprintf(stderr, "dbcsr_amd_mm_symbolic: incompatible block dimensions\n");
     return -2;
@@ -1362,9 +1506,31 @@ int dbcsr_amd_mm_symbolic(void* handle, const dbcsr_amd_bcsr* a, const dbcsr_amd
                        E->cin_bm.p);
     hipLaunchKernelGGL(row_prefix, grid_for((int64_t)nbr * 64), dim3(256), 0, st, E->cin_bm.p, nbr, W, E->cin_pre.p, (int*)nullptr);
   }
+  // on-the-fly filter: block norms of A and alpha*B (fp32 values of fp64 sums)
+  E->filter = FilterArgs{nullptr, nullptr, 0.0f};
+  if (filtering) {
+    if (E->a_norms.ensure((size_t)a->nblks + 1) || E->b_norms.ensure((size_t)b->nblks + 1)) return -1;
+    if (datatype == dbcsr_type_real_8) {
+      hipLaunchKernelGGL((bcsr_block_norms<double>), grid_for((int64_t)nbr * 64), dim3(256), 0, st, a->row_p, a->col_i, a->blk_p,
+                         static_cast<const double*>(a->data), a->row_blk_size, a->col_blk_size, nbr, 1.0, E->a_norms.p, (double*)nullptr);
+      hipLaunchKernelGGL((bcsr_block_norms<double>), grid_for((int64_t)nbk * 64), dim3(256), 0, st, b->row_p, b->col_i, b->blk_p,
+                         static_cast<const double*>(b->data), b->row_blk_size, b->col_blk_size, nbk, alpha, E->b_norms.p, (double*)nullptr);
+    } else {
+      hipLaunchKernelGGL((bcsr_block_norms<float>), grid_for((int64_t)nbr * 64), dim3(256), 0, st, a->row_p, a->col_i, a->blk_p,
+                         static_cast<const float*>(a->data), a->row_blk_size, a->col_blk_size, nbr, 1.0, E->a_norms.p, (double*)nullptr);
+      hipLaunchKernelGGL((bcsr_block_norms<float>), grid_for((int64_t)nbk * 64), dim3(256), 0, st, b->row_p, b->col_i, b->blk_p,
+                         static_cast<const float*>(b->data), b->row_blk_size, b->col_blk_size, nbk, alpha, E->b_norms.p, (double*)nullptr);
+    }
+    E->filter = FilterArgs{E->a_norms.p, E->b_norms.p, (float)filter_eps};
+  }
   // 2. pattern of C_out, its row prefix and row pointer
-  hipLaunchKernelGGL(c_bitmap, grid_for((int64_t)nbr * W), dim3(256), 0, st, a->row_p, a->col_i, E->b_bm.p,
-                     E->have_cin ? E->cin_bm.p : (const uint32_t*)nullptr, nbr, W, retain_sparsity ? 1 : 0, E->c_bm.p);
+  if (filtering)
+    hipLaunchKernelGGL(c_bitmap_filtered, grid_for((int64_t)nbr * ((nbc + 63) / 64) * 64), dim3(256), 0, st, a->row_p, a->col_i, b->row_p,
+                       E->b_bm.p, E->b_pre.p, E->have_cin ? E->cin_bm.p : (const uint32_t*)nullptr, nbr, nbc, W, (nbc + 63) / 64,
+                       retain_sparsity ? 1 : 0, E->filter, E->c_bm.p);
+  else
+    hipLaunchKernelGGL(c_bitmap, grid_for((int64_t)nbr * W), dim3(256), 0, st, a->row_p, a->col_i, E->b_bm.p,
+                       E->have_cin ? E->cin_bm.p : (const uint32_t*)nullptr, nbr, W, retain_sparsity ? 1 : 0, E->c_bm.p);
   hipLaunchKernelGGL(row_prefix, grid_for((int64_t)nbr * 64), dim3(256), 0, st, E->c_bm.p, nbr, W, E->c_pre.p, E->row_nnz.p);
   int64_t* dsc = reinterpret_cast<int64_t*>(E->dev_scalars.p);
   if (exclusive_scan<int32_t>(E, E->row_nnz.p, nbr, c_out_row_p, dsc + 0, true, st)) return -1;
@@ -1408,11 +1574,11 @@ int dbcsr_amd_mm_symbolic(void* handle, const dbcsr_amd_bcsr* a, const dbcsr_amd
   // 3. per C block: number of products, size; flop
   // one lane per (row, column) candidate unless C is extremely sparse (then one thread per bitmap word)
   const int nJ = (nbc + 63) / 64;
-  E->grid_kernels = ((int64_t)nbr * nJ * 64 <= 256 * std::max<int64_t>(c_nblks, 1)) && !E->force_word_kernels;
+  E->grid_kernels = filtering || (((int64_t)nbr * nJ * 64 <= 256 * std::max<int64_t>(c_nblks, 1)) && !E->force_word_kernels);
   if (E->grid_kernels)
     hipLaunchKernelGGL(count_products_grid, grid_for((int64_t)nbr * nJ * 64), dim3(256), 0, st, a->row_p, a->col_i, a->row_blk_size,
                        a->col_blk_size, b->col_blk_size, E->b_bm.p, E->c_bm.p, E->c_pre.p, c_out_row_p, nbr, nbc, W, nJ,
-                       E->prod_cnt.p, E->blk_nze.p, E->dev_scalars.p + 3);
+                       E->prod_cnt.p, E->blk_nze.p, E->dev_scalars.p + 3, b->row_p, E->b_pre.p, E->filter);
   else
     hipLaunchKernelGGL(count_products, grid_for((int64_t)nbr * W), dim3(256), 0, st, a->row_p, a->col_i, a->row_blk_size,
                        a->col_blk_size, b->col_blk_size, E->b_bm.p, E->c_bm.p, E->c_pre.p, c_out_row_p, nbr, W, E->prod_cnt.p,
@@ -1458,7 +1624,7 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
                        b->blk_p, c_in->row_p, c_in->blk_p, a->row_blk_size, a->col_blk_size, b->col_blk_size, E->b_bm.p, E->b_pre.p,
                        E->have_cin ? E->cin_bm.p : (const uint32_t*)nullptr, E->have_cin ? E->cin_pre.p : (const int*)nullptr,
                        E->c_bm.p, E->c_pre.p, c_out->row_p, E->prod_start.p, E->c_blk_p_ws.p, nbr, nbc, W, nJ, c_out->col_i,
-                       c_out->blk_p, E->descs.p, E->entries.p);
+                       c_out->blk_p, E->descs.p, E->entries.p, E->filter);
   } else {
     hipLaunchKernelGGL(fill_products, grid_for((int64_t)nbr * W), dim3(256), 0, st, a->row_p, a->col_i, a->blk_p, b->row_p, b->blk_p,
                        c_in->row_p, c_in->blk_p, a->row_blk_size, a->col_blk_size, b->col_blk_size, E->b_bm.p, E->b_pre.p,
@@ -1550,6 +1716,62 @@ int dbcsr_amd_mm_init_c(void* handle, libsmm_acc_data_t datatype, double beta, c
     hipLaunchKernelGGL((init_c_blocks<float>), grid_for(nblk * 64), dim3(256), 0, st, E->descs.p, nblk,
                        static_cast<float*>(c_out->data), static_cast<const float*>(c_in->data), (float)beta);
   return check(hipGetLastError(), "dbcsr_amd_mm_init_c", __FILE__, __LINE__);
+}
+
+
+int dbcsr_amd_bcsr_filter_count(void* handle, libsmm_acc_data_t datatype, const dbcsr_amd_bcsr* m, double eps, int32_t* new_row_p,
+                                int64_t* new_nblks, int64_t* new_nze, void* stream) {
+  Engine* E = static_cast<Engine*>(handle);
+  if (!E || !m || !new_row_p || !new_nblks || !new_nze) return -1;
+  if (datatype != dbcsr_type_real_8 && datatype != dbcsr_type_real_4) return -10;
+  hipStream_t st = stream_of(stream);
+  const int nbr = m->nblkrows;
+  const int64_t nb = m->nblks;
+  E->valid = false;  // shares workspace with the symbolic phase
+  E->flt_nblks = nb;
+  if (E->norms64.ensure((size_t)nb + 1) || E->keep.ensure((size_t)nb + 1) || E->blk_nze.ensure((size_t)nb + 1) ||
+      E->row_nnz.ensure((size_t)nbr + 1) || E->prod_start.ensure((size_t)nb + 1) || E->c_blk_p_ws.ensure((size_t)nb + 1) ||
+      E->dev_scalars.ensure(16))
+    return -1;
+  int64_t* dsc = reinterpret_cast<int64_t*>(E->dev_scalars.p);
+  ACC_CHECK(hipMemsetAsync(dsc, 0, 16 * sizeof(int64_t), st));
+  if (nbr > 0 && nb > 0) {
+    if (datatype == dbcsr_type_real_8)
+      hipLaunchKernelGGL((bcsr_block_norms<double>), grid_for((int64_t)nbr * 64), dim3(256), 0, st, m->row_p, m->col_i, m->blk_p,
+                         static_cast<const double*>(m->data), m->row_blk_size, m->col_blk_size, nbr, 1.0, (float*)nullptr, E->norms64.p);
+    else
+      hipLaunchKernelGGL((bcsr_block_norms<float>), grid_for((int64_t)nbr * 64), dim3(256), 0, st, m->row_p, m->col_i, m->blk_p,
+                         static_cast<const float*>(m->data), m->row_blk_size, m->col_blk_size, nbr, 1.0, (float*)nullptr, E->norms64.p);
+    hipLaunchKernelGGL(filter_flags, grid_for((int64_t)nbr * 64), dim3(256), 0, st, E->norms64.p, nb, m->row_p, m->col_i, m->row_blk_size,
+                       m->col_blk_size, nbr, eps * eps, E->keep.p, E->blk_nze.p, E->row_nnz.p);
+  }
+  if (exclusive_scan<int32_t>(E, E->row_nnz.p, nbr, new_row_p, dsc + 0, true, st)) return -1;
+  if (exclusive_scan<int64_t>(E, E->keep.p, nb, E->prod_start.p, nullptr, false, st)) return -1;     // new index of each kept block
+  if (exclusive_scan<int64_t>(E, E->blk_nze.p, nb, E->c_blk_p_ws.p, dsc + 1, false, st)) return -1;  // new data offset
+  ACC_CHECK(hipMemcpyAsync(E->host_scalars, dsc, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+  ACC_CHECK(hipStreamSynchronize(st));
+  *new_nblks = E->host_scalars[0];
+  *new_nze = E->host_scalars[1];
+  return check(hipGetLastError(), "dbcsr_amd_bcsr_filter_count", __FILE__, __LINE__);
+}
+
+int dbcsr_amd_bcsr_filter_apply(void* handle, libsmm_acc_data_t datatype, const dbcsr_amd_bcsr* src, dbcsr_amd_bcsr* dst, void* stream) {
+  Engine* E = static_cast<Engine*>(handle);
+  if (!E || !src || !dst || E->flt_nblks != src->nblks) return -1;
+  hipStream_t st = stream_of(stream);
+  const int nbr = src->nblkrows;
+  if (nbr == 0 || src->nblks == 0) return 0;
+  if (datatype == dbcsr_type_real_8)
+    hipLaunchKernelGGL((filter_compact<double>), grid_for((int64_t)nbr * 64), dim3(256), 0, st, src->row_p, src->col_i, src->blk_p,
+                       static_cast<const double*>(src->data), src->row_blk_size, src->col_blk_size, nbr, E->keep.p, E->prod_start.p,
+                       E->c_blk_p_ws.p, dst->col_i, dst->blk_p, static_cast<double*>(dst->data));
+  else if (datatype == dbcsr_type_real_4)
+    hipLaunchKernelGGL((filter_compact<float>), grid_for((int64_t)nbr * 64), dim3(256), 0, st, src->row_p, src->col_i, src->blk_p,
+                       static_cast<const float*>(src->data), src->row_blk_size, src->col_blk_size, nbr, E->keep.p, E->prod_start.p,
+                       E->c_blk_p_ws.p, dst->col_i, dst->blk_p, static_cast<float*>(dst->data));
+  else
+    return -10;
+  return check(hipGetLastError(), "dbcsr_amd_bcsr_filter_apply", __FILE__, __LINE__);
 }
 
 static int element_offsets(Engine* E, const int* sizes, int n, DevBuf<int64_t>& off, hipStream_t st) {

@@ -29,6 +29,7 @@ LIBSMM_SYMBOLS = [
 MM_SYMBOLS = [
     "dbcsr_amd_mm_create", "dbcsr_amd_mm_destroy", "dbcsr_amd_mm_symbolic", "dbcsr_amd_mm_numeric", "dbcsr_amd_bcsr_transpose",
     "dbcsr_amd_bcsr_checksum", "dbcsr_amd_bcsr_fill_random", "dbcsr_amd_mm_kernel_name", "dbcsr_amd_mm_timing", "dbcsr_amd_mm_init_c", "dbcsr_amd_bcsr_fill_random_dist",
+    "dbcsr_amd_mm_symbolic_filtered", "dbcsr_amd_bcsr_filter_count", "dbcsr_amd_bcsr_filter_apply",
 ]
 
 
@@ -93,6 +94,9 @@ def load_library():
     L.dbcsr_amd_bcsr_transpose.argtypes = [vp, i32, BP, BP, vp]
     L.dbcsr_amd_bcsr_checksum.argtypes = [vp, i32, BP, C.POINTER(C.c_double), vp]
     L.dbcsr_amd_bcsr_fill_random.argtypes = [vp, i32, BP, i32, vp]
+    L.dbcsr_amd_mm_symbolic_filtered.argtypes = [vp, i32, C.c_double, C.c_double, BP, BP, BP, i32, vp, C.POINTER(MmCounts), vp]
+    L.dbcsr_amd_bcsr_filter_count.argtypes = [vp, i32, BP, C.c_double, vp, C.POINTER(i64), C.POINTER(i64), vp]
+    L.dbcsr_amd_bcsr_filter_apply.argtypes = [vp, i32, BP, BP, vp]
     L.dbcsr_amd_mm_init_c.argtypes = [vp, i32, C.c_double, BP, BP, vp]
     L.dbcsr_amd_bcsr_fill_random_dist.argtypes = [vp, i32, BP, i32, vp, vp, i32, vp]
     L.dbcsr_amd_mm_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]

@@ -139,15 +139,34 @@ class MultiplyEngine:
             raise RuntimeError("dbcsr_amd_mm_numeric failed (%d)" % rc)
         return out
 
-    def multiply_local(self, alpha, A, B, beta, Cm, retain_sparsity=False, stream=None):
+    def filtered(self, M, eps, stream=None):
+        """Copy of M without the blocks whose squared Frobenius norm is below eps^2 (final filter of a multiply)."""
+        st = StreamHandle(stream)
+        dev = M.row_p.device
+        src = M.desc()
+        row_p = torch.empty(M.nblkrows + 1, dtype=torch.int32, device=dev)
+        nb, nz = C.c_int64(), C.c_int64()
+        rc = self.L.dbcsr_amd_bcsr_filter_count(self.h, M.dtype_code, C.byref(src), float(eps), row_p.data_ptr(), C.byref(nb), C.byref(nz),
+                                                st.ptr)
+        if rc != 0:
+            raise RuntimeError("dbcsr_amd_bcsr_filter_count failed (%d)" % rc)
+        out = DbcsrMatrix(M.row_blk_size, M.col_blk_size, row_p, torch.empty(nb.value, dtype=torch.int32, device=dev),
+                          torch.empty(nb.value, dtype=torch.int64, device=dev), torch.empty(nz.value, dtype=M.dtype, device=dev), M.name)
+        dst = out.desc()
+        rc = self.L.dbcsr_amd_bcsr_filter_apply(self.h, M.dtype_code, C.byref(src), C.byref(dst), st.ptr)
+        if rc != 0:
+            raise RuntimeError("dbcsr_amd_bcsr_filter_apply failed (%d)" % rc)
+        return out
+
+    def multiply_local(self, alpha, A, B, beta, Cm, retain_sparsity=False, stream=None, filter_eps=0.0):
         """C_out = beta*Cm + alpha*A*B for already-oriented operands; returns (C_out, counts)."""
         st = StreamHandle(stream)
         dev = A.data.device
         a, b, cin = A.desc(), B.desc(), Cm.desc()
         row_p = torch.empty(Cm.nblkrows + 1, dtype=torch.int32, device=dev)
         counts = _lib.MmCounts()
-        rc = self.L.dbcsr_amd_mm_symbolic(self.h, C.byref(a), C.byref(b), C.byref(cin), 1 if retain_sparsity else 0,
-                                          row_p.data_ptr(), C.byref(counts), st.ptr)
+        rc = self.L.dbcsr_amd_mm_symbolic_filtered(self.h, A.dtype_code, float(alpha), float(filter_eps or 0.0), C.byref(a), C.byref(b),
+                                                   C.byref(cin), 1 if retain_sparsity else 0, row_p.data_ptr(), C.byref(counts), st.ptr)
         if rc != 0:
             raise RuntimeError("dbcsr_amd_mm_symbolic failed (%d)" % rc)
         out = DbcsrMatrix(Cm.row_blk_size, Cm.col_blk_size, row_p, torch.empty(counts.c_nblks, dtype=torch.int32, device=dev),
@@ -158,6 +177,8 @@ class MultiplyEngine:
                                          C.byref(cout), st.ptr)
         if rc != 0:
             raise RuntimeError("dbcsr_amd_mm_numeric failed (%d)" % rc)
+        if filter_eps and filter_eps > 0 and not retain_sparsity:  # dbcsr_mm_multrec.F:373-383
+            out = self.filtered(out, filter_eps, stream=stream)
         return out, counts
 
 
@@ -178,8 +199,6 @@ def dbcsr_multiply(transa, transb, alpha, matrix_a, matrix_b, beta, matrix_c, fi
     list that receives the flop count, as the reference's optional INTENT(OUT)."""
     if any(v is not None for v in (first_row, last_row, first_column, last_column, first_k, last_k)):
         raise NotImplementedError("dbcsr_multiply: submatrix limits are not implemented on the device path yet")
-    if filter_eps is not None and filter_eps > 0:
-        raise NotImplementedError("dbcsr_multiply: filter_eps is not implemented on the device path yet")
     for t in (transa, transb):
         if t not in ("N", "T", "C"):
             raise ValueError("dbcsr_multiply: invalid transpose flag %r" % (t,))
@@ -190,7 +209,7 @@ def dbcsr_multiply(transa, transb, alpha, matrix_a, matrix_b, beta, matrix_c, fi
     B = E.transposed(matrix_b) if transb != "N" else matrix_b
     if A.nblkcols != B.nblkrows or A.nblkrows != matrix_c.nblkrows or B.nblkcols != matrix_c.nblkcols:
         raise ValueError("dbcsr_multiply: incompatible block dimensions")
-    out, counts = E.multiply_local(alpha, A, B, beta, matrix_c, retain_sparsity=retain_sparsity)
+    out, counts = E.multiply_local(alpha, A, B, beta, matrix_c, retain_sparsity=retain_sparsity, filter_eps=filter_eps or 0.0)
     matrix_c.row_p, matrix_c.col_i, matrix_c.blk_p, matrix_c.data = out.row_p, out.col_i, out.blk_p, out.data
     if flop is not None:
         flop[:] = [counts.flop]

@@ -62,6 +62,21 @@ int dbcsr_amd_mm_destroy(void* handle);
 int dbcsr_amd_mm_symbolic(void* handle, const dbcsr_amd_bcsr* a, const dbcsr_amd_bcsr* b, const dbcsr_amd_bcsr* c_in,
   int retain_sparsity, int32_t* c_out_row_p, dbcsr_amd_mm_counts* counts, void* stream);
 
+/* Symbolic product with on-the-fly filtering (dbcsr_mm_csr.F:276, dbcsr_mm_cannon.F:1040-1113): a product
+ * A(i,k)*B(k,j) is skipped when ||A(i,k)||^2 * ||alpha*B(k,j)||^2 < (filter_eps / max(1, #blocks of A row i))^2
+ * (single precision, as the reference); new C blocks are created only by surviving products.  Needs the data
+ * areas of a and b (norms) and the alpha of the numeric call that follows.  filter_eps <= 0: same as above. */
+int dbcsr_amd_mm_symbolic_filtered(void* handle, libsmm_acc_data_t datatype, double alpha, double filter_eps, const dbcsr_amd_bcsr* a,
+  const dbcsr_amd_bcsr* b, const dbcsr_amd_bcsr* c_in, int retain_sparsity, int32_t* c_out_row_p, dbcsr_amd_mm_counts* counts,
+  void* stream);
+
+/* Final block filter of a multiply (dbcsr_mm_multrec.F:694-748) / dbcsr_filter: blocks with sum x^2 < eps^2 are
+ * dropped.  _count writes new_row_p [nblkrows+1] (device) and the new block/element counts (host, synchronises);
+ * _apply then compacts index and data into caller-allocated dst arrays (dst->row_p = new_row_p). */
+int dbcsr_amd_bcsr_filter_count(void* handle, libsmm_acc_data_t datatype, const dbcsr_amd_bcsr* m, double eps, int32_t* new_row_p,
+  int64_t* new_nblks, int64_t* new_nze, void* stream);
+int dbcsr_amd_bcsr_filter_apply(void* handle, libsmm_acc_data_t datatype, const dbcsr_amd_bcsr* src, dbcsr_amd_bcsr* dst, void* stream);
+
 /* Numeric phase.  c_out->row_p is the array written by the symbolic call;
  * col_i [c_nblks], blk_p [c_nblks] and data [c_nze] are allocated by the caller
  * and filled here (blocks laid out in index order).  c_out->data may alias

@@ -154,3 +154,29 @@ def test_cannon_driver_single_gpu_ticks(nvirt, mode):
     assert np.array_equal(out.row_p, ref.row_p) and np.array_equal(out.col_i, ref.col_i) and np.array_equal(out.blk_p, ref.blk_p)
     assert counts.flop == info["flop"]
     assert rel_err(out.data, ref.data) <= TOL
+
+
+@pytest.mark.parametrize("eps,retain,alpha", [(2.0, False, 1.0), (40.0, False, 0.5), (60.0, True, 1.0), (1e-30, False, 1.0)])
+def test_filter_eps_matches_oracle(eps, retain, alpha):
+    # on-the-fly product filter + final block filter (CP2K's linear-scaling mode); eps chosen so that a good part
+    # of the products / blocks is actually dropped (U(0,1) 13..23-blocks have squared norms of ~50..180)
+    A, B, Cm = O.perf_case(300, 280, 290, 0.5, 0.5, 0.6, [1, 13, 1, 23], [1, 23, 1, 5], [1, 13, 1, 7])
+    # spread the block magnitudes so that the norm test separates products
+    rng = np.random.default_rng(5)
+    for M in (A, B, Cm):
+        rows = M.rows()
+        for b in range(M.nblks):
+            ne = int(M.row_sizes[rows[b]]) * int(M.col_sizes[M.col_i[b]])
+            M.data[M.blk_p[b]:M.blk_p[b] + ne] *= 10.0 ** rng.uniform(-2, 0.5)
+    ref, info = O.multiply("N", "N", alpha, A, B, 1.0, Cm, retain_sparsity=retain, filter_eps=eps)
+    full, info_full = O.multiply("N", "N", alpha, A, B, 1.0, Cm, retain_sparsity=retain)
+    if eps > 1:
+        assert info["nproducts"] < info_full["nproducts"]  # the filter really removed products
+    dA, dB, dC = to_dev(A), to_dev(B), to_dev(Cm)
+    flop = [0]
+    dbcsr_multiply("N", "N", alpha, dA, dB, 1.0, dC, retain_sparsity=retain, filter_eps=eps, flop=flop)
+    torch.cuda.synchronize()
+    out = dev_to_bcsr(dC)
+    assert np.array_equal(out.row_p, ref.row_p) and np.array_equal(out.col_i, ref.col_i) and np.array_equal(out.blk_p, ref.blk_p)
+    assert flop[0] == info["flop"]
+    assert rel_err(out.data, ref.data) <= TOL
