@@ -131,8 +131,9 @@ class CannonMultiply:
     (process column c, images v = r mod nprows); values are generated in HBM."""
 
     def __init__(self, M, N, K, sparsities, mix, dtype=torch.float64, engine=None, device=None, grid=None, mix_n=None, mix_k=None,
-                 mode="gather"):
+                 mode="gather", local_first=True):
         self.mode = mode
+        self.local_first = local_first
         world = dist.get_world_size() if dist.is_initialized() else 1
         rank = dist.get_rank() if dist.is_initialized() else 0
         self.grid = grid or Grid(world, rank)
@@ -198,6 +199,13 @@ class CannonMultiply:
                 if img.data.numel():
                     buf[base:base + img.data_numel].copy_(img.data)
                     img.data = buf[base:base + img.data_numel]
+        # local-first split of the gather schedule: images this rank owns on BOTH sides can be multiplied while
+        # the other images are still travelling
+        self._S1 = [v for v in range(g.nvirt) if g.a_owner(r, v) == g.rank and g.b_owner(v, c) == g.rank]
+        self._S2 = [v for v in range(g.nvirt) if v not in self._S1]
+        self._sub = {}
+        for name, S in (("S1", self._S1), ("S2", self._S2)):
+            self._sub[name] = (self._sub_panel("A", S), self._sub_panel("B", S)) if S and g.world > 1 else None
         # double-buffered receive space for A and B panels
         amax = max([m.data_numel for v, m in self.A_img.items() if g.a_owner(r, v) != g.rank] + [0])
         bmax = max([m.data_numel for v, m in self.B_img.items() if g.b_owner(v, c) != g.rank] + [0])
@@ -234,6 +242,22 @@ class CannonMultiply:
             assert int(sel.sum()) == len(blk)
             out[sel] = bases[v] + blk  # both enumerate the image's blocks in global (row, col) order
         return torch.as_tensor(out, dtype=torch.int64).to(self.device)
+
+    def _sub_panel(self, which, S):
+        """Panel restricted to the k-images in S: same buffers and global k numbering, fewer blocks."""
+        P, g = self.part, self.grid
+        full = self.A_panel if which == "A" else self.B_panel
+        rs, cs, row_p, col_i, blk_p, _ = [x for x in DbcsrMatrix(full.row_blk_size, full.col_blk_size, full.row_p, full.col_i, full.blk_p,
+                                                                full.row_p[:0]).to_host()]
+        rows = np.repeat(np.arange(len(rs), dtype=np.int64), np.diff(row_p))
+        kk = col_i if which == "A" else rows            # the k index of each block (global numbering)
+        keep = np.isin(P.k_dist[kk], np.asarray(S, np.int32))
+        nrow_p = np.zeros(len(rs) + 1, np.int64)
+        np.add.at(nrow_p, rows[keep] + 1, 1)
+        t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt).to(self.device)
+        M = DbcsrMatrix(full.row_blk_size, full.col_blk_size, t(np.cumsum(nrow_p), torch.int32), t(col_i[keep], torch.int32),
+                        t(blk_p[keep], torch.int64), full.data, which)
+        return M
 
     def _post_all(self):
         """gather mode: one batch with every image this rank misses (and every send the others expect)."""
@@ -280,15 +304,30 @@ class CannonMultiply:
     def _multiply_gather(self, alpha, beta):
         eng = self.eng
         works, staged = self._post_all()                       # panels travel over all links ...
-        row_p, counts = eng.symbolic(self.A_panel, self.B_panel, self.C_in, retain_sparsity=False)  # ... during the symbolic phase
-        for w in works:
-            w.wait()
-        for item in staged:
-            if isinstance(item, tuple):
-                item[1].copy_(item[0])
-        Cout = eng.numeric_after_symbolic(alpha, self.A_panel, self.B_panel, beta, self.C_in, row_p, counts, self.dtype)
-        self.last_tick_flop = counts.flop
-        return Cout, counts
+
+        def arrived():
+            for w in works:
+                w.wait()
+            for item in staged:
+                if isinstance(item, tuple):
+                    item[1].copy_(item[0])
+
+        s1, s2 = self._sub["S1"], self._sub["S2"]
+        if s1 is None or s2 is None or not self.local_first:
+            # ... during the symbolic phase of the one multiply over the full panels
+            row_p, counts = eng.symbolic(self.A_panel, self.B_panel, self.C_in, retain_sparsity=False)
+            arrived()
+            Cout = eng.numeric_after_symbolic(alpha, self.A_panel, self.B_panel, beta, self.C_in, row_p, counts, self.dtype)
+            self.last_tick_flop = counts.flop
+            return Cout, counts
+        # local-first: the images owned on both sides are multiplied while the rest is still in flight
+        C1, cnt1 = eng.multiply_local(alpha, s1[0], s1[1], beta, self.C_in)
+        arrived()
+        Cout, cnt2 = eng.multiply_local(alpha, s2[0], s2[1], 1.0, C1)
+        self.last_tick_flop = cnt2.flop
+        cnt2.flop += cnt1.flop
+        cnt2.nproducts += cnt1.nproducts
+        return Cout, cnt2
 
     # ------------------------------------------------------------------
     def _post(self, tick, parity):

@@ -76,6 +76,12 @@ class OracleBackend:
         return DbcsrMatrix(Cm.row_blk_size, Cm.col_blk_size, torch.from_numpy(out.row_p.copy()), torch.from_numpy(out.col_i.copy()),
                            torch.from_numpy(out.blk_p.copy()), torch.from_numpy(out.data.copy()), "C")
 
+    def multiply_local(self, alpha, A, B, beta, Cm, retain_sparsity=False, stream=None, filter_eps=0.0):
+        row_p, counts = self.symbolic(A, B, Cm, retain_sparsity)
+        info_flop, info_np = counts.flop, counts.nproducts
+        out = self.numeric_after_symbolic(alpha, A, B, beta, Cm, row_p, counts, torch.float64)
+        return out, _Counts(out.nblks, out.data.numel(), info_np, info_flop)
+
     def accumulate(self, alpha, A, B, Cacc, stream=None):
         out, info = O.multiply("N", "N", alpha, _to_oracle(A), _to_oracle(B), 1.0, _to_oracle(Cacc), retain_sparsity=True)
         assert np.array_equal(out.col_i, Cacc.col_i.numpy())
