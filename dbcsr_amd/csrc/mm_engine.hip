@@ -470,10 +470,22 @@ fill_products_grid(const int* __restrict__ a_row_p, const int* __restrict__ a_co
   const int a0 = a_row_p[i], a1 = a_row_p[i + 1];
   const float reps = F.a_norms ? row_filter_eps(F, a1 - a0) : 0.0f;
   int cnt = 0;
-  for (int ab = a0; ab < a1; ++ab) {
-    const int k = a_col_i[ab];
-    const uint32_t bw = w < W ? b_bm[(size_t)k * W + w] : 0u;
-    if (present && ((bw >> bit) & 1u)) {
+  // A's row is walked in chunks of 64 blocks: first a cheap pass that only tests the B bitmap and records the
+  // hits of this lane in a 64-bit mask, then the expensive part (index look-ups, entry store) runs per HIT -- about
+  // fill x 64 trips per chunk instead of 64 (v4: 0.85 ms for config 2 with the one-pass loop).
+  for (int base = a0; base < a1; base += 64) {
+    const int top = min(base + 64, a1);
+    unsigned long long hits = 0ull;
+    for (int ab = base; ab < top; ++ab) {
+      const int k = a_col_i[ab];
+      const uint32_t bw = w < W ? b_bm[(size_t)k * W + w] : 0u;
+      if (present && ((bw >> bit) & 1u)) hits |= 1ull << (ab - base);
+    }
+    while (hits) {
+      const int ab = base + __ffsll((long long)hits) - 1;
+      hits &= hits - 1;
+      const int k = a_col_i[ab];
+      const uint32_t bw = b_bm[(size_t)k * W + w];
       const int bidx = b_row_p[k] + b_pre[(size_t)k * W + w] + __popc(bw & below);
       if (F.a_norms && F.a_norms[ab] * F.b_norms[bidx] < reps) continue;
       Entry e;
