@@ -124,16 +124,21 @@ def _sub_index(rows, cols, keep, row_local, col_local, nrows_local, row_sizes, c
 
 
 class CannonMultiply:
-    """Distributed C <- beta*C + alpha*A*B on synthetic matrices of the reference's generator.
+    """Distributed C <- beta*C + alpha*A*B.
 
-    Every rank builds the same global block patterns (host, O(nblks)) and materialises only its
-    own part: its C tile, its A images (process row r, images v = c mod npcols) and its B images
-    (process column c, images v = r mod nprows); values are generated in HBM."""
+    Inputs are either synthetic matrices of the reference's generator (M, N, K, sparsities, block-size mix:
+    every rank builds the same global block patterns on the host, O(nblks), and generates the values of its own
+    part directly in HBM), or -- ``matrices=(A, B, C)`` -- global host matrices replicated on every rank (objects
+    with row_sizes, col_sizes, row_p, col_i, blk_p, data), from which each rank cuts its part: the counterpart of
+    the reference's ``make_m2s``/``make_images`` (dbcsr_mm_cannon.F:146-258, 292-750) for replicated input.
+    A rank materialises its C tile, its A images (process row r, images v = c mod npcols) and its B images
+    (process column c, images v = r mod nprows)."""
 
-    def __init__(self, M, N, K, sparsities, mix, dtype=torch.float64, engine=None, device=None, grid=None, mix_n=None, mix_k=None,
-                 mode="gather", local_first=True):
+    def __init__(self, M=0, N=0, K=0, sparsities=(0, 0, 0), mix=(1, 1), dtype=torch.float64, engine=None, device=None, grid=None,
+                 mix_n=None, mix_k=None, mode="gather", local_first=True, matrices=None):
         self.mode = mode
         self.local_first = local_first
+        self._host = None
         world = dist.get_world_size() if dist.is_initialized() else 1
         rank = dist.get_rank() if dist.is_initialized() else 0
         self.grid = grid or Grid(world, rank)
@@ -144,15 +149,22 @@ class CannonMultiply:
             engine = default_engine()
         self.eng = engine
         g = self.grid
-        sm = randmat.make_random_block_sizes(M, mix)
-        sn = randmat.make_random_block_sizes(N, mix_n or mix)
-        sk = randmat.make_random_block_sizes(K, mix_k or mix)
-        self.part = P = Partition(sm, sk, sn, g)
         c0 = randmat.RANDMAT_SEED_INIT
-        # global patterns, identical on every rank (C, A, B in the reference driver's order)
-        self.pat = {"C": randmat.random_pattern(len(sm), len(sn), sparsities[2], c0 + 1),
-                    "A": randmat.random_pattern(len(sm), len(sk), sparsities[0], c0 + 2),
-                    "B": randmat.random_pattern(len(sk), len(sn), sparsities[1], c0 + 3)}
+        if matrices is not None:
+            hA, hB, hC = matrices
+            sm, sk, sn = (np.asarray(x, np.int32) for x in (hA.row_sizes, hA.col_sizes, hB.col_sizes))
+            rows_of = lambda m: np.repeat(np.arange(len(m.row_sizes), dtype=np.int32), np.diff(np.asarray(m.row_p)))
+            self.pat = {w: (rows_of(m), np.asarray(m.col_i, np.int32)) for w, m in (("A", hA), ("B", hB), ("C", hC))}
+            self._host = {"A": hA, "B": hB, "C": hC}
+        else:
+            sm = randmat.make_random_block_sizes(M, mix)
+            sn = randmat.make_random_block_sizes(N, mix_n or mix)
+            sk = randmat.make_random_block_sizes(K, mix_k or mix)
+            # global patterns, identical on every rank (C, A, B in the reference driver's order)
+            self.pat = {"C": randmat.random_pattern(len(sm), len(sn), sparsities[2], c0 + 1),
+                        "A": randmat.random_pattern(len(sm), len(sk), sparsities[0], c0 + 2),
+                        "B": randmat.random_pattern(len(sk), len(sn), sparsities[1], c0 + 3)}
+        self.part = P = Partition(sm, sk, sn, g)
         self.counters = {"C": c0 + 1, "A": c0 + 2, "B": c0 + 3}
         self.nbr_g, self.nbk_g, self.nbc_g = len(sm), len(sk), len(sn)
         r, c = g.myprow, g.mypcol
@@ -221,7 +233,14 @@ class CannonMultiply:
         M = DbcsrMatrix(rs_t, cs_t, t(row_p, torch.int32), t(col_i, torch.int32), t(blk_p, torch.int64), data, which)
         M.data_numel = nze
         if fill and nze:
-            self.eng.fill_random_dist(M, self.counters[which], rgid, cgid, nrow_global)
+            if self._host is not None:  # cut the kept blocks out of the replicated global matrix
+                h = self._host[which]
+                hb, hd = np.asarray(h.blk_p, np.int64), np.asarray(h.data)
+                sizes = rsizes[rows[keep]].astype(np.int64) * csizes[cols[keep]].astype(np.int64)
+                src = hb[np.nonzero(keep)[0]]
+                M.data.copy_(torch.as_tensor(np.concatenate([hd[o:o + n] for o, n in zip(src, sizes)])).to(self.device))
+            else:
+                self.eng.fill_random_dist(M, self.counters[which], rgid, cgid, nrow_global)
         return M
 
     def _panel_blk_p(self, which, rdist, rsel, csel, k_dist, bases, imgs, rloc, cloc, rows_are_k):

@@ -33,8 +33,14 @@ def _worker(rank, world, port, alpha, beta, q, mode):
     try:
         from dbcsr_amd import cannon
         from tests.cpu_backend import OracleBackend
-        plan = cannon.CannonMultiply(CASE["M"], CASE["N"], CASE["K"], CASE["sp"], CASE["mix"], dtype=torch.float64,
-                                     engine=OracleBackend(), device=torch.device("cpu"), mix_n=CASE["mix_n"], mix_k=CASE["mix_k"], mode=mode)
+        if mode.endswith("+given"):  # replicated global host matrices instead of the built-in generator
+            A, B, Cm = O.perf_case(CASE["M"], CASE["N"], CASE["K"], *CASE["sp"], CASE["mix"], CASE["mix_n"], CASE["mix_k"])
+            plan = cannon.CannonMultiply(dtype=torch.float64, engine=OracleBackend(), device=torch.device("cpu"),
+                                         mode=mode.split("+")[0], matrices=(A, B, Cm))
+        else:
+            plan = cannon.CannonMultiply(CASE["M"], CASE["N"], CASE["K"], CASE["sp"], CASE["mix"], dtype=torch.float64,
+                                         engine=OracleBackend(), device=torch.device("cpu"), mix_n=CASE["mix_n"], mix_k=CASE["mix_k"],
+                                         mode=mode)
         Cout, counts = plan.multiply(alpha, beta)
         parts = plan.gather_global(Cout)
         fl = torch.tensor([counts.flop], dtype=torch.int64)
@@ -45,7 +51,7 @@ def _worker(rank, world, port, alpha, beta, q, mode):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,mode", [(2, "gather"), (4, "gather"), (6, "gather"), (4, "ticks"), (6, "ticks")])
+@pytest.mark.parametrize("world,mode", [(2, "gather"), (4, "gather+given"), (6, "gather"), (4, "ticks"), (6, "ticks+given")])
 def test_cannon_matches_global_oracle(world, mode):
     alpha, beta = 0.75, -1.25
     ctx = mp.get_context("spawn")
