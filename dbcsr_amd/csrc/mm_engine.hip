@@ -1052,6 +1052,99 @@ __global__ void __launch_bounds__(256) max_of(const int* __restrict__ v, int n, 
   }
 }
 
+// ---- fp32, LDS-staged (blocks up to 32 x 32; BASELINE config 5) -----------------------------------------
+// One v_mfma_f32_32x32x2_f32 covers the whole C block for 2 k.  A (m x k, column-major) is copied to LDS as
+// is: its fragment (lane = row, two k per instruction) reads 32 consecutive floats.  B is stored k x n with k
+// contiguous, but its fragment wants n across lanes at a fixed k -- 32 lanes 128 B apart would all hit one LDS
+// bank -- so B is written to LDS TRANSPOSED with a row pitch of 33 floats (Bt[j + 33 kk]); the staging write
+// computes (kk, j) per element with a multiply-shift division by the runtime k.
+__global__ void __launch_bounds__(256) mm_numeric_f32_lds(const Desc* __restrict__ descs, int64_t nblk, const Entry* __restrict__ entries,
+                                                          const float* __restrict__ a_data, const float* __restrict__ b_data,
+                                                          float* __restrict__ c_out, const float* __restrict__ c_in, float alpha,
+                                                          float beta, int skip_empty, const int* __restrict__ order) {
+  constexpr int CH = 4;            // 1 KiB chunks: 4 x 256 floats >= 32 x 32
+  constexpr int LDN = 33;          // pitch of the transposed B image
+  constexpr int A_FLOATS = 1024 + 64, BT_FLOATS = LDN * 32 + 31;
+  __shared__ __attribute__((aligned(16))) float smem[4 * (A_FLOATS + ((BT_FLOATS + 3) & ~3))];
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int64_t pos = (int64_t)wg * 4 + wid;
+  const int64_t cb = order[pos];
+  if (cb < 0 || cb >= nblk) return;
+  const Desc d = descs[cb];
+  if (skip_empty && d.prod_cnt == 0) return;
+  float* lds_a = smem + (size_t)wid * (A_FLOATS + ((BT_FLOATS + 3) & ~3));
+  float* lds_bt = lds_a + A_FLOATS;
+  const int m = d.m, n = d.n, cnt = d.prod_cnt;
+  const Entry* e = entries + d.prod_start;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  u32x4 ra[CH], rb[CH];
+  const int voff = lane * 16;
+  auto issue = [&](int p) {
+    const int ks = (int)e[p].ks;
+    const int abytes = m * ks * 4, bbytes = ks * n * 4;
+    const int nca = (m * (ks + 1) * 4 + 1023) >> 10, ncb = (bbytes + 1023) >> 10;  // A: one zero column of k padding
+    const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)(a_data + e[p].a_off), 0, abytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)(b_data + e[p].b_off), 0, bbytes, 0x00020000);
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+      if (c < nca) ra[c] = __builtin_amdgcn_raw_buffer_load_b128(rsa, voff, c * 1024, 0);
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+      if (c < ncb) rb[c] = __builtin_amdgcn_raw_buffer_load_b128(rsb, voff, c * 1024, 0);
+  };
+  if (cnt > 0) issue(0);
+  const int i = lane & 31, kh = lane >> 5;
+  const int arow = i < m ? i : m - 1, bcol = i < n ? i : n - 1;
+  for (int p = 0; p < cnt; ++p) {
+    const int ks = (int)e[p].ks;
+    const int kn = ks * n;
+    const int nca = (m * (ks + 1) * 4 + 1023) >> 10, ncb = (kn * 4 + 1023) >> 10;
+    const unsigned inv = (65536u + (unsigned)ks - 1u) / (unsigned)ks;  // j = (e * inv) >> 16 == e / ks for e < 2048, ks <= 32
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+      if (c < nca) *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(lds_a) + c * 1024 + voff) = ra[c];
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+      if (c < ncb) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const unsigned el = (unsigned)((c * 64 + lane) * 4 + t);
+          const unsigned j = (el * inv) >> 16, kk = el - j * (unsigned)ks;
+          if ((int)el < kn) lds_bt[j + LDN * kk] = __uint_as_float(rb[c][t]);
+        }
+      }
+    if (p + 1 < cnt) issue(p + 1);
+    // multiply: lane (i, kh) feeds A[i][2s + kh] and B[2s + kh][i]; the odd-k tail reads A's zero padding column
+    const int nsteps = (ks + 1) >> 1;
+    int aoff = arow + m * kh;
+    for (int s2 = 0; s2 < nsteps; ++s2) {
+      const int kk = 2 * s2 + kh;
+      const float av = lds_a[aoff];
+      const float bv = lds_bt[bcol + LDN * (kk < ks ? kk : ks - 1)];
+      aoff += 2 * m;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+  }
+  float* C = c_out + d.c_off;
+  const bool has_in = d.cin_off >= 0;
+  const float* Ci = c_in + (has_in ? d.cin_off : 0);
+  const int col = lane & 31;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    if (row < m && col < n) {
+      float v = alpha * acc[r];
+      if (has_in) v += beta * Ci[row + (size_t)m * col];
+      C[row + (size_t)m * col] = v;
+    }
+  }
+}
+
+
 __global__ void __launch_bounds__(256) mm_numeric_f32(const Desc* __restrict__ descs, int64_t nblk, const Entry* __restrict__ entries,
                                                       const float* __restrict__ a_data, const float* __restrict__ b_data,
                                                       float* __restrict__ c_out, const float* __restrict__ c_in, float alpha,
@@ -1693,7 +1786,14 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
                          static_cast<double*>(c_out->data), static_cast<const double*>(c_in->data), alpha, beta, skip_empty);
     }
   } else {
-    hipLaunchKernelGGL(mm_numeric_f32, dim3(nwg), dim3(256), 0, st, E->descs.p, nblk, E->entries.p,
+    const bool small32 = E->max_m <= 32 && E->max_k <= 32 && E->max_n <= 32 && E->min_m >= 1 && E->min_k >= 1 && E->min_n >= 1;
+    if (small32 && E->use_lds) {
+      const unsigned nwg_o = (unsigned)(8 * E->order_len / 4);
+      hipLaunchKernelGGL(mm_numeric_f32_lds, dim3(nwg_o), dim3(256), 0, st, E->descs.p, nblk, E->entries.p,
+                         static_cast<const float*>(a->data), static_cast<const float*>(b->data), static_cast<float*>(c_out->data),
+                         static_cast<const float*>(c_in->data), (float)alpha, (float)beta, skip_empty, E->order.p);
+    } else
+        hipLaunchKernelGGL(mm_numeric_f32, dim3(nwg), dim3(256), 0, st, E->descs.p, nblk, E->entries.p,
                        static_cast<const float*>(a->data), static_cast<const float*>(b->data), static_cast<float*>(c_out->data),
                        static_cast<const float*>(c_in->data), (float)alpha, (float)beta, skip_empty);
   }

@@ -180,3 +180,19 @@ def test_filter_eps_matches_oracle(eps, retain, alpha):
     assert np.array_equal(out.row_p, ref.row_p) and np.array_equal(out.col_i, ref.col_i) and np.array_equal(out.blk_p, ref.blk_p)
     assert flop[0] == info["flop"]
     assert rel_err(out.data, ref.data) <= TOL
+
+
+@pytest.mark.parametrize("mix", [[1, 13, 1, 23, 1, 32], [1, 5, 1, 7, 1, 9], [1, 31], [1, 1, 1, 3, 1, 4]])
+def test_fp32_mixed_sizes(mix):
+    # the fp32 kernel stages B transposed in LDS with a multiply-shift division by the runtime k: odd sizes matter
+    A, B, Cm = O.perf_case(330, 310, 290, 0.6, 0.6, 0.6, mix, mix, mix)
+    ref, info = O.multiply("N", "N", 0.5, A, B, 2.0, Cm)
+    f32 = lambda M: O.Bcsr(M.row_sizes, M.col_sizes, M.row_p, M.col_i, M.blk_p, M.data.astype(np.float32))
+    dA, dB, dC = to_dev(f32(A)), to_dev(f32(B)), to_dev(f32(Cm))
+    flop = [0]
+    dbcsr_multiply("N", "N", 0.5, dA, dB, 2.0, dC, flop=flop)
+    torch.cuda.synchronize()
+    out = dev_to_bcsr(dC)
+    assert np.array_equal(out.row_p, ref.row_p) and np.array_equal(out.col_i, ref.col_i) and np.array_equal(out.blk_p, ref.blk_p)
+    assert flop[0] == info["flop"]
+    assert float(np.max(np.abs(out.data - ref.data))) <= 1e-5 * float(np.max(np.abs(ref.data)))
