@@ -108,7 +108,7 @@ __device__ __forceinline__ void block_product_f64(double (&acc)[MA][NC], const d
 // a clamped (valid, finite) B element, so they contribute exact zeros without any
 // select on loaded values -- which lets the operand fetches of step s+1 stay in flight
 // under the MFMAs of step s (two-stage software pipeline).
-template <int MA, int NC>
+template <int MA, int NC, bool BT = false>
 __device__ __forceinline__ void block_product_f64_lds(double (&acc)[MA][NC], const double* lds_a, const double* lds_b, int m,
                                                       int n, int k, const LaneMap& L) {
   int aoff[MA], boff[NC];
@@ -122,15 +122,16 @@ __device__ __forceinline__ void block_product_f64_lds(double (&acc)[MA][NC], con
   for (int c = 0; c < NC; ++c) {
     int col = 8 * c + L.coll;
     col = col < n ? col : n - 1;
-    boff[c] = L.kq + k * col;
+    boff[c] = BT ? (col + n * L.kq) : (L.kq + k * col);  // BT: B staged as libsmm_acc_transpose leaves it (n x k)
   }
   const int nsteps = (k + 3) >> 2;
   const int astep = 4 * m;
+  const int bstep = BT ? 4 * n : 4;
   const int klast = k - 1 - L.kq;  // 4*s <= klast  <=>  this lane's k index is inside the block
   auto fetch = [&](int s, double (&av)[MA], double (&bv)[NC]) {
 #pragma unroll
     for (int a = 0; a < MA; ++a) av[a] = lds_a[aoff[a] + s * astep];
-    const int bs = 4 * s <= klast ? 4 * s : -L.kq;  // past the end: element (0, col), always valid
+    const int bs = 4 * s <= klast ? s * bstep : (BT ? -n * L.kq : -L.kq);  // past the end: element (k = 0, col), always valid
 #pragma unroll
     for (int c = 0; c < NC; ++c) bv[c] = lds_b[boff[c] + bs];
   };

@@ -61,6 +61,78 @@ __global__ void __launch_bounds__(256) smm_stack_f64(const int* __restrict__ sta
   }
 }
 
+
+// LDS-staged variant for blocks up to 32 x 32 (same staging as the device-resident engine, mm_engine.hip):
+// whole A and B blocks of a stack entry are copied with bounds-checked 1 KiB buffer loads into the wave's private
+// LDS slice, the next entry's blocks are in flight in registers meanwhile.
+typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
+
+template <int MA, int NC, bool BT>
+__global__ void __launch_bounds__(256) smm_stack_f64_lds(const int* __restrict__ stack, int nstack, const double* __restrict__ a_data,
+                                                         const double* __restrict__ b_data, double* __restrict__ c_data, int m,
+                                                         int n, int k, int lds_a_bytes, int lds_wave_bytes) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int CA = 2 * MA, CB = 2 * NC;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+  const int first = wave * kStackGroup;
+  if (first >= nstack) return;
+  const int last = min(first + kStackGroup, nstack);
+  char* lds_a = smem + (size_t)wid * lds_wave_bytes;
+  char* lds_b = lds_a + lds_a_bytes;
+  const LaneMap L(lane);
+  const int voff = lane * 16;
+  const int abytes = m * k * 8, bbytes = k * n * 8;
+  const int nca = (m * ((k + 3) & ~3) * 8 + 1023) >> 10, ncb = (bbytes + 1023) >> 10;
+  double acc[MA][NC];
+#pragma unroll
+  for (int a = 0; a < MA; ++a)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[a][c] = 0.0;
+  u32x4s ra[CA], rb[CB];
+  auto issue = [&](int s) {
+    const int ao = __builtin_amdgcn_readfirstlane(stack[3 * s]), bo = __builtin_amdgcn_readfirstlane(stack[3 * s + 1]);
+    const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)(a_data + (ao - 1)), 0, abytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)(b_data + (bo - 1)), 0, bbytes, 0x00020000);
+#pragma unroll
+    for (int c = 0; c < CA; ++c)
+      if (c < nca) ra[c] = __builtin_amdgcn_raw_buffer_load_b128(rsa, voff, c * 1024, 0);
+#pragma unroll
+    for (int c = 0; c < CB; ++c)
+      if (c < ncb) rb[c] = __builtin_amdgcn_raw_buffer_load_b128(rsb, voff, c * 1024, 0);
+  };
+  auto flush = [&](int co) {
+    double* C = c_data + (co - 1);
+#pragma unroll
+    for (int a = 0; a < MA; ++a)
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const int row = 8 * a + L.rowd, col = 8 * c + L.coll;
+        if (row < m && col < n) unsafeAtomicAdd(C + row + (size_t)m * col, acc[a][c]);
+        acc[a][c] = 0.0;
+      }
+  };
+  int cur_c = __builtin_amdgcn_readfirstlane(stack[3 * first + 2]);
+  issue(first);
+  for (int s = first; s < last; ++s) {
+    const int co = __builtin_amdgcn_readfirstlane(stack[3 * s + 2]);
+    if (co != cur_c) {
+      flush(cur_c);
+      cur_c = co;
+    }
+#pragma unroll
+    for (int c = 0; c < CA; ++c)
+      if (c < nca) *reinterpret_cast<u32x4s*>(lds_a + c * 1024 + voff) = ra[c];
+#pragma unroll
+    for (int c = 0; c < CB; ++c)
+      if (c < ncb) *reinterpret_cast<u32x4s*>(lds_b + c * 1024 + voff) = rb[c];
+    if (s + 1 < last) issue(s + 1);
+    block_product_f64_lds<MA, NC, BT>(acc, reinterpret_cast<const double*>(lds_a), reinterpret_cast<const double*>(lds_b), m, n, k, L);
+  }
+  flush(cur_c);
+}
+
 template <bool BT>
 __global__ void __launch_bounds__(256) smm_stack_f32(const int* __restrict__ stack, int nstack, const float* __restrict__ a_data,
                                                      const float* __restrict__ b_data, float* __restrict__ c_data, int m, int n,
@@ -131,6 +203,15 @@ __global__ void __launch_bounds__(256) block_norms_f64(const double* __restrict_
 template <int MA, int NC>
 static int launch_f64(bool bt, dim3 grid, hipStream_t st, const int* stack, int nstack, const double* a, const double* b, double* c,
                       int m, int n, int k) {
+  if (m <= 32 && n <= 32 && k <= 32 && grid.y == 1 && grid.z == 1) {  // LDS-staged kernel (whole blocks fit the staging chunks)
+    const int lds_a = ((m * ((k + 3) & ~3) * 8 + 1023) / 1024) * 1024, lds_b = ((k * n * 8 + 1023) / 1024) * 1024;
+    const size_t lds = (size_t)4 * (lds_a + lds_b);
+    if (bt)
+      hipLaunchKernelGGL((smm_stack_f64_lds<MA, NC, true>), grid, dim3(256), lds, st, stack, nstack, a, b, c, m, n, k, lds_a, lds_a + lds_b);
+    else
+      hipLaunchKernelGGL((smm_stack_f64_lds<MA, NC, false>), grid, dim3(256), lds, st, stack, nstack, a, b, c, m, n, k, lds_a, lds_a + lds_b);
+    return dbcsr_amd::check(hipGetLastError(), "smm_stack_f64_lds launch", __FILE__, __LINE__);
+  }
   if (bt)
     hipLaunchKernelGGL((smm_stack_f64<MA, NC, true>), grid, dim3(256), 0, st, stack, nstack, a, b, c, m, n, k);
   else
