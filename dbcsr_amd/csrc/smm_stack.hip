@@ -169,6 +169,88 @@ __global__ void __launch_bounds__(256) smm_stack_f32(const int* __restrict__ sta
   }
 }
 
+
+// fp32, blocks up to 32 x 32, LDS-staged: A copied as stored, B written transposed with a 33-float pitch (see
+// mm_numeric_f32_lds in mm_engine.hip for the reasoning).  fp32 stacks always carry B as stored (k x n): the
+// reference's transpose pass is a no-op for fp32 (libsmm_acc.cpp:484).
+__global__ void __launch_bounds__(256) smm_stack_f32_lds(const int* __restrict__ stack, int nstack, const float* __restrict__ a_data,
+                                                         const float* __restrict__ b_data, float* __restrict__ c_data, int m, int n,
+                                                         int k) {
+  constexpr int CH = 4, LDN = 33, A_FLOATS = 1024 + 64, BT_FLOATS = ((LDN * 32 + 31) + 3) & ~3;
+  __shared__ __attribute__((aligned(16))) float smem[4 * (A_FLOATS + BT_FLOATS)];
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+  const int first = wave * kStackGroup;
+  if (first >= nstack) return;
+  const int last = min(first + kStackGroup, nstack);
+  float* lds_a = smem + (size_t)wid * (A_FLOATS + BT_FLOATS);
+  float* lds_bt = lds_a + A_FLOATS;
+  const int voff = lane * 16;
+  const int kn = k * n;
+  const int nca = (m * (k + 1) * 4 + 1023) >> 10, ncb = (kn * 4 + 1023) >> 10;
+  const unsigned inv = (65536u + (unsigned)k - 1u) / (unsigned)k;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  u32x4s ra[CH], rb[CH];
+  auto issue = [&](int s) {
+    const int ao = __builtin_amdgcn_readfirstlane(stack[3 * s]), bo = __builtin_amdgcn_readfirstlane(stack[3 * s + 1]);
+    const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)(a_data + (ao - 1)), 0, m * k * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)(b_data + (bo - 1)), 0, kn * 4, 0x00020000);
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+      if (c < nca) ra[c] = __builtin_amdgcn_raw_buffer_load_b128(rsa, voff, c * 1024, 0);
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+      if (c < ncb) rb[c] = __builtin_amdgcn_raw_buffer_load_b128(rsb, voff, c * 1024, 0);
+  };
+  const int i = lane & 31, kh = lane >> 5;
+  const int arow = i < m ? i : m - 1, bcol = i < n ? i : n - 1;
+  auto flush = [&](int co) {
+    float* C = c_data + (co - 1);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (row < m && i < n) unsafeAtomicAdd(C + row + (size_t)m * i, acc[r]);
+      acc[r] = 0.0f;
+    }
+  };
+  int cur_c = __builtin_amdgcn_readfirstlane(stack[3 * first + 2]);
+  issue(first);
+  for (int s = first; s < last; ++s) {
+    const int co = __builtin_amdgcn_readfirstlane(stack[3 * s + 2]);
+    if (co != cur_c) {
+      flush(cur_c);
+      cur_c = co;
+    }
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+      if (c < nca) *reinterpret_cast<u32x4s*>(reinterpret_cast<char*>(lds_a) + c * 1024 + voff) = ra[c];
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+      if (c < ncb) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const unsigned el = (unsigned)((c * 64 + lane) * 4 + t);
+          const unsigned j = (el * inv) >> 16, kk = el - j * (unsigned)k;
+          if ((int)el < kn) lds_bt[j + LDN * kk] = __uint_as_float(rb[c][t]);
+        }
+      }
+    if (s + 1 < last) issue(s + 1);
+    const int nsteps = (k + 1) >> 1;
+    int aoff = arow + m * kh;
+    for (int s2 = 0; s2 < nsteps; ++s2) {
+      const int kk = 2 * s2 + kh;
+      const float av = lds_a[aoff];
+      const float bv = lds_bt[bcol + LDN * (kk < k ? kk : k - 1)];
+      aoff += 2 * m;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+  }
+  flush(cur_c);
+}
+
 // In-place transpose of listed m x n column-major blocks (-> n x m column-major).
 // One workgroup per block, the block staged in LDS.
 __global__ void __launch_bounds__(256) transpose_blocks_f64(const int* __restrict__ trs_stack, double* __restrict__ data, int m,
@@ -253,6 +335,10 @@ int process_stack_f32(const int* dev_stack, int nstack, const float* a, const fl
   if (m <= 0 || n <= 0 || k <= 0) return 0;
   const int nwaves = (nstack + kStackGroup - 1) / kStackGroup;
   dim3 grid((nwaves + 3) / 4, (m + 31) / 32, (n + 31) / 32);
+  if (!bt && m <= 32 && n <= 32 && k <= 32) {
+    hipLaunchKernelGGL(smm_stack_f32_lds, grid, dim3(256), 0, st, dev_stack, nstack, a, b, c, m, n, k);
+    return dbcsr_amd::check(hipGetLastError(), "smm_stack_f32_lds launch", __FILE__, __LINE__);
+  }
   if (bt)
     hipLaunchKernelGGL((smm_stack_f32<true>), grid, dim3(256), 0, st, dev_stack, nstack, a, b, c, m, n, k);
   else

@@ -79,6 +79,21 @@ def test_fp32_stack():
     assert rel_err(c, c_ref) <= 2e-3 * 1e-1  # acc_bench's fp32 epsilon is 2e-3 (acc_bench.c:69-71); we are far inside
 
 
+@pytest.mark.parametrize("m,n,k", [(13, 23, 7), (5, 9, 31), (32, 1, 3), (40, 33, 35)])
+def test_fp32_stack_odd_sizes(m, n, k):
+    na, nb, nc, nstack = 60, 70, 9, 500
+    rng = np.random.default_rng(m * 1000 + n * 10 + k)
+    a = rng.random(na * m * k, dtype=np.float32)
+    b = rng.random(nb * k * n, dtype=np.float32)
+    c0 = rng.random(nc * m * n, dtype=np.float32)
+    stack = O.stack_init(nstack, nc, na, nb, m, n, k, rseed=11)
+    c_ref = c0.astype(np.float64)
+    O.stack_calc(stack, c_ref, a.astype(np.float64), b.astype(np.float64), m, n, k, b_transposed=False)
+    rc, c = run_stack(stack, a, b, c0.copy(), m, n, k, L.dbcsr_type_real_4)
+    assert rc >= 0
+    assert float(np.max(np.abs(c - c_ref))) <= 2e-5 * float(np.max(np.abs(c_ref)))
+
+
 def test_return_codes():
     lib = L.load_library()
     st = StreamHandle()
