@@ -23,4 +23,18 @@ g++ -O2 -D__HIP -D__HIP_PLATFORM_AMD__ -ffunction-sections -fdata-sections -I/op
 g++ -O2 "$HERE/ref_stack_driver.cpp" "$OUT/libsmm_acc_benchmark.o" -Wl,--gc-sections -L/opt/rocm/lib -lamdhip64 \
     -Wl,-rpath,/opt/rocm/lib -o "$OUT/ref_stack_driver"
 rm -f "$OUT/libsmm_acc_benchmark.o"
-echo "built $OUT/dbcsr_acc_test $OUT/ref_stack_driver"
+# Fortran host check: the reference's own device-binding module (src/acc/dbcsr_acc_device.F + the base modules it
+# uses; these need no fypp) compiled with amdflang where they lie, linked with tests/fortran/dbcsr_amd_host_check.F90
+# and THIS repo's library.  (dbcsr_acc_stream/event/init/devmem pull in dbcsr_config -> dbcsr_mpiwrap -> fypp and are
+# not buildable here.)
+if command -v amdflang >/dev/null 2>&1; then
+  TMPF="$(mktemp -d)"
+  FFLAGS="-cpp -ffree-form -O1 -D__DBCSR_ACC -D__HIP -I$REF/src -I$REF/src/base -I$TMPF -module-dir $TMPF"
+  for f in base/dbcsr_kinds.F base/dbcsr_machine_internal.F base/dbcsr_machine.F base/dbcsr_base_hooks.F acc/dbcsr_acc_device.F; do
+    amdflang $FFLAGS -c "$REF/src/$f" -o "$TMPF/$(basename $f .F).o"
+  done
+  amdflang $FFLAGS -c "$HERE/../tests/fortran/dbcsr_amd_host_check.F90" -o "$TMPF/host_check.o"
+  amdflang -o "$OUT/fortran_host_check" "$TMPF"/*.o -L"$HERE/../dbcsr_amd" -ldbcsr_acc_amd -Wl,-rpath,'$ORIGIN/../../dbcsr_amd'
+  rm -rf "$TMPF"
+fi
+echo "built $(ls $OUT | tr '\n' ' ')"

@@ -21,6 +21,18 @@ def test_reference_spec_program_passes():
     assert r.returncode == 0, r.stderr.decode()[-2000:]
 
 
+FBIN = os.path.join(os.path.dirname(BIN), "fortran_host_check")
+
+
+@pytest.mark.skipif(not os.path.exists(FBIN), reason="oracle/_ref/fortran_host_check not built (needs amdflang + /root/reference)")
+def test_fortran_host_through_iso_c_binding():
+    # a Fortran program (amdflang) using the reference's own dbcsr_acc_device module and ISO_C_BINDING interfaces of the
+    # acc ABI: libsmm_acc_transpose + libsmm_acc_process on a 23x23x23 stack, checked against MATMUL
+    r = subprocess.run([FBIN], capture_output=True, timeout=120)
+    assert r.returncode == 0, (r.stdout.decode()[-500:], r.stderr.decode()[-1500:])
+    assert b"fortran host check" in r.stdout
+
+
 def test_acc_interface_expectations():
     lib = L.load_library()
     n = C.c_int(0)
