@@ -1476,7 +1476,7 @@ struct Engine {
   int max_m = 0, max_k = 0, max_n = 0, min_m = 0, min_k = 0, min_n = 0;
   bool grid_kernels = false, force_word_kernels = false;  // DBCSR_AMD_MM_SYMBOLIC=word forces the per-word symbolic kernels
   int dbg = 0;      // DBCSR_AMD_MM_DBG: ablation switches of the LDS kernel (profiling only)
-  int use_pipe = 0, pipe_g = 8;  // DBCSR_AMD_MM_KERNEL=pipe selects the multi-block pipelined kernel (measured slower); DBCSR_AMD_MM_PIPE_G = blocks per wave
+  int use_pipe = -1, pipe_g = 8;  // multi-block pipelined kernel: -1 automatic (short product lists only), DBCSR_AMD_MM_KERNEL=pipe|lds1 forces; DBCSR_AMD_MM_PIPE_G = blocks per wave
   int use_lds = 1;  // DBCSR_AMD_MM_KERNEL=direct selects the v1 kernel (A/B experiments)
 };
 
@@ -1514,7 +1514,7 @@ int dbcsr_amd_mm_create(void** handle) {
   }
   if (const char* k = getenv("DBCSR_AMD_MM_KERNEL")) {
     E->use_lds = strcmp(k, "direct") != 0;
-    E->use_pipe = strcmp(k, "pipe") == 0;
+    E->use_pipe = strcmp(k, "pipe") == 0 ? 1 : (strcmp(k, "lds1") == 0 ? 0 : -1);
   }
   if (const char* k = getenv("DBCSR_AMD_MM_PIPE_G")) E->pipe_g = std::max(1, atoi(k));
   if (const char* k = getenv("DBCSR_AMD_MM_DBG")) E->dbg = atoi(k);
@@ -1756,7 +1756,10 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
   hipLaunchKernelGGL(mm_numeric_f64_lds<T_>, dim3(nwg_o), dim3(256), lds_bytes, st, E->descs.p, nblk, E->entries.p,               \
                      static_cast<const double*>(a->data), static_cast<const double*>(b->data), static_cast<double*>(c_out->data), \
                      static_cast<const double*>(c_in->data), alpha, beta, lds_a, lds_wave, E->dbg | (skip_empty ? 32 : 0), E->order.p)
-      if (E->use_pipe) {
+      // measured: the pipelined kernel wins when C blocks have few products (config 3: 3.7 per block, 10.4 vs 11.8 ms) and
+      // loses when they have many (config 2: 14.4 per block, 32 vs 22 ms)
+      const bool pipe = E->use_pipe == 1 || (E->use_pipe < 0 && E->nproducts < 6 * nblk && E->nproducts > nblk + nblk / 2);
+      if (pipe) {
         const int64_t npos = 8 * E->order_len;
         const int G = E->pipe_g;
         const unsigned nwg_p = (unsigned)((npos + 4 * (int64_t)G - 1) / (4 * (int64_t)G));
