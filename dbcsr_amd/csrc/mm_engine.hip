@@ -745,12 +745,16 @@ __device__ __forceinline__ void cblock_f64_lds(const Desc& d, const Entry* __res
   const int cnt = d.prod_cnt;
   u32x4 ra[CA], rb[CB];
   const int voff = lane * 16;
-  auto issue = [&](int p) {
-    const int ks = (int)e[p].ks;
+  // The product-list entries are kept two ahead in scalar registers: entry p+1 is needed when product p's operands
+  // have been copied to LDS (to start the next prefetch), so it is requested one trip earlier and its scalar-load
+  // latency never sits between the LDS copy and the MFMAs.
+  auto issue = [&](uint32_t a_off, uint32_t b_off_in, int ks) {
     const int abytes = m * ks * 8, bbytes = ks * n * 8;
     const int nca = (m * ((ks + 3) & ~3) * 8 + 1023) >> 10, ncb = (bbytes + 1023) >> 10;
-    const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)(a_data + e[p].a_off), 0, abytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)(b_data + e[p].b_off), 0, bbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)(a_data + a_off), 0, abytes, 0x00020000);
+    // dbg 128 (profiling only): fold all B blocks onto the first 1 MB of B -> L2-resident; isolates the cost of L2 misses
+    const uint32_t b_off = (dbg & 128) ? (b_off_in % (uint32_t)(131072 - 1024)) : b_off_in;
+    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)(b_data + b_off), 0, bbytes, 0x00020000);
 #pragma unroll
     for (int c = 0; c < CA; ++c)
       if (c < nca) ra[c] = __builtin_amdgcn_raw_buffer_load_b128(rsa, voff, c * 1024, 0);
@@ -766,9 +770,11 @@ __device__ __forceinline__ void cblock_f64_lds(const Desc& d, const Entry* __res
 #pragma unroll
     for (int c = 0; c < CB; ++c) rb[c] = u32x4{0u, 0x3ff00000u, 0u, 0x3ff00000u};
   }
-  if (cnt > 0 && !(dbg & 1)) issue(0);
+  Entry e0 = cnt > 0 ? e[0] : Entry{0u, 0u, 1u};            // product p (being staged / multiplied)
+  Entry e1 = cnt > 1 ? e[1] : e0;                            // product p + 1 (prefetched next)
+  if (cnt > 0 && !(dbg & 1)) issue(e0.a_off, e0.b_off, (int)e0.ks);
   for (int p = 0; p < cnt; ++p) {
-    const int ks = (int)e[p].ks;
+    const int ks = (int)e0.ks;
     if (!(dbg & 4)) {
       const int nca = (m * ((ks + 3) & ~3) * 8 + 1023) >> 10, ncb = (ks * n * 8 + 1023) >> 10;
 #pragma unroll
@@ -778,9 +784,12 @@ __device__ __forceinline__ void cblock_f64_lds(const Desc& d, const Entry* __res
       for (int c = 0; c < CB; ++c)
         if (c < ncb) *reinterpret_cast<u32x4*>(lds_b + c * 1024 + voff) = rb[c];
     }
-    if (p + 1 < cnt && !(dbg & 1)) issue(p + 1);
+    if (p + 1 < cnt && !(dbg & 1)) issue(e1.a_off, e1.b_off, (int)e1.ks);
+    const Entry e2 = e[p + 2 < cnt ? p + 2 : cnt - 1];      // requested now, first used one trip later
     if (!(dbg & 2))
       block_product_f64_lds<MA, NC>(acc, reinterpret_cast<const double*>(lds_a), reinterpret_cast<const double*>(lds_b), m, n, ks, L);
+    e0 = e1;
+    e1 = e2;
   }
   double* C = c_out + d.c_off;
   const bool has_in = d.cin_off >= 0;
@@ -1746,8 +1755,11 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
     // LDS path: blocks of at most 32 x 32 (any smaller size: the staging loads are bounds-checked buffer loads)
     const bool small = E->max_m <= 32 && E->max_k <= 32 && E->max_n <= 32 && E->min_m >= 1 && E->min_k >= 1 && E->min_n >= 1;
     if (small && E->use_lds) {
-      // per-wave LDS slice: whole 1 KiB staging chunks (128 doubles) for the largest A (k padded to 4) and B block
-      const int lds_a = ((E->max_m * ((E->max_k + 3) & ~3) + 127) / 128) * 128, lds_b = ((E->max_k * E->max_n + 127) / 128) * 128;
+      // per-wave LDS slice.  Staging writes whole 1 KiB chunks (128 doubles), A's chunks first, then B's: the B part may
+      // start right after A's (zero-padded) block -- the tail of A's last chunk is simply overwritten by B's first chunk
+      // (one wave, in-order LDS queue) -- and only B's part is rounded up to whole chunks.  For 23x23 blocks this is
+      // 9.5 KB per wave instead of 10 KB, which is what lets a 4th workgroup (16 waves) fit the CU's 160 KB.
+      const int lds_a = (E->max_m * ((E->max_k + 3) & ~3) + 1) & ~1, lds_b = ((E->max_k * E->max_n + 127) / 128) * 128;
       const int lds_wave = lds_a + lds_b;
       const int maxt = (std::max(E->max_m, E->max_n) + 7) / 8;
       const size_t lds_bytes = (size_t)4 * lds_wave * sizeof(double);
