@@ -52,6 +52,14 @@ def load_library():
     if _LIB is not None:
         return _LIB
     path = library_path()
+    # PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64.  The HIP runtime that is loaded FIRST wins
+    # (same SONAME); if this library were loaded before torch, two different runtimes could end up in one process and
+    # device pointers allocated by torch would be foreign to the one this library talks to.  So when torch is
+    # installed, make sure it is loaded first.  (Pure C/Fortran hosts link the library against /opt/rocm directly.)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(path):
         raise RuntimeError(
             "dbcsr_amd: native library %s not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
