@@ -807,6 +807,152 @@ __device__ __forceinline__ void cblock_f64_lds(const Desc& d, const Entry* __res
     }
 }
 
+// ---- exact-size variant ------------------------------------------------------
+// Specialisation for C blocks of M x N whose products have inner dimension K, all compile-time (what the
+// reference's JIT does per (m, n, k) triple): chunk counts, LDS fragment offsets and the k loop are constants, so
+// a product costs its buffer loads, LDS copies, ds_reads with immediate offsets and MFMAs and next to nothing else
+// (the generic path: 103 VALU + 98 SALU instructions per 23^3 product besides the 54 MFMAs).  Products of the
+// block with another inner dimension (the tail block column of A) are multiplied straight from global memory.
+template <int M, int N, int K>
+__device__ __forceinline__ void cblock_f64_exact(const Desc& d, const Entry* __restrict__ entries, const double* __restrict__ a_data,
+                                                 const double* __restrict__ b_data, double* __restrict__ c_out,
+                                                 const double* __restrict__ c_in, double alpha, double beta, const LaneMap& L, int lane,
+                                                 char* lds_a, char* lds_b, int dbg) {
+  constexpr int MA = (M + 7) / 8, NC = (N + 7) / 8, KS = (K + 3) / 4, K4 = 4 * KS;
+  constexpr int CA = (M * K4 * 8 + 1023) / 1024, CB = (K * N * 8 + 1023) / 1024;
+  double acc[MA][NC];
+#pragma unroll
+  for (int a = 0; a < MA; ++a)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[a][c] = 0.0;
+  const Entry* e = entries + d.prod_start;
+  const int cnt = d.prod_cnt;
+  u32x4 ra[CA], rb[CB];
+  const int voff = lane * 16;
+  // fragment addresses: constant for the whole life of the wave
+  const double* pa[MA];
+  const double* pb[NC];
+  const double* pbt[NC];  // last k step when K is not a multiple of 4: lanes past the end read element (0, col) (A's padding is zero)
+#pragma unroll
+  for (int a = 0; a < MA; ++a) {
+    int row = 8 * a + L.rowl;
+    row = row < M ? row : M - 1;
+    pa[a] = reinterpret_cast<const double*>(lds_a) + row + M * L.kq;
+  }
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    int col = 8 * c + L.coll;
+    col = col < N ? col : N - 1;
+    pb[c] = reinterpret_cast<const double*>(lds_b) + L.kq + K * col;
+    const int kt = 4 * (KS - 1) + L.kq;
+    pbt[c] = reinterpret_cast<const double*>(lds_b) + (kt < K ? kt : 0) + K * col;
+  }
+  auto issue = [&](uint32_t a_off, uint32_t b_off_in) {
+    if (dbg & 1) return;
+    const uint32_t fold = (dbg >> 16) ? (uint32_t)(dbg >> 16) * 65536u : 131072u;  // B window of the L2/MALL experiments, doubles
+    const uint32_t b_off = (dbg & 128) ? (b_off_in % (fold - 1024u)) : b_off_in;
+    const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)(a_data + a_off), 0, M * K * 8, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)(b_data + b_off), 0, K * N * 8, 0x00020000);
+#pragma unroll
+    for (int c = 0; c < CA; ++c) ra[c] = __builtin_amdgcn_raw_buffer_load_b128(rsa, voff, c * 1024, 0);
+    // (measured on the streamed B loads: sc0 / sc1 / sc0+sc1 make no difference, nt costs +30 %)
+#pragma unroll
+    for (int c = 0; c < CB; ++c) rb[c] = __builtin_amdgcn_raw_buffer_load_b128(rsb, voff, c * 1024, 0);
+  };
+  // Products with inner dimension K run through the staged pipeline (i0 = the one being multiplied, i1 = the next
+  // candidate, whose list entry was requested one trip earlier); the others are summed afterwards.
+  int i0 = 0;
+  Entry e0 = e[0];
+  while (i0 < cnt && (int)e0.ks != K) {
+    ++i0;
+    e0 = e[i0 < cnt ? i0 : cnt - 1];
+  }
+  int i1 = i0 + 1;
+  Entry e1 = e[i1 < cnt ? i1 : cnt - 1];
+  if (dbg & 1) {
+#pragma unroll
+    for (int c = 0; c < CA; ++c) ra[c] = u32x4{0u, 0x3ff00000u, 0u, 0x3ff00000u};
+#pragma unroll
+    for (int c = 0; c < CB; ++c) rb[c] = u32x4{0u, 0x3ff00000u, 0u, 0x3ff00000u};
+  }
+  if (i0 < cnt) issue(e0.a_off, e0.b_off);
+  while (i0 < cnt) {
+    if (!(dbg & 4)) {
+#pragma unroll
+      for (int c = 0; c < CA; ++c) *reinterpret_cast<u32x4*>(lds_a + c * 1024 + voff) = ra[c];
+#pragma unroll
+      for (int c = 0; c < CB; ++c) *reinterpret_cast<u32x4*>(lds_b + c * 1024 + voff) = rb[c];
+    }
+    while (i1 < cnt && (int)e1.ks != K) {
+      ++i1;
+      e1 = e[i1 < cnt ? i1 : cnt - 1];
+    }
+    if (i1 < cnt) issue(e1.a_off, e1.b_off);
+    const Entry e2 = e[i1 + 1 < cnt ? i1 + 1 : cnt - 1];
+    if (!(dbg & 2))
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      double av[MA], bv[NC];
+#pragma unroll
+      for (int a = 0; a < MA; ++a) av[a] = pa[a][s * 4 * M];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) bv[c] = (s == KS - 1 && (K & 3)) ? pbt[c][0] : pb[c][4 * s];
+#pragma unroll
+      for (int a = 0; a < MA; ++a)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[a][c] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[a], bv[c], acc[a][c], 0, 0, 0);
+    }
+    i0 = i1;
+    e0 = e1;
+    i1 = i1 + 1;
+    e1 = e2;
+  }
+  for (int p = 0; p < cnt; ++p) {
+    const Entry ep = e[p];
+    if ((int)ep.ks != K) block_product_f64<MA, NC, false>(acc, a_data + ep.a_off, b_data + ep.b_off, M, N, (int)ep.ks, L);
+  }
+  double* C = c_out + d.c_off;
+  const bool has_in = d.cin_off >= 0;
+  const double* Ci = c_in + (has_in ? d.cin_off : 0);
+#pragma unroll
+  for (int a = 0; a < MA; ++a)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int row = 8 * a + L.rowd, col = 8 * c + L.coll;
+      if (row < M && col < N) {
+        double v = alpha * acc[a][c];
+        if (has_in) v += beta * Ci[row + (size_t)M * col];
+        C[row + (size_t)M * col] = v;
+      }
+    }
+}
+
+// C blocks of exactly M x N take the exact-size path; every other block of the launch the generic one.
+template <int M, int N, int K>
+__global__ void __launch_bounds__(256) mm_numeric_f64_hot(const Desc* __restrict__ descs, int64_t nblk, const Entry* __restrict__ entries,
+                                                          const double* __restrict__ a_data, const double* __restrict__ b_data,
+                                                          double* __restrict__ c_out, const double* __restrict__ c_in, double alpha,
+                                                          double beta, int lds_a_doubles, int lds_wave_doubles, int dbg, const int* __restrict__ order) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int64_t pos = (int64_t)wg * 4 + wid;
+  const int64_t cb = order[pos];
+  if (cb < 0 || cb >= nblk) return;
+  if ((dbg & 32) && descs[cb].prod_cnt == 0) return;
+  char* lds_a = smem + (size_t)wid * lds_wave_doubles * 8;
+  char* lds_b = lds_a + (size_t)lds_a_doubles * 8;
+  const Desc d = descs[cb];
+  const LaneMap L(lane);
+  if (d.m == M && d.n == N) {
+    cblock_f64_exact<M, N, K>(d, entries, a_data, b_data, c_out, c_in, alpha, beta, L, lane, lds_a, lds_b, dbg);
+    return;
+  }
+  // the few blocks of another size (tail block row / column): straight from global memory, as one 32 x 32 tile
+  cblock_f64<4, 4>(d, entries, a_data, b_data, c_out, c_in, alpha, beta, L, 0, 0);
+}
+
 // all block dimensions of the launch are <= 8*MAXT (<= 32); lds_wave_doubles = per-wave LDS slice (A part then B part).
 // MAXT bounds the register allocation to what the largest block class present needs.
 template <int MAXT>
@@ -1058,6 +1204,28 @@ __global__ void __launch_bounds__(256) max_of(const int* __restrict__ v, int n, 
   if ((threadIdx.x & 63) == 0) {
     atomicMax(out, mx);
     atomicMax(out + 1, mn);
+  }
+}
+
+// most frequent value among the entries of v that lie in 1..32: out[0] = value (0: none), out[1] = how often
+__global__ void __launch_bounds__(256) mode_of(const int* __restrict__ v, int n, int* __restrict__ out) {
+  __shared__ int h[33];
+  if (threadIdx.x < 33) h[threadIdx.x] = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int s = v[i];
+    if (s >= 1 && s <= 32) atomicAdd(&h[s], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int best = 0, cnt = 0;
+    for (int s = 1; s <= 32; ++s)
+      if (h[s] > cnt) {
+        cnt = h[s];
+        best = s;
+      }
+    out[0] = best;
+    out[1] = cnt;
   }
 }
 
@@ -1458,6 +1626,28 @@ __global__ void __launch_bounds__(256) filter_compact(const int* __restrict__ ro
 // ----------------------------------------------------------------------------
 // host side
 // ----------------------------------------------------------------------------
+// Exact-size kernels are instantiated for cubes of the block sizes CP2K's basis sets and the reference's
+// benchmarks produce (the reference compiles one kernel per (m, n, k) at run time; here the list is fixed at build time
+// and every other case runs the generic kernel; measured on 4 x 4 blocks the generic kernel is 7 % faster, so sizes
+// up to 8 are left to it).
+#define DBCSR_AMD_HOT_SIZES(X) X(9) X(10) X(12) X(13) X(14) X(16) X(17) X(20) X(22) X(23) X(24) X(25) X(26) X(28) X(29) X(32)
+
+static bool launch_hot_f64(int m, int n, int k, dim3 grid, size_t lds_bytes, hipStream_t st, const Desc* descs, int64_t nblk,
+                           const Entry* entries, const double* a_data, const double* b_data, double* c_out, const double* c_in,
+                           double alpha, double beta, int lds_a, int lds_wave, int dbg, const int* order) {
+  if (m != n || m != k) return false;
+  switch (m) {
+#define DBCSR_HOT_CASE(S_)                                                                                                      \
+  case S_:                                                                                                                      \
+    hipLaunchKernelGGL((mm_numeric_f64_hot<S_, S_, S_>), grid, dim3(256), lds_bytes, st, descs, nblk, entries, a_data, b_data, c_out, \
+                       c_in, alpha, beta, lds_a, lds_wave, dbg, order);                                                         \
+    return true;
+    DBCSR_AMD_HOT_SIZES(DBCSR_HOT_CASE)
+#undef DBCSR_HOT_CASE
+    default: return false;
+  }
+}
+
 struct Engine {
   DevBuf<uint32_t> b_bm, c_bm, cin_bm;
   DevBuf<int> b_pre, c_pre, cin_pre, row_nnz, prod_cnt, blk_nze, tmp_i32;
@@ -1472,7 +1662,10 @@ struct Engine {
   DevBuf<int> order, order_cnt;
   DevBuf<int64_t> order_base;
   int64_t order_len = 0;
-  int64_t panel_bytes = 96ll << 20;  // DBCSR_AMD_MM_PANEL_MB: target size of a B column panel
+  int hot_m = 0, hot_n = 0, hot_k = 0;  // dominant block sizes of the last symbolic phase (0: none)
+  int use_hot = 1;                      // DBCSR_AMD_MM_HOT=0: never use the exact-size kernels
+  int lds_pad = 0;                      // DBCSR_AMD_MM_LDS_PAD: extra LDS bytes per workgroup (occupancy experiments)
+  int64_t panel_bytes = 160ll << 20;  // DBCSR_AMD_MM_PANEL_MB: target size of a B column panel
   int row_group = 0;                 // DBCSR_AMD_MM_ROW_GROUP: rows walked together per XCD (0 = automatic)
   DevBuf<unsigned long long> dev_scalars;
   int64_t* host_scalars = nullptr;  // pinned: [0]=c_nblks [1]=c_nze [2]=nproducts [3]=flop
@@ -1527,6 +1720,8 @@ int dbcsr_amd_mm_create(void** handle) {
   }
   if (const char* k = getenv("DBCSR_AMD_MM_PIPE_G")) E->pipe_g = std::max(1, atoi(k));
   if (const char* k = getenv("DBCSR_AMD_MM_DBG")) E->dbg = atoi(k);
+  if (const char* k = getenv("DBCSR_AMD_MM_HOT")) E->use_hot = atoi(k);
+  if (const char* k = getenv("DBCSR_AMD_MM_LDS_PAD")) E->lds_pad = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_SYMBOLIC")) E->force_word_kernels = strcmp(k, "word") == 0;
   if (const char* k = getenv("DBCSR_AMD_MM_PANEL_MB")) E->panel_bytes = (int64_t)atoll(k) << 20;
   if (const char* k = getenv("DBCSR_AMD_MM_ROW_GROUP")) E->row_group = atoi(k);
@@ -1655,9 +1850,14 @@ int dbcsr_amd_mm_symbolic_filtered(void* handle, libsmm_acc_data_t datatype, dou
     hipLaunchKernelGGL(max_of, dim3(1), dim3(256), 0, st, a->row_blk_size, nbr, mx + 0);
     hipLaunchKernelGGL(max_of, dim3(1), dim3(256), 0, st, a->col_blk_size, nbk, mx + 2);
     hipLaunchKernelGGL(max_of, dim3(1), dim3(256), 0, st, b->col_blk_size, nbc, mx + 4);
+    // ... and the most frequent block size per dimension (choice of an exact-size kernel)
+    int* md = reinterpret_cast<int*>(E->dev_scalars.p + 8);
+    hipLaunchKernelGGL(mode_of, dim3(1), dim3(256), 0, st, a->row_blk_size, nbr, md + 0);
+    hipLaunchKernelGGL(mode_of, dim3(1), dim3(256), 0, st, a->col_blk_size, nbk, md + 2);
+    hipLaunchKernelGGL(mode_of, dim3(1), dim3(256), 0, st, b->col_blk_size, nbc, md + 4);
   }
   // need c_nblks (and the block-size extrema) on the host to size per-block work arrays
-  ACC_CHECK(hipMemcpyAsync(E->host_scalars, dsc, 8 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+  ACC_CHECK(hipMemcpyAsync(E->host_scalars, dsc, 11 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
   ACC_CHECK(hipStreamSynchronize(st));
   const int64_t c_nblks = E->host_scalars[0];
   {
@@ -1665,6 +1865,12 @@ int dbcsr_amd_mm_symbolic_filtered(void* handle, libsmm_acc_data_t datatype, dou
     E->max_m = mx[0]; E->min_m = -mx[1];
     E->max_k = mx[2]; E->min_k = -mx[3];
     E->max_n = mx[4]; E->min_n = -mx[5];
+    // exact-size kernel: only when one (m, n, k) covers at least 90 % of the block rows / columns of each dimension
+    const int* md = reinterpret_cast<const int*>(E->host_scalars + 8);
+    const bool dominant = 10ll * md[1] >= 9ll * nbr && 10ll * md[3] >= 9ll * nbk && 10ll * md[5] >= 9ll * nbc;
+    E->hot_m = dominant ? md[0] : 0;
+    E->hot_k = dominant ? md[2] : 0;
+    E->hot_n = dominant ? md[4] : 0;
   }
   // processing order of the numeric phase: column panels sized for the Infinity Cache, rows dealt to XCDs
   const int64_t b_bytes_est = b->nblks * (int64_t)E->max_k * E->max_n * (int64_t)sizeof(double);
@@ -1762,7 +1968,7 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
       const int lds_a = (E->max_m * ((E->max_k + 3) & ~3) + 1) & ~1, lds_b = ((E->max_k * E->max_n + 127) / 128) * 128;
       const int lds_wave = lds_a + lds_b;
       const int maxt = (std::max(E->max_m, E->max_n) + 7) / 8;
-      const size_t lds_bytes = (size_t)4 * lds_wave * sizeof(double);
+      const size_t lds_bytes = (size_t)4 * lds_wave * sizeof(double) + (size_t)E->lds_pad;
       const unsigned nwg_o = (unsigned)(8 * E->order_len / 4);
 #define DBCSR_LAUNCH(T_)                                                                                                        \
   hipLaunchKernelGGL(mm_numeric_f64_lds<T_>, dim3(nwg_o), dim3(256), lds_bytes, st, E->descs.p, nblk, E->entries.p,               \
@@ -1770,6 +1976,12 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
                      static_cast<const double*>(c_in->data), alpha, beta, lds_a, lds_wave, E->dbg | (skip_empty ? 32 : 0), E->order.p)
       // measured: the pipelined kernel wins when C blocks have few products (config 3: 3.7 per block, 10.4 vs 11.8 ms) and
       // loses when they have many (config 2: 14.4 per block, 32 vs 22 ms)
+      if (E->use_hot && E->use_pipe != 1 && E->hot_m > 0 &&
+          launch_hot_f64(E->hot_m, E->hot_n, E->hot_k, dim3(nwg_o), lds_bytes, st, E->descs.p, nblk, E->entries.p,
+                         static_cast<const double*>(a->data), static_cast<const double*>(b->data), static_cast<double*>(c_out->data),
+                         static_cast<const double*>(c_in->data), alpha, beta, lds_a, lds_wave, E->dbg | (skip_empty ? 32 : 0), E->order.p)) {
+        // launched: C blocks of the dominant size take the exact-size path, the others the generic one
+      } else {
       const bool pipe = E->use_pipe == 1 || (E->use_pipe < 0 && E->nproducts < 6 * nblk && E->nproducts > nblk + nblk / 2);
       if (pipe) {
         const int64_t npos = 8 * E->order_len;
@@ -1793,6 +2005,7 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
           case 3: DBCSR_LAUNCH(3); break;
           default: DBCSR_LAUNCH(4); break;
         }
+      }
       }
 #undef DBCSR_LAUNCH
     } else {
