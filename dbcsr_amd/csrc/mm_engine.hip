@@ -1235,24 +1235,16 @@ __global__ void __launch_bounds__(256) mode_of(const int* __restrict__ v, int n,
 // contiguous, but its fragment wants n across lanes at a fixed k -- 32 lanes 128 B apart would all hit one LDS
 // bank -- so B is written to LDS TRANSPOSED with a row pitch of 33 floats (Bt[j + 33 kk]); the staging write
 // computes (kk, j) per element with a multiply-shift division by the runtime k.
-__global__ void __launch_bounds__(256) mm_numeric_f32_lds(const Desc* __restrict__ descs, int64_t nblk, const Entry* __restrict__ entries,
-                                                          const float* __restrict__ a_data, const float* __restrict__ b_data,
-                                                          float* __restrict__ c_out, const float* __restrict__ c_in, float alpha,
-                                                          float beta, int skip_empty, const int* __restrict__ order) {
-  constexpr int CH = 4;            // 1 KiB chunks: 4 x 256 floats >= 32 x 32
-  constexpr int LDN = 33;          // pitch of the transposed B image
-  constexpr int A_FLOATS = 1024 + 64, BT_FLOATS = LDN * 32 + 31;
-  __shared__ __attribute__((aligned(16))) float smem[4 * (A_FLOATS + ((BT_FLOATS + 3) & ~3))];
-  const int lane = threadIdx.x & 63;
-  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int64_t pos = (int64_t)wg * 4 + wid;
-  const int64_t cb = order[pos];
-  if (cb < 0 || cb >= nblk) return;
-  const Desc d = descs[cb];
-  if (skip_empty && d.prod_cnt == 0) return;
-  float* lds_a = smem + (size_t)wid * (A_FLOATS + ((BT_FLOATS + 3) & ~3));
-  float* lds_bt = lds_a + A_FLOATS;
+constexpr int F32_CH = 4;            // 1 KiB chunks: 4 x 256 floats >= 32 x 32
+constexpr int F32_LDN = 33;          // pitch of the transposed B image
+constexpr int F32_A_FLOATS = 1024 + 64, F32_BT_FLOATS = F32_LDN * 32 + 31;
+constexpr int F32_WAVE_FLOATS = F32_A_FLOATS + ((F32_BT_FLOATS + 3) & ~3);
+
+__device__ __forceinline__ void cblock_f32_lds(const Desc& d, const Entry* __restrict__ entries, const float* __restrict__ a_data,
+                                               const float* __restrict__ b_data, float* __restrict__ c_out,
+                                               const float* __restrict__ c_in, float alpha, float beta, int lane, float* lds_a,
+                                               float* lds_bt) {
+  constexpr int CH = F32_CH, LDN = F32_LDN;
   const int m = d.m, n = d.n, cnt = d.prod_cnt;
   const Entry* e = entries + d.prod_start;
   f32x16 acc;
@@ -1321,6 +1313,130 @@ __global__ void __launch_bounds__(256) mm_numeric_f32_lds(const Desc* __restrict
   }
 }
 
+// Exact-size fp32 variant (see cblock_f64_exact): with M, N, K known at compile time the transposed LDS image of B needs no
+// per-element division (the generic kernel spends 208 VALU + 140 SALU instructions per 32^3 product next to 16 MFMAs,
+// MFMA pipe 42 % busy): the LDS address of every staged element is a per-wave constant.
+template <int M, int N, int K>
+__device__ __forceinline__ void cblock_f32_exact(const Desc& d, const Entry* __restrict__ entries, const float* __restrict__ a_data,
+                                                 const float* __restrict__ b_data, float* __restrict__ c_out,
+                                                 const float* __restrict__ c_in, float alpha, float beta, int lane, float* lds_a,
+                                                 float* lds_bt) {
+  constexpr int LDN = F32_LDN;
+  constexpr int KS2 = (K + 1) / 2, KP = 2 * KS2;                       // k steps of 2; A is zero-padded to KP columns
+  constexpr int CA = (M * KP * 4 + 1023) / 1024, CB = (K * N * 4 + 1023) / 1024;
+  constexpr int DUMMY = F32_BT_FLOATS;                                 // LDS slot that swallows the staging lanes past the block end
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  const Entry* e = entries + d.prod_start;
+  const int cnt = d.prod_cnt;
+  u32x4 ra[CA], rb[CB];
+  const int voff = lane * 16;
+  int baddr[CB][4];  // where element t of chunk c of this lane goes in the transposed image: constants of the wave
+#pragma unroll
+  for (int c = 0; c < CB; ++c)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int el = (c * 64 + lane) * 4 + t;
+      const int j = el / K, kk = el - j * K;
+      baddr[c][t] = el < K * N ? j + LDN * kk : DUMMY;
+    }
+  const int i = lane & 31, kh = lane >> 5;
+  const float* pa = lds_a + (i < M ? i : M - 1) + M * kh;
+  const float* pb = lds_bt + (i < N ? i : N - 1) + LDN * kh;
+  const float* pbt = lds_bt + (i < N ? i : N - 1) + LDN * ((K & 1) && kh ? K - 1 : 2 * (KS2 - 1) + kh);  // last step of an odd K
+  auto issue = [&](uint32_t a_off, uint32_t b_off) {
+    const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)(a_data + a_off), 0, M * K * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)(b_data + b_off), 0, K * N * 4, 0x00020000);
+#pragma unroll
+    for (int c = 0; c < CA; ++c) ra[c] = __builtin_amdgcn_raw_buffer_load_b128(rsa, voff, c * 1024, 0);
+#pragma unroll
+    for (int c = 0; c < CB; ++c) rb[c] = __builtin_amdgcn_raw_buffer_load_b128(rsb, voff, c * 1024, 0);
+  };
+  int i0 = 0;
+  Entry e0 = e[0];
+  while (i0 < cnt && (int)e0.ks != K) {
+    ++i0;
+    e0 = e[i0 < cnt ? i0 : cnt - 1];
+  }
+  int i1 = i0 + 1;
+  Entry e1 = e[i1 < cnt ? i1 : cnt - 1];
+  if (i0 < cnt) issue(e0.a_off, e0.b_off);
+  while (i0 < cnt) {
+#pragma unroll
+    for (int c = 0; c < CA; ++c) *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(lds_a) + c * 1024 + voff) = ra[c];
+#pragma unroll
+    for (int c = 0; c < CB; ++c)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) lds_bt[baddr[c][t]] = __uint_as_float(rb[c][t]);
+    while (i1 < cnt && (int)e1.ks != K) {
+      ++i1;
+      e1 = e[i1 < cnt ? i1 : cnt - 1];
+    }
+    if (i1 < cnt) issue(e1.a_off, e1.b_off);
+    const Entry e2 = e[i1 + 1 < cnt ? i1 + 1 : cnt - 1];
+#pragma unroll
+    for (int s2 = 0; s2 < KS2; ++s2) {
+      const float av = pa[s2 * 2 * M];
+      const float bv = (s2 == KS2 - 1) ? pbt[0] : pb[s2 * 2 * LDN];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+    i0 = i1;
+    e0 = e1;
+    i1 = i1 + 1;
+    e1 = e2;
+  }
+  for (int p = 0; p < cnt; ++p) {
+    const Entry ep = e[p];
+    if ((int)ep.ks != K) block_product_f32<false>(acc, a_data + ep.a_off, b_data + ep.b_off, M, N, (int)ep.ks, lane);
+  }
+  float* C = c_out + d.c_off;
+  const bool has_in = d.cin_off >= 0;
+  const float* Ci = c_in + (has_in ? d.cin_off : 0);
+  const int col = lane & 31;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    if (row < M && col < N) {
+      float v = alpha * acc[r];
+      if (has_in) v += beta * Ci[row + (size_t)M * col];
+      C[row + (size_t)M * col] = v;
+    }
+  }
+}
+
+#define DBCSR_F32_KERNEL_HEAD                                                                          \
+  __shared__ __attribute__((aligned(16))) float smem[4 * F32_WAVE_FLOATS + 4];                          \
+  const int lane = threadIdx.x & 63;                                                                   \
+  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));                             \
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);                                                     \
+  const int64_t pos = (int64_t)wg * 4 + wid;                                                           \
+  const int64_t cb = order[pos];                                                                       \
+  if (cb < 0 || cb >= nblk) return;                                                                    \
+  const Desc d = descs[cb];                                                                            \
+  if (skip_empty && d.prod_cnt == 0) return;                                                           \
+  float* lds_a = smem + (size_t)wid * F32_WAVE_FLOATS;                                                 \
+  float* lds_bt = lds_a + F32_A_FLOATS;
+
+__global__ void __launch_bounds__(256) mm_numeric_f32_lds(const Desc* __restrict__ descs, int64_t nblk, const Entry* __restrict__ entries,
+                                                          const float* __restrict__ a_data, const float* __restrict__ b_data,
+                                                          float* __restrict__ c_out, const float* __restrict__ c_in, float alpha,
+                                                          float beta, int skip_empty, const int* __restrict__ order) {
+  DBCSR_F32_KERNEL_HEAD
+  cblock_f32_lds(d, entries, a_data, b_data, c_out, c_in, alpha, beta, lane, lds_a, lds_bt);
+}
+
+template <int M, int N, int K>
+__global__ void __launch_bounds__(256) mm_numeric_f32_hot(const Desc* __restrict__ descs, int64_t nblk, const Entry* __restrict__ entries,
+                                                          const float* __restrict__ a_data, const float* __restrict__ b_data,
+                                                          float* __restrict__ c_out, const float* __restrict__ c_in, float alpha,
+                                                          float beta, int skip_empty, const int* __restrict__ order) {
+  DBCSR_F32_KERNEL_HEAD
+  if (d.m == M && d.n == N)
+    cblock_f32_exact<M, N, K>(d, entries, a_data, b_data, c_out, c_in, alpha, beta, lane, lds_a, lds_bt);
+  else
+    cblock_f32_lds(d, entries, a_data, b_data, c_out, c_in, alpha, beta, lane, lds_a, lds_bt);
+}
 
 __global__ void __launch_bounds__(256) mm_numeric_f32(const Desc* __restrict__ descs, int64_t nblk, const Entry* __restrict__ entries,
                                                       const float* __restrict__ a_data, const float* __restrict__ b_data,
@@ -1641,6 +1757,22 @@ static bool launch_hot_f64(int m, int n, int k, dim3 grid, size_t lds_bytes, hip
   case S_:                                                                                                                      \
     hipLaunchKernelGGL((mm_numeric_f64_hot<S_, S_, S_>), grid, dim3(256), lds_bytes, st, descs, nblk, entries, a_data, b_data, c_out, \
                        c_in, alpha, beta, lds_a, lds_wave, dbg, order);                                                         \
+    return true;
+    DBCSR_AMD_HOT_SIZES(DBCSR_HOT_CASE)
+#undef DBCSR_HOT_CASE
+    default: return false;
+  }
+}
+
+static bool launch_hot_f32(int m, int n, int k, dim3 grid, hipStream_t st, const Desc* descs, int64_t nblk, const Entry* entries,
+                           const float* a_data, const float* b_data, float* c_out, const float* c_in, float alpha, float beta,
+                           int skip_empty, const int* order) {
+  if (m != n || m != k) return false;
+  switch (m) {
+#define DBCSR_HOT_CASE(S_)                                                                                                     \
+  case S_:                                                                                                                     \
+    hipLaunchKernelGGL((mm_numeric_f32_hot<S_, S_, S_>), grid, dim3(256), 0, st, descs, nblk, entries, a_data, b_data, c_out, c_in, \
+                       alpha, beta, skip_empty, order);                                                                        \
     return true;
     DBCSR_AMD_HOT_SIZES(DBCSR_HOT_CASE)
 #undef DBCSR_HOT_CASE
@@ -2017,6 +2149,12 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
     const bool small32 = E->max_m <= 32 && E->max_k <= 32 && E->max_n <= 32 && E->min_m >= 1 && E->min_k >= 1 && E->min_n >= 1;
     if (small32 && E->use_lds) {
       const unsigned nwg_o = (unsigned)(8 * E->order_len / 4);
+      if (E->use_hot && E->hot_m > 0 &&
+          launch_hot_f32(E->hot_m, E->hot_n, E->hot_k, dim3(nwg_o), st, E->descs.p, nblk, E->entries.p, static_cast<const float*>(a->data),
+                         static_cast<const float*>(b->data), static_cast<float*>(c_out->data), static_cast<const float*>(c_in->data),
+                         (float)alpha, (float)beta, skip_empty, E->order.p)) {
+        // exact-size kernel launched
+      } else
       hipLaunchKernelGGL(mm_numeric_f32_lds, dim3(nwg_o), dim3(256), 0, st, E->descs.p, nblk, E->entries.p,
                          static_cast<const float*>(a->data), static_cast<const float*>(b->data), static_cast<float*>(c_out->data),
                          static_cast<const float*>(c_in->data), (float)alpha, (float)beta, skip_empty, E->order.p);

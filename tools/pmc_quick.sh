@@ -4,7 +4,7 @@
 PMC=$1; shift
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 R=$PWD; OUT=$R/gpurun_out/pmcq_$$; mkdir -p "$OUT"; export TMPDIR=/tmp
-( cd /tmp && env "$@" timeout 150 rocprofv3 --pmc $PMC -d "$OUT" -o pmc --output-format csv -- python "$R/bench.py" --steps 3 --warmup 1 --cpu-seconds 0 ) > "$OUT/log" 2>&1
+( cd /tmp && env "$@" timeout 150 rocprofv3 --pmc $PMC -d "$OUT" -o pmc --output-format csv -- python "$R/bench.py" --steps 3 --warmup 1 --cpu-seconds 0 $BENCH_ARGS ) > "$OUT/log" 2>&1
 python3 - "$OUT" "$*" <<'PY'
 import csv, glob, sys, collections
 agg = collections.defaultdict(float); cnt = collections.Counter()
