@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 
 #include "../../include/dbcsr_acc_libsmm.h"
 #include "common.h"
@@ -19,18 +20,18 @@
 
 namespace dbcsr_amd {
 
-constexpr int kStackGroup = 16;  // stack entries per wavefront
+constexpr int kStackGroup = 16;  // default number of stack entries per wavefront (see stack_group())
 
 template <int MA, int NC, bool BT>
 __global__ void __launch_bounds__(256) smm_stack_f64(const int* __restrict__ stack, int nstack, const double* __restrict__ a_data,
                                                      const double* __restrict__ b_data, double* __restrict__ c_data, int m,
-                                                     int n, int k) {
+                                                     int n, int k, int group) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
   const int row0 = blockIdx.y * (8 * MA), col0 = blockIdx.z * (8 * NC);
-  const int first = wave * kStackGroup;
+  const int first = wave * group;
   if (first >= nstack) return;
-  const int last = min(first + kStackGroup, nstack);
+  const int last = min(first + group, nstack);
   const LaneMap L(lane);
   double acc[MA][NC];
 #pragma unroll
@@ -70,15 +71,15 @@ typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
 template <int MA, int NC, bool BT>
 __global__ void __launch_bounds__(256) smm_stack_f64_lds(const int* __restrict__ stack, int nstack, const double* __restrict__ a_data,
                                                          const double* __restrict__ b_data, double* __restrict__ c_data, int m,
-                                                         int n, int k, int lds_a_bytes, int lds_wave_bytes) {
+                                                         int n, int k, int group, int lds_a_bytes, int lds_wave_bytes) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int CA = 2 * MA, CB = 2 * NC;
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
-  const int first = wave * kStackGroup;
+  const int first = wave * group;
   if (first >= nstack) return;
-  const int last = min(first + kStackGroup, nstack);
+  const int last = min(first + group, nstack);
   char* lds_a = smem + (size_t)wid * lds_wave_bytes;
   char* lds_b = lds_a + lds_a_bytes;
   const LaneMap L(lane);
@@ -136,13 +137,13 @@ __global__ void __launch_bounds__(256) smm_stack_f64_lds(const int* __restrict__
 template <bool BT>
 __global__ void __launch_bounds__(256) smm_stack_f32(const int* __restrict__ stack, int nstack, const float* __restrict__ a_data,
                                                      const float* __restrict__ b_data, float* __restrict__ c_data, int m, int n,
-                                                     int k) {
+                                                     int k, int group) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
   const int row0 = blockIdx.y * 32, col0 = blockIdx.z * 32;
-  const int first = wave * kStackGroup;
+  const int first = wave * group;
   if (first >= nstack) return;
-  const int last = min(first + kStackGroup, nstack);
+  const int last = min(first + group, nstack);
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
@@ -175,15 +176,15 @@ __global__ void __launch_bounds__(256) smm_stack_f32(const int* __restrict__ sta
 // reference's transpose pass is a no-op for fp32 (libsmm_acc.cpp:484).
 __global__ void __launch_bounds__(256) smm_stack_f32_lds(const int* __restrict__ stack, int nstack, const float* __restrict__ a_data,
                                                          const float* __restrict__ b_data, float* __restrict__ c_data, int m, int n,
-                                                         int k) {
+                                                         int k, int group) {
   constexpr int CH = 4, LDN = 33, A_FLOATS = 1024 + 64, BT_FLOATS = ((LDN * 32 + 31) + 3) & ~3;
   __shared__ __attribute__((aligned(16))) float smem[4 * (A_FLOATS + BT_FLOATS)];
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
-  const int first = wave * kStackGroup;
+  const int first = wave * group;
   if (first >= nstack) return;
-  const int last = min(first + kStackGroup, nstack);
+  const int last = min(first + group, nstack);
   float* lds_a = smem + (size_t)wid * (A_FLOATS + BT_FLOATS);
   float* lds_bt = lds_a + A_FLOATS;
   const int voff = lane * 16;
@@ -282,33 +283,43 @@ __global__ void __launch_bounds__(256) block_norms_f64(const double* __restrict_
   if (lane == 0) norms[b] = (float)s;
 }
 
+// Stack entries per wavefront.  A wave keeps the C block of a run of equal c offsets in its accumulators, so long groups
+// save atomics and wave start-ups.  Measured with tools/stack_group_sweep.sh (16005-entry stacks, groups 2/4/8/16):
+// 23^3 6.5/9.2/12.4/12.7 TFLOP/s, 32^3 14.8/18.6/21.7/21.7, 13^3 3.3/4.7/5.7/4.5, 5^3 (30000 entries) 0.92/0.95/0.92/0.76
+// -> 16 entries for blocks of at least 8000 multiply-adds, 8 below.  DBCSR_AMD_STACK_GROUP overrides (experiments).
+static int stack_group(int m, int n, int k) {
+  static const int forced = getenv("DBCSR_AMD_STACK_GROUP") ? atoi(getenv("DBCSR_AMD_STACK_GROUP")) : 0;
+  if (forced > 0) return forced;
+  return (int64_t)m * n * k >= 8000 ? kStackGroup : kStackGroup / 2;
+}
+
 template <int MA, int NC>
 static int launch_f64(bool bt, dim3 grid, hipStream_t st, const int* stack, int nstack, const double* a, const double* b, double* c,
-                      int m, int n, int k) {
+                      int m, int n, int k, int group) {
   if (m <= 32 && n <= 32 && k <= 32 && grid.y == 1 && grid.z == 1) {  // LDS-staged kernel (whole blocks fit the staging chunks)
     const int lds_a = ((m * ((k + 3) & ~3) * 8 + 1023) / 1024) * 1024, lds_b = ((k * n * 8 + 1023) / 1024) * 1024;
     const size_t lds = (size_t)4 * (lds_a + lds_b);
     if (bt)
-      hipLaunchKernelGGL((smm_stack_f64_lds<MA, NC, true>), grid, dim3(256), lds, st, stack, nstack, a, b, c, m, n, k, lds_a, lds_a + lds_b);
+      hipLaunchKernelGGL((smm_stack_f64_lds<MA, NC, true>), grid, dim3(256), lds, st, stack, nstack, a, b, c, m, n, k, group, lds_a, lds_a + lds_b);
     else
-      hipLaunchKernelGGL((smm_stack_f64_lds<MA, NC, false>), grid, dim3(256), lds, st, stack, nstack, a, b, c, m, n, k, lds_a, lds_a + lds_b);
+      hipLaunchKernelGGL((smm_stack_f64_lds<MA, NC, false>), grid, dim3(256), lds, st, stack, nstack, a, b, c, m, n, k, group, lds_a, lds_a + lds_b);
     return dbcsr_amd::check(hipGetLastError(), "smm_stack_f64_lds launch", __FILE__, __LINE__);
   }
   if (bt)
-    hipLaunchKernelGGL((smm_stack_f64<MA, NC, true>), grid, dim3(256), 0, st, stack, nstack, a, b, c, m, n, k);
+    hipLaunchKernelGGL((smm_stack_f64<MA, NC, true>), grid, dim3(256), 0, st, stack, nstack, a, b, c, m, n, k, group);
   else
-    hipLaunchKernelGGL((smm_stack_f64<MA, NC, false>), grid, dim3(256), 0, st, stack, nstack, a, b, c, m, n, k);
+    hipLaunchKernelGGL((smm_stack_f64<MA, NC, false>), grid, dim3(256), 0, st, stack, nstack, a, b, c, m, n, k, group);
   return dbcsr_amd::check(hipGetLastError(), "smm_stack_f64 launch", __FILE__, __LINE__);
 }
 
 template <int MA>
 static int launch_f64_nc(int NC, bool bt, dim3 grid, hipStream_t st, const int* stack, int nstack, const double* a,
-                         const double* b, double* c, int m, int n, int k) {
+                         const double* b, double* c, int m, int n, int k, int group) {
   switch (NC) {
-    case 1: return launch_f64<MA, 1>(bt, grid, st, stack, nstack, a, b, c, m, n, k);
-    case 2: return launch_f64<MA, 2>(bt, grid, st, stack, nstack, a, b, c, m, n, k);
-    case 3: return launch_f64<MA, 3>(bt, grid, st, stack, nstack, a, b, c, m, n, k);
-    default: return launch_f64<MA, 4>(bt, grid, st, stack, nstack, a, b, c, m, n, k);
+    case 1: return launch_f64<MA, 1>(bt, grid, st, stack, nstack, a, b, c, m, n, k, group);
+    case 2: return launch_f64<MA, 2>(bt, grid, st, stack, nstack, a, b, c, m, n, k, group);
+    case 3: return launch_f64<MA, 3>(bt, grid, st, stack, nstack, a, b, c, m, n, k, group);
+    default: return launch_f64<MA, 4>(bt, grid, st, stack, nstack, a, b, c, m, n, k, group);
   }
 }
 
@@ -319,13 +330,14 @@ int process_stack_f64(const int* dev_stack, int nstack, const double* a, const d
   // C tile per wave: up to 32 x 32; larger blocks are tiled over grid.y/z
   const int MA = m >= 32 ? 4 : (m + 7) / 8, NC = n >= 32 ? 4 : (n + 7) / 8;
   const int tiles_r = (m + 8 * MA - 1) / (8 * MA), tiles_c = (n + 8 * NC - 1) / (8 * NC);
-  const int nwaves = (nstack + kStackGroup - 1) / kStackGroup;
+  const int group = stack_group(m, n, k);
+  const int nwaves = (nstack + group - 1) / group;
   dim3 grid((nwaves + 3) / 4, tiles_r, tiles_c);
   switch (MA) {
-    case 1: return launch_f64_nc<1>(NC, bt, grid, st, dev_stack, nstack, a, b, c, m, n, k);
-    case 2: return launch_f64_nc<2>(NC, bt, grid, st, dev_stack, nstack, a, b, c, m, n, k);
-    case 3: return launch_f64_nc<3>(NC, bt, grid, st, dev_stack, nstack, a, b, c, m, n, k);
-    default: return launch_f64_nc<4>(NC, bt, grid, st, dev_stack, nstack, a, b, c, m, n, k);
+    case 1: return launch_f64_nc<1>(NC, bt, grid, st, dev_stack, nstack, a, b, c, m, n, k, group);
+    case 2: return launch_f64_nc<2>(NC, bt, grid, st, dev_stack, nstack, a, b, c, m, n, k, group);
+    case 3: return launch_f64_nc<3>(NC, bt, grid, st, dev_stack, nstack, a, b, c, m, n, k, group);
+    default: return launch_f64_nc<4>(NC, bt, grid, st, dev_stack, nstack, a, b, c, m, n, k, group);
   }
 }
 
@@ -333,16 +345,17 @@ int process_stack_f32(const int* dev_stack, int nstack, const float* a, const fl
                       hipStream_t st) {
   if (nstack <= 0) return 0;
   if (m <= 0 || n <= 0 || k <= 0) return 0;
-  const int nwaves = (nstack + kStackGroup - 1) / kStackGroup;
+  const int group = stack_group(m, n, k);
+  const int nwaves = (nstack + group - 1) / group;
   dim3 grid((nwaves + 3) / 4, (m + 31) / 32, (n + 31) / 32);
   if (!bt && m <= 32 && n <= 32 && k <= 32) {
-    hipLaunchKernelGGL(smm_stack_f32_lds, grid, dim3(256), 0, st, dev_stack, nstack, a, b, c, m, n, k);
+    hipLaunchKernelGGL(smm_stack_f32_lds, grid, dim3(256), 0, st, dev_stack, nstack, a, b, c, m, n, k, group);
     return dbcsr_amd::check(hipGetLastError(), "smm_stack_f32_lds launch", __FILE__, __LINE__);
   }
   if (bt)
-    hipLaunchKernelGGL((smm_stack_f32<true>), grid, dim3(256), 0, st, dev_stack, nstack, a, b, c, m, n, k);
+    hipLaunchKernelGGL((smm_stack_f32<true>), grid, dim3(256), 0, st, dev_stack, nstack, a, b, c, m, n, k, group);
   else
-    hipLaunchKernelGGL((smm_stack_f32<false>), grid, dim3(256), 0, st, dev_stack, nstack, a, b, c, m, n, k);
+    hipLaunchKernelGGL((smm_stack_f32<false>), grid, dim3(256), 0, st, dev_stack, nstack, a, b, c, m, n, k, group);
   return dbcsr_amd::check(hipGetLastError(), "smm_stack_f32 launch", __FILE__, __LINE__);
 }
 
