@@ -1739,6 +1739,91 @@ __global__ void __launch_bounds__(256) filter_compact(const int* __restrict__ ro
   }
 }
 
+// ---- submatrix limits (dbcsr_crop_matrix, src/ops/dbcsr_operations.F:1652-1833; dbcsr_scale with limits) ---------
+struct Window {
+  int r0, r1, c0, c1;  // inclusive 0-based element bounds
+};
+
+// one wavefront per block row: a block is kept when it intersects the window
+__global__ void __launch_bounds__(256) crop_flags(const int* __restrict__ row_p, const int* __restrict__ col_i, const int* __restrict__ rs,
+                                                  const int* __restrict__ cs, const int64_t* __restrict__ roff,
+                                                  const int64_t* __restrict__ coff, int nbr, Window w, int* __restrict__ keep,
+                                                  int* __restrict__ blk_nze, int* __restrict__ row_keep) {
+  const int lane = threadIdx.x & 63;
+  const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (row >= nbr) return;
+  const int m = rs[row];
+  const bool row_in = roff[row] + m - 1 >= w.r0 && roff[row] <= w.r1;
+  int cnt = 0;
+  for (int b = row_p[row] + lane; b < row_p[row + 1]; b += 64) {
+    const int c = col_i[b], n = cs[c];
+    const int k = (row_in && coff[c] + n - 1 >= w.c0 && coff[c] <= w.c1) ? 1 : 0;
+    keep[b] = k;
+    blk_nze[b] = k ? m * n : 0;
+    cnt += k;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+  if (lane == 0) row_keep[row] = cnt;
+}
+
+// compaction of the kept blocks; elements outside the window become zero
+template <typename T>
+__global__ void __launch_bounds__(256) crop_compact(const int* __restrict__ row_p, const int* __restrict__ col_i,
+                                                    const int64_t* __restrict__ blk_p, const T* __restrict__ data,
+                                                    const int* __restrict__ rs, const int* __restrict__ cs,
+                                                    const int64_t* __restrict__ roff, const int64_t* __restrict__ coff, int nbr, Window w,
+                                                    const int* __restrict__ keep, const int64_t* __restrict__ newidx,
+                                                    const int64_t* __restrict__ newoff, int* __restrict__ d_col_i,
+                                                    int64_t* __restrict__ d_blk_p, T* __restrict__ d_data) {
+  const int lane = threadIdx.x & 63;
+  const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (row >= nbr) return;
+  const int m = rs[row];
+  const int64_t r_base = roff[row];
+  for (int b = row_p[row]; b < row_p[row + 1]; ++b) {
+    if (!keep[b]) continue;
+    const int64_t t = newidx[b], off = newoff[b];
+    const int c = col_i[b];
+    if (lane == 0) {
+      d_col_i[t] = c;
+      d_blk_p[t] = off;
+    }
+    const int ne = m * cs[c];
+    const int64_t c_base = coff[c];
+    const T* src = data + blk_p[b];
+    T* dst = d_data + off;
+    for (int e = lane; e < ne; e += 64) {
+      const int64_t gr = r_base + e % m, gc = c_base + e / m;
+      dst[e] = (gr >= w.r0 && gr <= w.r1 && gc >= w.c0 && gc <= w.c1) ? src[e] : T(0);
+    }
+  }
+}
+
+// in place: x *= beta for the elements inside the window
+template <typename T>
+__global__ void __launch_bounds__(256) scale_window(const int* __restrict__ row_p, const int* __restrict__ col_i,
+                                                    const int64_t* __restrict__ blk_p, T* __restrict__ data, const int* __restrict__ rs,
+                                                    const int* __restrict__ cs, const int64_t* __restrict__ roff,
+                                                    const int64_t* __restrict__ coff, int nbr, Window w, T beta) {
+  const int lane = threadIdx.x & 63;
+  const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (row >= nbr) return;
+  const int m = rs[row];
+  const int64_t r_base = roff[row];
+  if (r_base + m - 1 < w.r0 || r_base > w.r1) return;
+  for (int b = row_p[row]; b < row_p[row + 1]; ++b) {
+    const int c = col_i[b], n = cs[c];
+    const int64_t c_base = coff[c];
+    if (c_base + n - 1 < w.c0 || c_base > w.c1) continue;
+    T* blk = data + blk_p[b];
+    for (int e = lane; e < m * n; e += 64) {
+      const int64_t gr = r_base + e % m, gc = c_base + e / m;
+      if (gr >= w.r0 && gr <= w.r1 && gc >= w.c0 && gc <= w.c1) blk[e] *= beta;
+    }
+  }
+}
+
 // ----------------------------------------------------------------------------
 // host side
 // ----------------------------------------------------------------------------
@@ -1794,6 +1879,8 @@ struct Engine {
   DevBuf<int> order, order_cnt;
   DevBuf<int64_t> order_base;
   int64_t order_len = 0;
+  Window crop_win = {0, 0, 0, 0};       // window of the last dbcsr_amd_bcsr_crop_count
+  bool crop_pending = false;
   int hot_m = 0, hot_n = 0, hot_k = 0;  // dominant block sizes of the last symbolic phase (0: none)
   int use_hot = 1;                      // DBCSR_AMD_MM_HOT=0: never use the exact-size kernels
   int lds_pad = 0;                      // DBCSR_AMD_MM_LDS_PAD: extra LDS bytes per workgroup (occupancy experiments)
@@ -2198,6 +2285,97 @@ int dbcsr_amd_mm_init_c(void* handle, libsmm_acc_data_t datatype, double beta, c
 }
 
 
+static int element_offsets(Engine* E, const int* sizes, int n, DevBuf<int64_t>& off, hipStream_t st) {
+  if (off.ensure((size_t)n + 1)) return -1;
+  return exclusive_scan<int64_t>(E, sizes, n, off.p, nullptr, false, st);
+}
+
+static Window make_window(const dbcsr_amd_bcsr* m, int64_t row_lo, int64_t row_hi, int64_t col_lo, int64_t col_hi) {
+  (void)m;
+  const int64_t big = 0x7fffffff;
+  Window w;
+  w.r0 = (int)(row_lo < 0 ? 0 : row_lo);
+  w.r1 = (int)(row_hi < 0 || row_hi > big ? big : row_hi);
+  w.c0 = (int)(col_lo < 0 ? 0 : col_lo);
+  w.c1 = (int)(col_hi < 0 || col_hi > big ? big : col_hi);
+  return w;
+}
+
+int dbcsr_amd_bcsr_crop_count(void* handle, libsmm_acc_data_t datatype, const dbcsr_amd_bcsr* m, int64_t row_lo, int64_t row_hi,
+                              int64_t col_lo, int64_t col_hi, int32_t* new_row_p, int64_t* new_nblks, int64_t* new_nze, void* stream) {
+  Engine* E = static_cast<Engine*>(handle);
+  if (!E || !m || !new_row_p || !new_nblks || !new_nze) return -1;
+  if (datatype != dbcsr_type_real_8 && datatype != dbcsr_type_real_4) return -10;
+  hipStream_t st = stream_of(stream);
+  const int nbr = m->nblkrows;
+  const int64_t nb = m->nblks;
+  E->valid = false;  // shares workspace with the symbolic phase
+  E->flt_nblks = nb;
+  E->crop_win = make_window(m, row_lo, row_hi, col_lo, col_hi);
+  E->crop_pending = true;
+  if (E->keep.ensure((size_t)nb + 1) || E->blk_nze.ensure((size_t)nb + 1) || E->row_nnz.ensure((size_t)nbr + 1) ||
+      E->prod_start.ensure((size_t)nb + 1) || E->c_blk_p_ws.ensure((size_t)nb + 1) || E->dev_scalars.ensure(16))
+    return -1;
+  int64_t* dsc = reinterpret_cast<int64_t*>(E->dev_scalars.p);
+  ACC_CHECK(hipMemsetAsync(dsc, 0, 16 * sizeof(int64_t), st));
+  if (element_offsets(E, m->row_blk_size, nbr, E->off_a, st)) return -1;
+  if (element_offsets(E, m->col_blk_size, m->nblkcols, E->off_b, st)) return -1;
+  if (nbr > 0 && nb > 0)
+    hipLaunchKernelGGL(crop_flags, grid_for((int64_t)nbr * 64), dim3(256), 0, st, m->row_p, m->col_i, m->row_blk_size, m->col_blk_size,
+                       E->off_a.p, E->off_b.p, nbr, E->crop_win, E->keep.p, E->blk_nze.p, E->row_nnz.p);
+  else if (nbr > 0)
+    ACC_CHECK(hipMemsetAsync(E->row_nnz.p, 0, sizeof(int) * (size_t)nbr, st));
+  if (exclusive_scan<int32_t>(E, E->row_nnz.p, nbr, new_row_p, dsc + 0, true, st)) return -1;
+  if (exclusive_scan<int64_t>(E, E->keep.p, nb, E->prod_start.p, nullptr, false, st)) return -1;
+  if (exclusive_scan<int64_t>(E, E->blk_nze.p, nb, E->c_blk_p_ws.p, dsc + 1, false, st)) return -1;
+  ACC_CHECK(hipMemcpyAsync(E->host_scalars, dsc, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+  ACC_CHECK(hipStreamSynchronize(st));
+  *new_nblks = E->host_scalars[0];
+  *new_nze = E->host_scalars[1];
+  return check(hipGetLastError(), "dbcsr_amd_bcsr_crop_count", __FILE__, __LINE__);
+}
+
+int dbcsr_amd_bcsr_crop_apply(void* handle, libsmm_acc_data_t datatype, const dbcsr_amd_bcsr* src, dbcsr_amd_bcsr* dst, void* stream) {
+  Engine* E = static_cast<Engine*>(handle);
+  if (!E || !src || !dst || !E->crop_pending || E->flt_nblks != src->nblks) return -1;
+  E->crop_pending = false;
+  hipStream_t st = stream_of(stream);
+  const int nbr = src->nblkrows;
+  if (nbr == 0 || src->nblks == 0) return 0;
+  if (datatype == dbcsr_type_real_8)
+    hipLaunchKernelGGL((crop_compact<double>), grid_for((int64_t)nbr * 64), dim3(256), 0, st, src->row_p, src->col_i, src->blk_p,
+                       static_cast<const double*>(src->data), src->row_blk_size, src->col_blk_size, E->off_a.p, E->off_b.p, nbr,
+                       E->crop_win, E->keep.p, E->prod_start.p, E->c_blk_p_ws.p, dst->col_i, dst->blk_p, static_cast<double*>(dst->data));
+  else if (datatype == dbcsr_type_real_4)
+    hipLaunchKernelGGL((crop_compact<float>), grid_for((int64_t)nbr * 64), dim3(256), 0, st, src->row_p, src->col_i, src->blk_p,
+                       static_cast<const float*>(src->data), src->row_blk_size, src->col_blk_size, E->off_a.p, E->off_b.p, nbr,
+                       E->crop_win, E->keep.p, E->prod_start.p, E->c_blk_p_ws.p, dst->col_i, dst->blk_p, static_cast<float*>(dst->data));
+  else
+    return -10;
+  return check(hipGetLastError(), "dbcsr_amd_bcsr_crop_apply", __FILE__, __LINE__);
+}
+
+int dbcsr_amd_bcsr_scale_window(void* handle, libsmm_acc_data_t datatype, dbcsr_amd_bcsr* m, double beta, int64_t row_lo, int64_t row_hi,
+                                int64_t col_lo, int64_t col_hi, void* stream) {
+  Engine* E = static_cast<Engine*>(handle);
+  if (!E || !m) return -1;
+  hipStream_t st = stream_of(stream);
+  const int nbr = m->nblkrows;
+  if (nbr == 0 || m->nblks == 0) return 0;
+  const Window w = make_window(m, row_lo, row_hi, col_lo, col_hi);
+  if (element_offsets(E, m->row_blk_size, nbr, E->off_a, st)) return -1;
+  if (element_offsets(E, m->col_blk_size, m->nblkcols, E->off_b, st)) return -1;
+  if (datatype == dbcsr_type_real_8)
+    hipLaunchKernelGGL((scale_window<double>), grid_for((int64_t)nbr * 64), dim3(256), 0, st, m->row_p, m->col_i, m->blk_p,
+                       static_cast<double*>(m->data), m->row_blk_size, m->col_blk_size, E->off_a.p, E->off_b.p, nbr, w, beta);
+  else if (datatype == dbcsr_type_real_4)
+    hipLaunchKernelGGL((scale_window<float>), grid_for((int64_t)nbr * 64), dim3(256), 0, st, m->row_p, m->col_i, m->blk_p,
+                       static_cast<float*>(m->data), m->row_blk_size, m->col_blk_size, E->off_a.p, E->off_b.p, nbr, w, (float)beta);
+  else
+    return -10;
+  return check(hipGetLastError(), "dbcsr_amd_bcsr_scale_window", __FILE__, __LINE__);
+}
+
 int dbcsr_amd_bcsr_filter_count(void* handle, libsmm_acc_data_t datatype, const dbcsr_amd_bcsr* m, double eps, int32_t* new_row_p,
                                 int64_t* new_nblks, int64_t* new_nze, void* stream) {
   Engine* E = static_cast<Engine*>(handle);
@@ -2251,11 +2429,6 @@ int dbcsr_amd_bcsr_filter_apply(void* handle, libsmm_acc_data_t datatype, const 
   else
     return -10;
   return check(hipGetLastError(), "dbcsr_amd_bcsr_filter_apply", __FILE__, __LINE__);
-}
-
-static int element_offsets(Engine* E, const int* sizes, int n, DevBuf<int64_t>& off, hipStream_t st) {
-  if (off.ensure((size_t)n + 1)) return -1;
-  return exclusive_scan<int64_t>(E, sizes, n, off.p, nullptr, false, st);
 }
 
 int dbcsr_amd_bcsr_checksum(void* handle, libsmm_acc_data_t datatype, const dbcsr_amd_bcsr* m, double* out2, void* stream) {

@@ -158,6 +158,40 @@ class MultiplyEngine:
             raise RuntimeError("dbcsr_amd_bcsr_filter_apply failed (%d)" % rc)
         return out
 
+    def cropped(self, M, row_bounds=None, col_bounds=None, stream=None):
+        """dbcsr_crop_matrix (src/ops/dbcsr_operations.F:1652-1833): copy of M restricted to the window given as 0-based
+        inclusive element bounds (None = no bound); boundary blocks keep their size, their outside part is zero."""
+        st = StreamHandle(stream)
+        dev = M.row_p.device
+        src = M.desc()
+        r0, r1 = (-1, -1) if row_bounds is None else (int(row_bounds[0]), int(row_bounds[1]))
+        c0, c1 = (-1, -1) if col_bounds is None else (int(col_bounds[0]), int(col_bounds[1]))
+        row_p = torch.empty(M.nblkrows + 1, dtype=torch.int32, device=dev)
+        nb, nz = C.c_int64(), C.c_int64()
+        rc = self.L.dbcsr_amd_bcsr_crop_count(self.h, M.dtype_code, C.byref(src), r0, r1, c0, c1, row_p.data_ptr(), C.byref(nb),
+                                              C.byref(nz), st.ptr)
+        if rc != 0:
+            raise RuntimeError("dbcsr_amd_bcsr_crop_count failed (%d)" % rc)
+        out = DbcsrMatrix(M.row_blk_size, M.col_blk_size, row_p, torch.empty(nb.value, dtype=torch.int32, device=dev),
+                          torch.empty(nb.value, dtype=torch.int64, device=dev), torch.empty(nz.value, dtype=M.dtype, device=dev), M.name)
+        dst = out.desc()
+        rc = self.L.dbcsr_amd_bcsr_crop_apply(self.h, M.dtype_code, C.byref(src), C.byref(dst), st.ptr)
+        if rc != 0:
+            raise RuntimeError("dbcsr_amd_bcsr_crop_apply failed (%d)" % rc)
+        return out
+
+    def scaled_window(self, M, beta, row_bounds=None, col_bounds=None, stream=None):
+        """dbcsr_scale(matrix, beta, limits) on a copy of M: only the elements inside the window are scaled."""
+        st = StreamHandle(stream)
+        out = DbcsrMatrix(M.row_blk_size, M.col_blk_size, M.row_p, M.col_i, M.blk_p, M.data.clone(), M.name)
+        r0, r1 = (-1, -1) if row_bounds is None else (int(row_bounds[0]), int(row_bounds[1]))
+        c0, c1 = (-1, -1) if col_bounds is None else (int(col_bounds[0]), int(col_bounds[1]))
+        d = out.desc()
+        rc = self.L.dbcsr_amd_bcsr_scale_window(self.h, M.dtype_code, C.byref(d), float(beta), r0, r1, c0, c1, st.ptr)
+        if rc != 0:
+            raise RuntimeError("dbcsr_amd_bcsr_scale_window failed (%d)" % rc)
+        return out
+
     def multiply_local(self, alpha, A, B, beta, Cm, retain_sparsity=False, stream=None, filter_eps=0.0):
         """C_out = beta*Cm + alpha*A*B for already-oriented operands; returns (C_out, counts)."""
         st = StreamHandle(stream)
@@ -197,8 +231,6 @@ def dbcsr_multiply(transa, transb, alpha, matrix_a, matrix_b, beta, matrix_c, fi
     """Reference signature (src/dbcsr_api.F:1411-1433).  ``matrix_c`` is updated
     in place (its index/data tensors are replaced); ``flop`` may be a one-element
     list that receives the flop count, as the reference's optional INTENT(OUT)."""
-    if any(v is not None for v in (first_row, last_row, first_column, last_column, first_k, last_k)):
-        raise NotImplementedError("dbcsr_multiply: submatrix limits are not implemented on the device path yet")
     for t in (transa, transb):
         if t not in ("N", "T", "C"):
             raise ValueError("dbcsr_multiply: invalid transpose flag %r" % (t,))
@@ -209,7 +241,25 @@ def dbcsr_multiply(transa, transb, alpha, matrix_a, matrix_b, beta, matrix_c, fi
     B = E.transposed(matrix_b) if transb != "N" else matrix_b
     if A.nblkcols != B.nblkrows or A.nblkrows != matrix_c.nblkrows or B.nblkcols != matrix_c.nblkcols:
         raise ValueError("dbcsr_multiply: incompatible block dimensions")
-    out, counts = E.multiply_local(alpha, A, B, beta, matrix_c, retain_sparsity=retain_sparsity, filter_eps=filter_eps or 0.0)
+    limits = (first_row, last_row, first_column, last_column, first_k, last_k)
+    if any(v is not None and v != 0 for v in limits):
+        # Submatrix selection (src/mm/dbcsr_mm.F:631-709, 1-based inclusive full-matrix indices, None/0 = not given): the left
+        # matrix is cropped to (rows, k), the right one to (k, columns) (make_m2s, dbcsr_mm_cannon.F:194-214), beta acts on the
+        # window of C only (dbcsr_scale with limits) and everything outside the window stays as it is.
+        nr, nc, nk = int(A.row_blk_size.sum()), int(B.col_blk_size.sum()), int(A.col_blk_size.sum())
+        fr, lr, fc, lc, fk, lk = [int(v or 0) for v in limits]
+        if fr < 0 or fr > nr or lr > nr or (lr and fr > lr):
+            raise ValueError("dbcsr_multiply: invalid row limits")
+        if fc < 0 or fc > nc or lc > nc or (lc and fc > lc):
+            raise ValueError("dbcsr_multiply: invalid column limits")
+        if fk < 0 or fk > nk or lk > nk or (lk and fk > lk):
+            raise ValueError("dbcsr_multiply: invalid k limits")
+        rb, cb, kb = ((fr or 1) - 1, (lr or nr) - 1), ((fc or 1) - 1, (lc or nc) - 1), ((fk or 1) - 1, (lk or nk) - 1)
+        A, B = E.cropped(A, rb, kb), E.cropped(B, kb, cb)
+        matrix_in = E.scaled_window(matrix_c, beta, rb, cb) if beta != 1.0 else matrix_c
+        out, counts = E.multiply_local(alpha, A, B, 1.0, matrix_in, retain_sparsity=retain_sparsity, filter_eps=filter_eps or 0.0)
+    else:
+        out, counts = E.multiply_local(alpha, A, B, beta, matrix_c, retain_sparsity=retain_sparsity, filter_eps=filter_eps or 0.0)
     matrix_c.row_p, matrix_c.col_i, matrix_c.blk_p, matrix_c.data = out.row_p, out.col_i, out.blk_p, out.data
     if flop is not None:
         flop[:] = [counts.flop]

@@ -77,6 +77,18 @@ int dbcsr_amd_bcsr_filter_count(void* handle, libsmm_acc_data_t datatype, const 
   int64_t* new_nblks, int64_t* new_nze, void* stream);
 int dbcsr_amd_bcsr_filter_apply(void* handle, libsmm_acc_data_t datatype, const dbcsr_amd_bcsr* src, dbcsr_amd_bcsr* dst, void* stream);
 
+/* Submatrix limits of dbcsr_multiply (first_row ... last_k, src/mm/dbcsr_mm.F:631-709): dbcsr_crop_matrix
+ * (src/ops/dbcsr_operations.F:1652-1833) keeps the blocks that intersect the window [row_lo, row_hi] x [col_lo, col_hi]
+ * (0-based inclusive ELEMENT indices of the full matrix; a negative bound = no bound) and clears the parts of the
+ * boundary blocks outside it.  Same two-step protocol as the filter: _count writes new_row_p and the new counts
+ * (synchronises), _apply compacts into caller-allocated dst arrays.  _scale_window is dbcsr_scale with limits: in place,
+ * only the elements inside the window are multiplied by beta. */
+int dbcsr_amd_bcsr_crop_count(void* handle, libsmm_acc_data_t datatype, const dbcsr_amd_bcsr* m, int64_t row_lo, int64_t row_hi,
+  int64_t col_lo, int64_t col_hi, int32_t* new_row_p, int64_t* new_nblks, int64_t* new_nze, void* stream);
+int dbcsr_amd_bcsr_crop_apply(void* handle, libsmm_acc_data_t datatype, const dbcsr_amd_bcsr* src, dbcsr_amd_bcsr* dst, void* stream);
+int dbcsr_amd_bcsr_scale_window(void* handle, libsmm_acc_data_t datatype, dbcsr_amd_bcsr* m, double beta, int64_t row_lo,
+  int64_t row_hi, int64_t col_lo, int64_t col_hi, void* stream);
+
 /* Numeric phase.  c_out->row_p is the array written by the symbolic call;
  * col_i [c_nblks], blk_p [c_nblks] and data [c_nze] are allocated by the caller
  * and filled here (blocks laid out in index order).  c_out->data may alias

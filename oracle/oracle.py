@@ -256,3 +256,96 @@ def perf_case(M, N, K, sp_a, sp_b, sp_c, bs_m, bs_n, bs_k, transa="N", transb="N
     A = make_random_matrix(sk, sm, sp_a, c0 + 2, dtype) if transa != "N" else make_random_matrix(sm, sk, sp_a, c0 + 2, dtype)
     B = make_random_matrix(sn, sk, sp_b, c0 + 3, dtype) if transb != "N" else make_random_matrix(sk, sn, sp_b, c0 + 3, dtype)
     return A, B, Cm
+
+
+# ---- submatrix limits (dbcsr_multiply's first_row ... last_k) --------------------------------------------------
+# Restated for small cases in numpy: dbcsr_crop_matrix (src/ops/dbcsr_operations.F:1652-1833: the blocks that
+# intersect the bounds are copied, the parts of the boundary blocks outside the bounds are cleared), dbcsr_scale
+# with limits (src/mm/dbcsr_mm.F:706-709) and the order of operations of dbcsr_multiply_generic
+# (src/mm/dbcsr_mm.F:631-709; make_m2s crops the left matrix to (rows, k) and the right one to (k, columns),
+# src/mm/dbcsr_mm_cannon.F:194-214).  Pinned by tests/test_oracle_limits.py against the dense check of the
+# reference's own unit test (tests/dbcsr_test_multiply.F:585-755) on the limit cases of tests/dbcsr_unittest1.F.
+
+def transposed(M):
+    """dbcsr_new_transposed: block (r, c) of M becomes block (c, r), transposed."""
+    rows = M.rows()
+    order = np.lexsort((rows, M.col_i))  # sort by (new row = old column, new column = old row)
+    nze = (M.row_sizes[rows[order]].astype(np.int64) * M.col_sizes[M.col_i[order]]) if M.nblks else np.zeros(0, np.int64)
+    blk_p = np.concatenate([[0], np.cumsum(nze)[:-1]]).astype(np.int64) if M.nblks else np.zeros(0, np.int64)
+    data = np.empty(int(nze.sum()), M.data.dtype)
+    for t, b in enumerate(order):
+        m, n = M.row_sizes[rows[b]], M.col_sizes[M.col_i[b]]
+        blk = M.data[M.blk_p[b]:M.blk_p[b] + m * n].reshape(n, m)  # [col][row] of the m x n block
+        data[blk_p[t]:blk_p[t] + m * n] = blk.T.reshape(-1)        # n x m block, column-major
+    row_p = np.zeros(M.nbc + 1, np.int64)
+    np.add.at(row_p, M.col_i.astype(np.int64) + 1, 1)
+    return Bcsr(M.col_sizes, M.row_sizes, np.cumsum(row_p).astype(np.int32), rows[order], blk_p, data)
+
+
+def _bounds(b, n):
+    return (0, n - 1) if b is None else (int(b[0]), int(b[1]))
+
+
+def crop(M, row_bounds=None, col_bounds=None):
+    """Bounds are 0-based inclusive ELEMENT indices (None = everything)."""
+    ro = np.concatenate([[0], np.cumsum(M.row_sizes)]).astype(np.int64)
+    co = np.concatenate([[0], np.cumsum(M.col_sizes)]).astype(np.int64)
+    r0, r1 = _bounds(row_bounds, ro[-1])
+    c0, c1 = _bounds(col_bounds, co[-1])
+    rows = M.rows()
+    keep, chunks, off = [], [], 0
+    for b in range(M.nblks):
+        r, c = rows[b], M.col_i[b]
+        m, n = int(M.row_sizes[r]), int(M.col_sizes[c])
+        if ro[r] + m - 1 < r0 or ro[r] > r1 or co[c] + n - 1 < c0 or co[c] > c1:
+            continue
+        blk = M.data[M.blk_p[b]:M.blk_p[b] + m * n].reshape(n, m).copy()  # [col][row]
+        gi = ro[r] + np.arange(m)
+        gj = co[c] + np.arange(n)
+        blk[:, (gi < r0) | (gi > r1)] = 0
+        blk[(gj < c0) | (gj > c1), :] = 0
+        keep.append(b)
+        chunks.append(blk.reshape(-1))
+    keep = np.asarray(keep, np.int64)
+    row_p = np.zeros(M.nbr + 1, np.int64)
+    if len(keep):
+        np.add.at(row_p, rows[keep].astype(np.int64) + 1, 1)
+    nze = np.asarray([len(x) for x in chunks], np.int64)
+    blk_p = np.concatenate([[0], np.cumsum(nze)[:-1]]).astype(np.int64) if len(keep) else np.zeros(0, np.int64)
+    data = np.concatenate(chunks) if chunks else np.zeros(0, M.data.dtype)
+    return Bcsr(M.row_sizes, M.col_sizes, np.cumsum(row_p).astype(np.int32), M.col_i[keep] if len(keep) else np.zeros(0, np.int32),
+                blk_p, data.astype(M.data.dtype))
+
+
+def scale_window(M, beta, row_bounds=None, col_bounds=None):
+    """dbcsr_scale(matrix, beta, limits): only the elements inside the bounds are scaled.  Returns a copy."""
+    ro = np.concatenate([[0], np.cumsum(M.row_sizes)]).astype(np.int64)
+    co = np.concatenate([[0], np.cumsum(M.col_sizes)]).astype(np.int64)
+    r0, r1 = _bounds(row_bounds, ro[-1])
+    c0, c1 = _bounds(col_bounds, co[-1])
+    out = Bcsr(M.row_sizes, M.col_sizes, M.row_p, M.col_i, M.blk_p, M.data.copy())
+    rows = M.rows()
+    for b in range(M.nblks):
+        r, c = rows[b], M.col_i[b]
+        m, n = int(M.row_sizes[r]), int(M.col_sizes[c])
+        blk = out.data[M.blk_p[b]:M.blk_p[b] + m * n].reshape(n, m)
+        gi = ro[r] + np.arange(m)
+        gj = co[c] + np.arange(n)
+        mask = np.outer((gj >= c0) & (gj <= c1), (gi >= r0) & (gi <= r1))
+        blk[mask] *= beta
+    return out
+
+
+def multiply_limits(transa, transb, alpha, A, B, beta, Cm, limits, retain_sparsity=False, filter_eps=0.0):
+    """dbcsr_multiply with the reference's limits convention: (first_row, last_row, first_column, last_column,
+    first_k, last_k), 1-based inclusive full-matrix indices, 0 = not given."""
+    left = transposed(A) if transa.upper() != "N" else A
+    right = transposed(B) if transb.upper() != "N" else B
+    nr, nc, nk = int(left.row_sizes.sum()), int(right.col_sizes.sum()), int(left.col_sizes.sum())
+    fr, lr, fc, lc, fk, lk = [int(x) for x in limits]
+    rb = ((fr or 1) - 1, (lr or nr) - 1)
+    cb = ((fc or 1) - 1, (lc or nc) - 1)
+    kb = ((fk or 1) - 1, (lk or nk) - 1)
+    Cs = scale_window(Cm, beta, rb, cb)
+    return multiply("N", "N", alpha, crop(left, rb, kb), crop(right, kb, cb), 1.0, Cs, retain_sparsity=retain_sparsity,
+                    filter_eps=filter_eps)
