@@ -30,9 +30,19 @@
 
 namespace dbcsr_amd {
 
-struct Entry {  // one block product feeding a C block
-  uint32_t a_off, b_off;  // element offsets into the A / B data areas
-  uint32_t ks;            // k extent of this product
+struct Entry {  // one block product feeding a C block: 12 bytes, 40-bit element offsets (any operand that fits 288 GB)
+  uint32_t a_lo, b_lo;  // low 32 bits of the element offsets into the A / B data areas
+  uint32_t w;           // bits 0-15: k extent of this product; bits 16-23 / 24-31: bits 32-39 of the A / B offset
+  __device__ __forceinline__ uint64_t a_off() const { return (uint64_t)a_lo | ((uint64_t)((w >> 16) & 0xffu) << 32); }
+  __device__ __forceinline__ uint64_t b_off() const { return (uint64_t)b_lo | ((uint64_t)(w >> 24) << 32); }
+  __device__ __forceinline__ int ks() const { return (int)(w & 0xffffu); }
+  __device__ __forceinline__ static Entry make(int64_t a, int64_t b, int k) {
+    Entry e;
+    e.a_lo = (uint32_t)a;
+    e.b_lo = (uint32_t)b;
+    e.w = ((uint32_t)k & 0xffffu) | ((uint32_t)(((uint64_t)a >> 32) & 0xffu) << 16) | ((uint32_t)(((uint64_t)b >> 32) & 0xffu) << 24);
+    return e;
+  }
 };
 
 struct Desc {  // one C block
@@ -288,11 +298,7 @@ fill_products(const int* __restrict__ a_row_p, const int* __restrict__ a_col_i, 
       const uint32_t bw = b_bm[(size_t)k * W + w];
       if ((bw >> bit) & 1u) {
         const int bidx = b_row_p[k] + b_pre[(size_t)k * W + w] + __popc(bw & below);
-        Entry e;
-        e.a_off = (uint32_t)a_blk_p[ab];
-        e.b_off = (uint32_t)b_blk_p[bidx];
-        e.ks = (uint32_t)ks[k];
-        entries[p + cnt] = e;
+        entries[p + cnt] = Entry::make(a_blk_p[ab], b_blk_p[bidx], ks[k]);
         ++cnt;
       }
     }
@@ -488,11 +494,7 @@ fill_products_grid(const int* __restrict__ a_row_p, const int* __restrict__ a_co
       const uint32_t bw = b_bm[(size_t)k * W + w];
       const int bidx = b_row_p[k] + b_pre[(size_t)k * W + w] + __popc(bw & below);
       if (F.a_norms && F.a_norms[ab] * F.b_norms[bidx] < reps) continue;
-      Entry e;
-      e.a_off = (uint32_t)a_blk_p[ab];
-      e.b_off = (uint32_t)b_blk_p[bidx];
-      e.ks = (uint32_t)ks[k];
-      entries[p0 + cnt] = e;
+      entries[p0 + cnt] = Entry::make(a_blk_p[ab], b_blk_p[bidx], ks[k]);
       ++cnt;
     }
   }
@@ -665,8 +667,8 @@ __device__ __forceinline__ void cblock_f64(const Desc& d, const Entry* __restric
   const int m = d.m, n = d.n;
   const Entry* e = entries + d.prod_start;
   for (int p = 0; p < d.prod_cnt; ++p) {
-    const uint32_t ao = e[p].a_off, bo = e[p].b_off, kk = e[p].ks;
-    block_product_f64<MA, NC, false>(acc, a_data + ao, b_data + bo, m, n, (int)kk, L, row0, col0);
+    const uint64_t ao = e[p].a_off(), bo = e[p].b_off();
+    block_product_f64<MA, NC, false>(acc, a_data + ao, b_data + bo, m, n, e[p].ks(), L, row0, col0);
   }
   double* C = c_out + d.c_off;
   const bool has_in = d.cin_off >= 0;
@@ -748,12 +750,12 @@ __device__ __forceinline__ void cblock_f64_lds(const Desc& d, const Entry* __res
   // The product-list entries are kept two ahead in scalar registers: entry p+1 is needed when product p's operands
   // have been copied to LDS (to start the next prefetch), so it is requested one trip earlier and its scalar-load
   // latency never sits between the LDS copy and the MFMAs.
-  auto issue = [&](uint32_t a_off, uint32_t b_off_in, int ks) {
+  auto issue = [&](uint64_t a_off, uint64_t b_off_in, int ks) {
     const int abytes = m * ks * 8, bbytes = ks * n * 8;
     const int nca = (m * ((ks + 3) & ~3) * 8 + 1023) >> 10, ncb = (bbytes + 1023) >> 10;
     const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)(a_data + a_off), 0, abytes, 0x00020000);
     // dbg 128 (profiling only): fold all B blocks onto the first 1 MB of B -> L2-resident; isolates the cost of L2 misses
-    const uint32_t b_off = (dbg & 128) ? (b_off_in % (uint32_t)(131072 - 1024)) : b_off_in;
+    const uint64_t b_off = (dbg & 128) ? (b_off_in % (uint64_t)(131072 - 1024)) : b_off_in;
     const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)(b_data + b_off), 0, bbytes, 0x00020000);
 #pragma unroll
     for (int c = 0; c < CA; ++c)
@@ -770,11 +772,11 @@ __device__ __forceinline__ void cblock_f64_lds(const Desc& d, const Entry* __res
 #pragma unroll
     for (int c = 0; c < CB; ++c) rb[c] = u32x4{0u, 0x3ff00000u, 0u, 0x3ff00000u};
   }
-  Entry e0 = cnt > 0 ? e[0] : Entry{0u, 0u, 1u};            // product p (being staged / multiplied)
+  Entry e0 = cnt > 0 ? e[0] : Entry::make(0, 0, 1);            // product p (being staged / multiplied)
   Entry e1 = cnt > 1 ? e[1] : e0;                            // product p + 1 (prefetched next)
-  if (cnt > 0 && !(dbg & 1)) issue(e0.a_off, e0.b_off, (int)e0.ks);
+  if (cnt > 0 && !(dbg & 1)) issue(e0.a_off(), e0.b_off(), e0.ks());
   for (int p = 0; p < cnt; ++p) {
-    const int ks = (int)e0.ks;
+    const int ks = e0.ks();
     if (!(dbg & 4)) {
       const int nca = (m * ((ks + 3) & ~3) * 8 + 1023) >> 10, ncb = (ks * n * 8 + 1023) >> 10;
 #pragma unroll
@@ -784,7 +786,7 @@ __device__ __forceinline__ void cblock_f64_lds(const Desc& d, const Entry* __res
       for (int c = 0; c < CB; ++c)
         if (c < ncb) *reinterpret_cast<u32x4*>(lds_b + c * 1024 + voff) = rb[c];
     }
-    if (p + 1 < cnt && !(dbg & 1)) issue(e1.a_off, e1.b_off, (int)e1.ks);
+    if (p + 1 < cnt && !(dbg & 1)) issue(e1.a_off(), e1.b_off(), e1.ks());
     const Entry e2 = e[p + 2 < cnt ? p + 2 : cnt - 1];      // requested now, first used one trip later
     if (!(dbg & 2))
       block_product_f64_lds<MA, NC>(acc, reinterpret_cast<const double*>(lds_a), reinterpret_cast<const double*>(lds_b), m, n, ks, L);
@@ -847,10 +849,10 @@ __device__ __forceinline__ void cblock_f64_exact(const Desc& d, const Entry* __r
     const int kt = 4 * (KS - 1) + L.kq;
     pbt[c] = reinterpret_cast<const double*>(lds_b) + (kt < K ? kt : 0) + K * col;
   }
-  auto issue = [&](uint32_t a_off, uint32_t b_off_in) {
+  auto issue = [&](uint64_t a_off, uint64_t b_off_in) {
     if (dbg & 1) return;
     const uint32_t fold = (dbg >> 16) ? (uint32_t)(dbg >> 16) * 65536u : 131072u;  // B window of the L2/MALL experiments, doubles
-    const uint32_t b_off = (dbg & 128) ? (b_off_in % (fold - 1024u)) : b_off_in;
+    const uint64_t b_off = (dbg & 128) ? (b_off_in % (uint64_t)(fold - 1024u)) : b_off_in;
     const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)(a_data + a_off), 0, M * K * 8, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)(b_data + b_off), 0, K * N * 8, 0x00020000);
 #pragma unroll
@@ -863,7 +865,7 @@ __device__ __forceinline__ void cblock_f64_exact(const Desc& d, const Entry* __r
   // candidate, whose list entry was requested one trip earlier); the others are summed afterwards.
   int i0 = 0;
   Entry e0 = e[0];
-  while (i0 < cnt && (int)e0.ks != K) {
+  while (i0 < cnt && e0.ks() != K) {
     ++i0;
     e0 = e[i0 < cnt ? i0 : cnt - 1];
   }
@@ -875,7 +877,7 @@ __device__ __forceinline__ void cblock_f64_exact(const Desc& d, const Entry* __r
 #pragma unroll
     for (int c = 0; c < CB; ++c) rb[c] = u32x4{0u, 0x3ff00000u, 0u, 0x3ff00000u};
   }
-  if (i0 < cnt) issue(e0.a_off, e0.b_off);
+  if (i0 < cnt) issue(e0.a_off(), e0.b_off());
   while (i0 < cnt) {
     if (!(dbg & 4)) {
 #pragma unroll
@@ -883,11 +885,11 @@ __device__ __forceinline__ void cblock_f64_exact(const Desc& d, const Entry* __r
 #pragma unroll
       for (int c = 0; c < CB; ++c) *reinterpret_cast<u32x4*>(lds_b + c * 1024 + voff) = rb[c];
     }
-    while (i1 < cnt && (int)e1.ks != K) {
+    while (i1 < cnt && e1.ks() != K) {
       ++i1;
       e1 = e[i1 < cnt ? i1 : cnt - 1];
     }
-    if (i1 < cnt) issue(e1.a_off, e1.b_off);
+    if (i1 < cnt) issue(e1.a_off(), e1.b_off());
     const Entry e2 = e[i1 + 1 < cnt ? i1 + 1 : cnt - 1];
     if (!(dbg & 2))
 #pragma unroll
@@ -909,7 +911,7 @@ __device__ __forceinline__ void cblock_f64_exact(const Desc& d, const Entry* __r
   }
   for (int p = 0; p < cnt; ++p) {
     const Entry ep = e[p];
-    if ((int)ep.ks != K) block_product_f64<MA, NC, false>(acc, a_data + ep.a_off, b_data + ep.b_off, M, N, (int)ep.ks, L);
+    if (ep.ks() != K) block_product_f64<MA, NC, false>(acc, a_data + ep.a_off(), b_data + ep.b_off(), M, N, ep.ks(), L);
   }
   double* C = c_out + d.c_off;
   const bool has_in = d.cin_off >= 0;
@@ -1033,8 +1035,12 @@ __device__ __forceinline__ Desc load_desc_uniform(const Desc* __restrict__ descs
 template <int CMAX>
 __device__ __forceinline__ void pipe_issue(const PipeCtx& X, int64_t pidx, int m, int n, u32x4 (&ra)[CMAX], u32x4 (&rb)[CMAX]) {
   const Entry e = X.entries[pidx];
-  const uint32_t ao = __builtin_amdgcn_readfirstlane(e.a_off), bo = __builtin_amdgcn_readfirstlane(e.b_off);
-  const int ks = __builtin_amdgcn_readfirstlane((int)e.ks);
+  Entry u;  // wave-uniform copy
+  u.a_lo = __builtin_amdgcn_readfirstlane(e.a_lo);
+  u.b_lo = __builtin_amdgcn_readfirstlane(e.b_lo);
+  u.w = __builtin_amdgcn_readfirstlane(e.w);
+  const uint64_t ao = u.a_off(), bo = u.b_off();
+  const int ks = u.ks();
   const int abytes = m * ks * 8, bbytes = ks * n * 8;
   const int nca = (m * ((ks + 3) & ~3) * 8 + 1023) >> 10, ncb = (bbytes + 1023) >> 10;
   const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)(X.a_data + ao), 0, abytes, 0x00020000);
@@ -1145,7 +1151,7 @@ __global__ void __launch_bounds__(256) mm_numeric_f64_pipe(const Desc* __restric
   int p = -1, ks = 0;
   for (;;) {
     if (p >= 0) {
-      ks = __builtin_amdgcn_readfirstlane((int)entries[cur.prod_start + p].ks);
+      ks = __builtin_amdgcn_readfirstlane(entries[cur.prod_start + p].ks());
       const int nca = (cur.m * ((ks + 3) & ~3) * 8 + 1023) >> 10, ncb = (ks * cur.n * 8 + 1023) >> 10;
 #pragma unroll
       for (int c = 0; c < CMAX; ++c)
@@ -1253,11 +1259,11 @@ __device__ __forceinline__ void cblock_f32_lds(const Desc& d, const Entry* __res
   u32x4 ra[CH], rb[CH];
   const int voff = lane * 16;
   auto issue = [&](int p) {
-    const int ks = (int)e[p].ks;
+    const int ks = e[p].ks();
     const int abytes = m * ks * 4, bbytes = ks * n * 4;
     const int nca = (m * (ks + 1) * 4 + 1023) >> 10, ncb = (bbytes + 1023) >> 10;  // A: one zero column of k padding
-    const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)(a_data + e[p].a_off), 0, abytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)(b_data + e[p].b_off), 0, bbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)(a_data + e[p].a_off()), 0, abytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)(b_data + e[p].b_off()), 0, bbytes, 0x00020000);
 #pragma unroll
     for (int c = 0; c < CH; ++c)
       if (c < nca) ra[c] = __builtin_amdgcn_raw_buffer_load_b128(rsa, voff, c * 1024, 0);
@@ -1269,7 +1275,7 @@ __device__ __forceinline__ void cblock_f32_lds(const Desc& d, const Entry* __res
   const int i = lane & 31, kh = lane >> 5;
   const int arow = i < m ? i : m - 1, bcol = i < n ? i : n - 1;
   for (int p = 0; p < cnt; ++p) {
-    const int ks = (int)e[p].ks;
+    const int ks = e[p].ks();
     const int kn = ks * n;
     const int nca = (m * (ks + 1) * 4 + 1023) >> 10, ncb = (kn * 4 + 1023) >> 10;
     const unsigned inv = (65536u + (unsigned)ks - 1u) / (unsigned)ks;  // j = (e * inv) >> 16 == e / ks for e < 2048, ks <= 32
@@ -1345,7 +1351,7 @@ __device__ __forceinline__ void cblock_f32_exact(const Desc& d, const Entry* __r
   const float* pa = lds_a + (i < M ? i : M - 1) + M * kh;
   const float* pb = lds_bt + (i < N ? i : N - 1) + LDN * kh;
   const float* pbt = lds_bt + (i < N ? i : N - 1) + LDN * ((K & 1) && kh ? K - 1 : 2 * (KS2 - 1) + kh);  // last step of an odd K
-  auto issue = [&](uint32_t a_off, uint32_t b_off) {
+  auto issue = [&](uint64_t a_off, uint64_t b_off) {
     const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)(a_data + a_off), 0, M * K * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)(b_data + b_off), 0, K * N * 4, 0x00020000);
 #pragma unroll
@@ -1355,13 +1361,13 @@ __device__ __forceinline__ void cblock_f32_exact(const Desc& d, const Entry* __r
   };
   int i0 = 0;
   Entry e0 = e[0];
-  while (i0 < cnt && (int)e0.ks != K) {
+  while (i0 < cnt && e0.ks() != K) {
     ++i0;
     e0 = e[i0 < cnt ? i0 : cnt - 1];
   }
   int i1 = i0 + 1;
   Entry e1 = e[i1 < cnt ? i1 : cnt - 1];
-  if (i0 < cnt) issue(e0.a_off, e0.b_off);
+  if (i0 < cnt) issue(e0.a_off(), e0.b_off());
   while (i0 < cnt) {
 #pragma unroll
     for (int c = 0; c < CA; ++c) *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(lds_a) + c * 1024 + voff) = ra[c];
@@ -1369,11 +1375,11 @@ __device__ __forceinline__ void cblock_f32_exact(const Desc& d, const Entry* __r
     for (int c = 0; c < CB; ++c)
 #pragma unroll
       for (int t = 0; t < 4; ++t) lds_bt[baddr[c][t]] = __uint_as_float(rb[c][t]);
-    while (i1 < cnt && (int)e1.ks != K) {
+    while (i1 < cnt && e1.ks() != K) {
       ++i1;
       e1 = e[i1 < cnt ? i1 : cnt - 1];
     }
-    if (i1 < cnt) issue(e1.a_off, e1.b_off);
+    if (i1 < cnt) issue(e1.a_off(), e1.b_off());
     const Entry e2 = e[i1 + 1 < cnt ? i1 + 1 : cnt - 1];
 #pragma unroll
     for (int s2 = 0; s2 < KS2; ++s2) {
@@ -1388,7 +1394,7 @@ __device__ __forceinline__ void cblock_f32_exact(const Desc& d, const Entry* __r
   }
   for (int p = 0; p < cnt; ++p) {
     const Entry ep = e[p];
-    if ((int)ep.ks != K) block_product_f32<false>(acc, a_data + ep.a_off, b_data + ep.b_off, M, N, (int)ep.ks, lane);
+    if (ep.ks() != K) block_product_f32<false>(acc, a_data + ep.a_off(), b_data + ep.b_off(), M, N, ep.ks(), lane);
   }
   float* C = c_out + d.c_off;
   const bool has_in = d.cin_off >= 0;
@@ -1457,7 +1463,7 @@ __global__ void __launch_bounds__(256) mm_numeric_f32(const Desc* __restrict__ d
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
       for (int p = 0; p < d.prod_cnt; ++p)
-        block_product_f32<false>(acc, a_data + e[p].a_off, b_data + e[p].b_off, m, n, (int)e[p].ks, lane, row0, col0);
+        block_product_f32<false>(acc, a_data + e[p].a_off(), b_data + e[p].b_off(), m, n, e[p].ks(), lane, row0, col0);
       float* C = c_out + d.c_off;
       const float* Ci = c_in + (has_in ? d.cin_off : 0);
       const int col = col0 + (lane & 31);
@@ -2084,6 +2090,10 @@ int dbcsr_amd_mm_symbolic_filtered(void* handle, libsmm_acc_data_t datatype, dou
     E->max_m = mx[0]; E->min_m = -mx[1];
     E->max_k = mx[2]; E->min_k = -mx[3];
     E->max_n = mx[4]; E->min_n = -mx[5];
+    if (E->max_k > 0xffff) {
+      fprintf(stderr, "dbcsr_amd_mm_symbolic: block sizes above 65535 are not supported (k extent is packed in 16 bits)\n");
+      return -1;
+    }
     // exact-size kernel: only when one (m, n, k) covers at least 90 % of the block rows / columns of each dimension
     const int* md = reinterpret_cast<const int*>(E->host_scalars + 8);
     const bool dominant = 10ll * md[1] >= 9ll * nbr && 10ll * md[3] >= 9ll * nbk && 10ll * md[5] >= 9ll * nbc;
