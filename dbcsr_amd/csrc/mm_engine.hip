@@ -1235,6 +1235,59 @@ __global__ void __launch_bounds__(256) mode_of(const int* __restrict__ v, int n,
   }
 }
 
+// ---- fp64, C blocks of at most 4 x 4 (BASELINE config 1: 4 x 4 x 4 blocks) -------------------------------------------
+// v_mfma_f64_4x4x4_4b_f64 multiplies FOUR independent 4x4x4 block triples at once (lane bits 2-3 select the triple).  With
+// one wave per C block three quarters of every instruction are padding and a wave lives for ten products; here a wave
+// owns four C blocks, one per MFMA sub-block, each walking its own product list, and every lane fetches exactly the A and
+// B element it feeds (no LDS, no staging): per block product 2 element loads per lane and one MFMA per 4 of k.
+// Sub-block b of lane l: b = (l >> 2) & 3; operands A[i = l & 3][k = l >> 4], B[k = l >> 4][j = l & 3]; result C[i = l >> 4][j = l & 3].
+__global__ void __launch_bounds__(256) mm_numeric_f64_tiny(const Desc* __restrict__ descs, int64_t nblk, const Entry* __restrict__ entries,
+                                                           const double* __restrict__ a_data, const double* __restrict__ b_data,
+                                                           double* __restrict__ c_out, const double* __restrict__ c_in, double alpha,
+                                                           double beta, int skip_empty, const int* __restrict__ order) {
+  const int lane = threadIdx.x & 63;
+  const int wid = threadIdx.x >> 6;
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int sub = (lane >> 2) & 3, x = lane & 3, kq = lane >> 4;
+  const int64_t pos = ((int64_t)wg * 4 + wid) * 4 + sub;  // gridDim.x * 16 == padded length of order[]
+  const int cb = order[pos];
+  const bool live = cb >= 0 && cb < nblk;
+  Desc d;
+  d.prod_cnt = 0;
+  d.m = d.n = 0;
+  d.c_off = d.cin_off = d.prod_start = 0;
+  if (live) d = descs[cb];
+  const int m = d.m, n = d.n;
+  const Entry* e = entries + d.prod_start;
+  const int cnt = live ? d.prod_cnt : 0;
+  double acc = 0.0;
+  Entry cur = Entry::make(0, 0, 0);
+  if (cnt > 0) cur = e[0];
+  for (int p = 0; __any(p < cnt); ++p) {
+    const bool on = p < cnt;
+    Entry nxt = cur;
+    if (p + 1 < cnt) nxt = e[p + 1];  // requested before this product's elements: one entry ahead
+    const int ks = on ? cur.ks() : 0;
+    const double* A = a_data + cur.a_off();
+    const double* B = b_data + cur.b_off();
+    for (int kb = 0; __any(kb < ks); kb += 4) {
+      const int k = kb + kq;
+      const bool kv = k < ks;
+      const double av = (kv && x < m) ? A[x + m * k] : 0.0;
+      const double bv = (kv && x < n) ? B[k + ks * x] : 0.0;
+      acc = __builtin_amdgcn_mfma_f64_4x4x4f64(av, bv, acc, 0, 0, 0);
+    }
+    cur = nxt;
+  }
+  if (!live || (skip_empty && cnt == 0)) return;
+  const int i = kq, j = x;
+  if (i < m && j < n) {
+    double v = alpha * acc;
+    if (d.cin_off >= 0) v += beta * c_in[d.cin_off + i + m * j];
+    c_out[d.c_off + i + m * j] = v;
+  }
+}
+
 // ---- fp32, LDS-staged (blocks up to 32 x 32; BASELINE config 5) -----------------------------------------
 // One v_mfma_f32_32x32x2_f32 covers the whole C block for 2 k.  A (m x k, column-major) is copied to LDS as
 // is: its fragment (lane = row, two k per instruction) reads 32 consecutive floats.  B is stored k x n with k
@@ -1888,6 +1941,7 @@ struct Engine {
   Window crop_win = {0, 0, 0, 0};       // window of the last dbcsr_amd_bcsr_crop_count
   bool crop_pending = false;
   int hot_m = 0, hot_n = 0, hot_k = 0;  // dominant block sizes of the last symbolic phase (0: none)
+  int use_tiny = 1;                     // DBCSR_AMD_MM_TINY=0: no packed kernel for blocks of at most 4 x 4
   int use_hot = 1;                      // DBCSR_AMD_MM_HOT=0: never use the exact-size kernels
   int lds_pad = 0;                      // DBCSR_AMD_MM_LDS_PAD: extra LDS bytes per workgroup (occupancy experiments)
   int64_t panel_bytes = 160ll << 20;  // DBCSR_AMD_MM_PANEL_MB: target size of a B column panel
@@ -1946,6 +2000,7 @@ int dbcsr_amd_mm_create(void** handle) {
   if (const char* k = getenv("DBCSR_AMD_MM_PIPE_G")) E->pipe_g = std::max(1, atoi(k));
   if (const char* k = getenv("DBCSR_AMD_MM_DBG")) E->dbg = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_HOT")) E->use_hot = atoi(k);
+  if (const char* k = getenv("DBCSR_AMD_MM_TINY")) E->use_tiny = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_LDS_PAD")) E->lds_pad = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_SYMBOLIC")) E->force_word_kernels = strcmp(k, "word") == 0;
   if (const char* k = getenv("DBCSR_AMD_MM_PANEL_MB")) E->panel_bytes = (int64_t)atoll(k) << 20;
@@ -2140,7 +2195,7 @@ int dbcsr_amd_mm_symbolic_filtered(void* handle, libsmm_acc_data_t datatype, dou
   E->order_len = E->host_scalars[7];
   if (E->order.ensure((size_t)(8 * E->order_len) + 64)) return -1;
   if (E->order_len > 0) {
-    ACC_CHECK(hipMemsetAsync(E->order.p, 0xff, sizeof(int) * (size_t)(8 * E->order_len), st));
+    ACC_CHECK(hipMemsetAsync(E->order.p, 0xff, sizeof(int) * ((size_t)(8 * E->order_len) + 64), st));  // padding included
     hipLaunchKernelGGL(order_fill, grid_for((int64_t)nbr * W), dim3(256), 0, st, E->c_bm.p, E->c_pre.p, E->row_nnz.p, c_out_row_p,
                        E->order_base.p, nbr, W, PW, NP, NG, RG, E->order_len, E->order.p);
   }
@@ -2189,7 +2244,14 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
   if (datatype == dbcsr_type_real_8) {
     // LDS path: blocks of at most 32 x 32 (any smaller size: the staging loads are bounds-checked buffer loads)
     const bool small = E->max_m <= 32 && E->max_k <= 32 && E->max_n <= 32 && E->min_m >= 1 && E->min_k >= 1 && E->min_n >= 1;
-    if (small && E->use_lds) {
+    if (E->use_tiny && E->max_m <= 4 && E->max_n <= 4 && E->min_m >= 1 && E->min_n >= 1 && E->min_k >= 1) {
+      // four C blocks per wave, one per MFMA sub-block; order[] is padded to a multiple of 4 per XCD stream, so a wave's
+      // four positions never straddle two streams only if the stream length is a multiple of 16: the tail positions hold -1
+      const unsigned nwg_t = (unsigned)((8 * E->order_len + 15) / 16);
+      hipLaunchKernelGGL(mm_numeric_f64_tiny, dim3(nwg_t), dim3(256), 0, st, E->descs.p, nblk, E->entries.p,
+                         static_cast<const double*>(a->data), static_cast<const double*>(b->data), static_cast<double*>(c_out->data),
+                         static_cast<const double*>(c_in->data), alpha, beta, skip_empty, E->order.p);
+    } else if (small && E->use_lds) {
       // per-wave LDS slice.  Staging writes whole 1 KiB chunks (128 doubles), A's chunks first, then B's: the B part may
       // start right after A's (zero-padded) block -- the tail of A's last chunk is simply overwritten by B's first chunk
       // (one wave, in-order LDS queue) -- and only B's part is rounded up to whole chunks.  For 23x23 blocks this is

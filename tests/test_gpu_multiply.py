@@ -196,3 +196,17 @@ def test_fp32_mixed_sizes(mix):
     assert np.array_equal(out.row_p, ref.row_p) and np.array_equal(out.col_i, ref.col_i) and np.array_equal(out.blk_p, ref.blk_p)
     assert flop[0] == info["flop"]
     assert float(np.max(np.abs(out.data - ref.data))) <= 1e-5 * float(np.max(np.abs(ref.data)))
+
+
+@pytest.mark.parametrize("bs_m,bs_n,bs_k", [([1, 4], [1, 4], [1, 4]), ([1, 1, 1, 2, 1, 3, 1, 4], [1, 4, 1, 3, 1, 1], [1, 4]),
+                                            ([1, 3], [1, 2], [1, 9, 1, 5, 1, 13]), ([1, 4], [1, 4], [1, 32, 1, 1])])
+@pytest.mark.parametrize("alpha,beta,retain", [(1.0, 1.0, False), (-0.5, 2.0, False), (1.0, 0.0, True)])
+def test_blocks_of_at_most_4x4_packed_kernel(bs_m, bs_n, bs_k, alpha, beta, retain):
+    """C blocks of at most 4 x 4 run the packed kernel (four C blocks per wavefront); k is unrestricted."""
+    A, B, Cm = O.perf_case(150, 130, 170, 0.7, 0.6, 0.8, bs_m, bs_n, bs_k)
+    check_against_oracle(A, B, Cm, alpha=alpha, beta=beta, retain=retain)
+
+
+def test_config1_shape_4x4_blocks():
+    A, B, Cm = O.perf_case(512, 512, 512, 0.9, 0.9, 0.9, [1, 4], [1, 4], [1, 4])
+    check_against_oracle(A, B, Cm)
