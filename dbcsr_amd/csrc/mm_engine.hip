@@ -913,20 +913,64 @@ __device__ __forceinline__ void cblock_f64_exact(const Desc& d, const Entry* __r
     const Entry ep = e[p];
     if (ep.ks() != K) block_product_f64<MA, NC, false>(acc, a_data + ep.a_off(), b_data + ep.b_off(), M, N, ep.ks(), L);
   }
-  double* C = c_out + d.c_off;
   const bool has_in = d.cin_off >= 0;
-  const double* Ci = c_in + (has_in ? d.cin_off : 0);
+  if (dbg & 8) {  // scattered 8-byte stores straight from the accumulators (the first version; kept for comparison)
+    double* C = c_out + d.c_off;
+    const double* Ci = c_in + (has_in ? d.cin_off : 0);
+#pragma unroll
+    for (int a = 0; a < MA; ++a)
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const int row = 8 * a + L.rowd, col = 8 * c + L.coll;
+        if (row < M && col < N) {
+          double v = alpha * acc[a][c];
+          if (has_in) v += beta * Ci[row + (size_t)M * col];
+          C[row + (size_t)M * col] = v;
+        }
+      }
+    return;
+  }
+  // C epilogue through LDS: the block is laid out as stored (column-major, contiguous) in the wave's staging area and
+  // leaves in whole 1 KiB pieces -- 16 B per lane, full cache lines except at the two ends of the block -- with the
+  // streaming hint, so that the 8.6 GB of C that config 2 writes do not push the A block-rows out of L2 / the B panel out
+  // of the Infinity Cache.  (Non-temporal on the scattered 8-byte stores doubled WRITE_SIZE: partial lines are not combined.)
+  constexpr int CC = (M * N * 8 + 1023) / 1024;
+  double* lds_c = reinterpret_cast<double*>(lds_a);
 #pragma unroll
   for (int a = 0; a < MA; ++a)
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       const int row = 8 * a + L.rowd, col = 8 * c + L.coll;
-      if (row < M && col < N) {
-        double v = alpha * acc[a][c];
-        if (has_in) v += beta * Ci[row + (size_t)M * col];
-        C[row + (size_t)M * col] = v;
-      }
+      if (row < M && col < N) lds_c[row + M * col] = alpha * acc[a][c];
     }
+  const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc((void*)(c_out + d.c_off), 0, M * N * 8, 0x00020000);
+  typedef double f64x2 __attribute__((ext_vector_type(2)));
+  if (has_in) {
+    const __amdgpu_buffer_rsrc_t rsi = __builtin_amdgcn_make_buffer_rsrc((void*)(c_in + d.cin_off), 0, M * N * 8, 0x00020000);
+    u32x4 ci[CC];
+#pragma unroll
+    for (int c = 0; c < CC; ++c) ci[c] = __builtin_amdgcn_raw_buffer_load_b128(rsi, voff, c * 1024, 0);
+#pragma unroll
+    for (int c = 0; c < CC; ++c) {
+      f64x2 v = *reinterpret_cast<const f64x2*>(lds_a + c * 1024 + voff);
+      const f64x2 w = __builtin_bit_cast(f64x2, ci[c]);
+      v[0] += beta * w[0];
+      v[1] += beta * w[1];
+      if (dbg & 16)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsc, voff, c * 1024, 0);
+      else
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsc, voff, c * 1024, 2);
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < CC; ++c) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(lds_a + c * 1024 + voff);
+      if (dbg & 16)
+        __builtin_amdgcn_raw_buffer_store_b128(v, rsc, voff, c * 1024, 0);
+      else
+        __builtin_amdgcn_raw_buffer_store_b128(v, rsc, voff, c * 1024, 2);
+    }
+  }
 }
 
 // C blocks of exactly M x N take the exact-size path; every other block of the launch the generic one.
