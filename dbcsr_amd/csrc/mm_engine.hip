@@ -751,8 +751,10 @@ __device__ __forceinline__ void cblock_f64_lds(const Desc& d, const Entry* __res
   // have been copied to LDS (to start the next prefetch), so it is requested one trip earlier and its scalar-load
   // latency never sits between the LDS copy and the MFMAs.
   auto issue = [&](uint64_t a_off, uint64_t b_off_in, int ks) {
-    const int abytes = m * ks * 8, bbytes = ks * n * 8;
-    const int nca = (m * ((ks + 3) & ~3) * 8 + 1023) >> 10, ncb = (bbytes + 1023) >> 10;
+    // explicit scalarisation: with the k extent known to fit 16 bits the compiler multiplies on the VALU (mul24), the buffer
+    // descriptor then sits in VGPRs and every load becomes a waterfall loop (measured: config 3 10.6 -> 12.7 ms)
+    const int abytes = __builtin_amdgcn_readfirstlane(m * ks * 8), bbytes = __builtin_amdgcn_readfirstlane(ks * n * 8);
+    const int nca = __builtin_amdgcn_readfirstlane((m * ((ks + 3) & ~3) * 8 + 1023) >> 10), ncb = (bbytes + 1023) >> 10;
     const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)(a_data + a_off), 0, abytes, 0x00020000);
     // dbg 128 (profiling only): fold all B blocks onto the first 1 MB of B -> L2-resident; isolates the cost of L2 misses
     const uint64_t b_off = (dbg & 128) ? (b_off_in % (uint64_t)(131072 - 1024)) : b_off_in;
@@ -778,7 +780,7 @@ __device__ __forceinline__ void cblock_f64_lds(const Desc& d, const Entry* __res
   for (int p = 0; p < cnt; ++p) {
     const int ks = e0.ks();
     if (!(dbg & 4)) {
-      const int nca = (m * ((ks + 3) & ~3) * 8 + 1023) >> 10, ncb = (ks * n * 8 + 1023) >> 10;
+      const int nca = __builtin_amdgcn_readfirstlane((m * ((ks + 3) & ~3) * 8 + 1023) >> 10), ncb = __builtin_amdgcn_readfirstlane((ks * n * 8 + 1023) >> 10);
 #pragma unroll
       for (int c = 0; c < CA; ++c)
         if (c < nca) *reinterpret_cast<u32x4*>(lds_a + c * 1024 + voff) = ra[c];
@@ -1085,8 +1087,8 @@ __device__ __forceinline__ void pipe_issue(const PipeCtx& X, int64_t pidx, int m
   u.w = __builtin_amdgcn_readfirstlane(e.w);
   const uint64_t ao = u.a_off(), bo = u.b_off();
   const int ks = u.ks();
-  const int abytes = m * ks * 8, bbytes = ks * n * 8;
-  const int nca = (m * ((ks + 3) & ~3) * 8 + 1023) >> 10, ncb = (bbytes + 1023) >> 10;
+  const int abytes = __builtin_amdgcn_readfirstlane(m * ks * 8), bbytes = __builtin_amdgcn_readfirstlane(ks * n * 8);  // scalar on purpose, see cblock_f64_lds
+  const int nca = __builtin_amdgcn_readfirstlane((m * ((ks + 3) & ~3) * 8 + 1023) >> 10), ncb = (bbytes + 1023) >> 10;
   const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)(X.a_data + ao), 0, abytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)(X.b_data + bo), 0, bbytes, 0x00020000);
 #pragma unroll
@@ -1196,7 +1198,7 @@ __global__ void __launch_bounds__(256) mm_numeric_f64_pipe(const Desc* __restric
   for (;;) {
     if (p >= 0) {
       ks = __builtin_amdgcn_readfirstlane(entries[cur.prod_start + p].ks());
-      const int nca = (cur.m * ((ks + 3) & ~3) * 8 + 1023) >> 10, ncb = (ks * cur.n * 8 + 1023) >> 10;
+      const int nca = __builtin_amdgcn_readfirstlane((cur.m * ((ks + 3) & ~3) * 8 + 1023) >> 10), ncb = __builtin_amdgcn_readfirstlane((ks * cur.n * 8 + 1023) >> 10);
 #pragma unroll
       for (int c = 0; c < CMAX; ++c)
         if (c < nca) *reinterpret_cast<u32x4*>(X.lds_a + c * 1024 + X.voff) = ra[c];
@@ -1357,8 +1359,8 @@ __device__ __forceinline__ void cblock_f32_lds(const Desc& d, const Entry* __res
   const int voff = lane * 16;
   auto issue = [&](int p) {
     const int ks = e[p].ks();
-    const int abytes = m * ks * 4, bbytes = ks * n * 4;
-    const int nca = (m * (ks + 1) * 4 + 1023) >> 10, ncb = (bbytes + 1023) >> 10;  // A: one zero column of k padding
+    const int abytes = __builtin_amdgcn_readfirstlane(m * ks * 4), bbytes = __builtin_amdgcn_readfirstlane(ks * n * 4);  // scalar on purpose, see cblock_f64_lds
+    const int nca = __builtin_amdgcn_readfirstlane((m * (ks + 1) * 4 + 1023) >> 10), ncb = (bbytes + 1023) >> 10;  // A: one zero column of k padding
     const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)(a_data + e[p].a_off()), 0, abytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)(b_data + e[p].b_off()), 0, bbytes, 0x00020000);
 #pragma unroll
@@ -1374,7 +1376,7 @@ __device__ __forceinline__ void cblock_f32_lds(const Desc& d, const Entry* __res
   for (int p = 0; p < cnt; ++p) {
     const int ks = e[p].ks();
     const int kn = ks * n;
-    const int nca = (m * (ks + 1) * 4 + 1023) >> 10, ncb = (kn * 4 + 1023) >> 10;
+    const int nca = __builtin_amdgcn_readfirstlane((m * (ks + 1) * 4 + 1023) >> 10), ncb = __builtin_amdgcn_readfirstlane((kn * 4 + 1023) >> 10);
     const unsigned inv = (65536u + (unsigned)ks - 1u) / (unsigned)ks;  // j = (e * inv) >> 16 == e / ks for e < 2048, ks <= 32
 #pragma unroll
     for (int c = 0; c < CH; ++c)
