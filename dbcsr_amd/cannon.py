@@ -334,6 +334,12 @@ class CannonMultiply:
         s1, s2 = self._sub["S1"], self._sub["S2"]
         if s1 is None or s2 is None or not self.local_first:
             # ... during the symbolic phase of the one multiply over the full panels
+            auto_k = getattr(eng, "_auto_kchunks", None)
+            if auto_k is not None and auto_k(self.A_panel, 0.0) > 1:  # large A block-rows: passes over k (multiply.py)
+                arrived()
+                Cout, counts = eng.multiply_local(alpha, self.A_panel, self.B_panel, beta, self.C_in)
+                self.last_tick_flop = getattr(eng, "last_launch_flop", counts.flop)
+                return Cout, counts
             row_p, counts = eng.symbolic(self.A_panel, self.B_panel, self.C_in, retain_sparsity=False)
             arrived()
             Cout = eng.numeric_after_symbolic(alpha, self.A_panel, self.B_panel, beta, self.C_in, row_p, counts, self.dtype)
@@ -343,7 +349,7 @@ class CannonMultiply:
         C1, cnt1 = eng.multiply_local(alpha, s1[0], s1[1], beta, self.C_in)
         arrived()
         Cout, cnt2 = eng.multiply_local(alpha, s2[0], s2[1], 1.0, C1)
-        self.last_tick_flop = cnt2.flop
+        self.last_tick_flop = getattr(eng, "last_launch_flop", cnt2.flop)
         cnt2.flop += cnt1.flop
         cnt2.nproducts += cnt1.nproducts
         return Cout, cnt2

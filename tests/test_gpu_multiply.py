@@ -210,3 +210,17 @@ def test_blocks_of_at_most_4x4_packed_kernel(bs_m, bs_n, bs_k, alpha, beta, reta
 def test_config1_shape_4x4_blocks():
     A, B, Cm = O.perf_case(512, 512, 512, 0.9, 0.9, 0.9, [1, 4], [1, 4], [1, 4])
     check_against_oracle(A, B, Cm)
+
+
+@pytest.mark.parametrize("nchunks", [2, 3, 7])
+def test_k_chunked_passes_match_oracle(nchunks):
+    """L2 blocking over k (MultiplyEngine.multiply_local(kchunks=n)): same structure, values within tolerance."""
+    A, B, Cm = O.perf_case(260, 240, 300, 0.5, 0.6, 0.7, [1, 13, 1, 5], [1, 23, 1, 4], [1, 7, 1, 32, 1, 9])
+    ref, info = O.multiply("N", "N", -1.5, A, B, 0.5, Cm)
+    E = MultiplyEngine()
+    out, counts = E.multiply_local(-1.5, to_dev(A), to_dev(B), 0.5, to_dev(Cm), kchunks=nchunks)
+    torch.cuda.synchronize()
+    got = dev_to_bcsr(out)
+    assert np.array_equal(got.row_p, ref.row_p) and np.array_equal(got.col_i, ref.col_i) and np.array_equal(got.blk_p, ref.blk_p)
+    assert counts.flop == info["flop"] and counts.nproducts == info["nproducts"]
+    assert np.all(np.abs(got.data - ref.data) <= 1e-10 * np.maximum(np.abs(ref.data), 1.0))
