@@ -1932,11 +1932,11 @@ __global__ void __launch_bounds__(256) scale_window(const int* __restrict__ row_
 // ----------------------------------------------------------------------------
 // host side
 // ----------------------------------------------------------------------------
-// Exact-size kernels are instantiated for cubes of the block sizes CP2K's basis sets and the reference's
-// benchmarks produce (the reference compiles one kernel per (m, n, k) at run time; here the list is fixed at build time
-// and every other case runs the generic kernel; measured on 4 x 4 blocks the generic kernel is 7 % faster, so sizes
+// Exact-size kernels are instantiated for every cube from 9 to 32 (the reference compiles one kernel per (m, n, k) at run
+// time; here the list is fixed at build time and every other case -- mixed sizes, blocks above 32 -- runs the generic kernels; measured on 4 x 4 blocks the generic kernel is 7 % faster, so sizes
 // up to 8 are left to it).
-#define DBCSR_AMD_HOT_SIZES(X) X(9) X(10) X(12) X(13) X(14) X(16) X(17) X(20) X(22) X(23) X(24) X(25) X(26) X(28) X(29) X(32)
+#define DBCSR_AMD_HOT_SIZES(X) \
+  X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32)
 
 static bool launch_hot_f64(int m, int n, int k, dim3 grid, size_t lds_bytes, hipStream_t st, const Desc* descs, int64_t nblk,
                            const Entry* entries, const double* a_data, const double* b_data, double* c_out, const double* c_in,

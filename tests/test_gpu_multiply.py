@@ -224,3 +224,20 @@ def test_k_chunked_passes_match_oracle(nchunks):
     assert np.array_equal(got.row_p, ref.row_p) and np.array_equal(got.col_i, ref.col_i) and np.array_equal(got.blk_p, ref.blk_p)
     assert counts.flop == info["flop"] and counts.nproducts == info["nproducts"]
     assert np.all(np.abs(got.data - ref.data) <= 1e-10 * np.maximum(np.abs(ref.data), 1.0))
+
+
+@pytest.mark.parametrize("size", list(range(9, 33)))
+def test_exact_size_kernels_every_cube_with_tails(size):
+    """Uniform size s (one exact-size kernel per cube 9..32) with a ragged tail block in every dimension: the tail row / column /
+    inner blocks take the fall-back paths inside the same launch.  fp64 at 1e-10, fp32 against the fp64 oracle at 1e-5."""
+    dim = 12 * size + max(1, size // 3)
+    A, B, Cm = O.perf_case(dim, dim, dim, 0.6, 0.6, 0.7, [1, size], [1, size], [1, size])
+    check_against_oracle(A, B, Cm, alpha=0.75, beta=-1.25)
+    ref, info = O.multiply("N", "N", 0.75, A, B, -1.25, Cm)
+    f32 = lambda M: O.Bcsr(M.row_sizes, M.col_sizes, M.row_p, M.col_i, M.blk_p, M.data.astype(np.float32))
+    dA, dB, dC = to_dev(f32(A)), to_dev(f32(B)), to_dev(f32(Cm))
+    dbcsr_multiply("N", "N", 0.75, dA, dB, -1.25, dC)
+    torch.cuda.synchronize()
+    out = dev_to_bcsr(dC)
+    assert np.array_equal(out.row_p, ref.row_p) and np.array_equal(out.col_i, ref.col_i) and np.array_equal(out.blk_p, ref.blk_p)
+    assert float(np.max(np.abs(out.data - ref.data))) <= 1e-5 * float(np.max(np.abs(ref.data)))
