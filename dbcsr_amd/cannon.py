@@ -347,9 +347,17 @@ class CannonMultiply:
             return Cout, counts
         # local-first: the images owned on both sides are multiplied while the rest is still in flight
         C1, cnt1 = eng.multiply_local(alpha, s1[0], s1[1], beta, self.C_in)
-        arrived()
-        Cout, cnt2 = eng.multiply_local(alpha, s2[0], s2[1], 1.0, C1)
-        self.last_tick_flop = getattr(eng, "last_launch_flop", cnt2.flop)
+        auto_k = getattr(eng, "_auto_kchunks", None)
+        if auto_k is not None and auto_k(s2[0], 0.0) > 1:  # large A block-rows: passes over k (multiply.py)
+            arrived()
+            Cout, cnt2 = eng.multiply_local(alpha, s2[0], s2[1], 1.0, C1)
+            self.last_tick_flop = getattr(eng, "last_launch_flop", cnt2.flop)
+        else:
+            # the symbolic phase of the second part needs only the (replicated) index: it runs while the panels still travel
+            row_p, cnt2 = eng.symbolic(s2[0], s2[1], C1, retain_sparsity=False)
+            arrived()
+            Cout = eng.numeric_after_symbolic(alpha, s2[0], s2[1], 1.0, C1, row_p, cnt2, self.dtype)
+            self.last_tick_flop = cnt2.flop
         cnt2.flop += cnt1.flop
         cnt2.nproducts += cnt1.nproducts
         return Cout, cnt2
