@@ -15,7 +15,13 @@
 //
 // Numeric phase (fp64/fp32 MFMA): one wavefront per C block, all products of
 // the block accumulated in registers, C written exactly once (no atomics, no
-// zero-fill pass, bitwise reproducible).
+// zero-fill pass, bitwise reproducible).  Kernels, chosen per launch by the host code at the end of this file:
+//   mm_numeric_f64_hot<M,N,K> / mm_numeric_f32_hot<M,N,K>  exact-size kernels, one (m, n, k) dominates (cubes 9..32)
+//   mm_numeric_f64_tiny                                    C blocks of at most 4 x 4: four C blocks per wave
+//   mm_numeric_f64_lds<MAXT> / mm_numeric_f64_pipe<MAXT>   any sizes up to 32 (pipe: mixed sizes, few products per block)
+//   mm_numeric_f32_lds                                     fp32, any sizes up to 32
+//   mm_numeric_f64 / mm_numeric_f32                        blocks above 32 (32 x 32 tiles, fragments from global memory)
+// Around them: transpose, checksum, synthetic fill, norm filter, crop / window scale (submatrix limits).
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
