@@ -1,0 +1,205 @@
+// mm_api.hip -- dbcsr_multiply for one rank as ONE native call (include/dbcsr_amd_mm.h: dbcsr_amd_multiply).
+//
+// The orchestration of the reference's dbcsr_multiply_generic (src/mm/dbcsr_mm.F:336-1023) that matters on the hot path --
+// op(A)/op(B) (:520-580), submatrix limits (:631-709: crop of the left matrix to (rows, k) and of the right one to
+// (k, columns) in make_m2s, dbcsr_mm_cannon.F:194-214; beta acts on the window of C only), retain_sparsity, filter_eps
+// (on-the-fly product filter + final block filter, dbcsr_mm_multrec.F:373-383) -- written on top of the primitives of
+// dbcsr_amd_mm.h, so that a Fortran / C host needs one binding instead of re-implementing the sequence.  The Python
+// mirror dbcsr_amd/multiply.py does the same with torch tensors as storage; here storage comes from hipMalloc and the
+// result is handed to the caller (dbcsr_amd_bcsr_release frees it).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+
+#include "../../include/dbcsr_amd_mm.h"
+#include "common.h"
+
+using namespace dbcsr_amd;
+
+namespace {
+
+size_t elem_size(libsmm_acc_data_t dt) { return dt == dbcsr_type_real_8 ? 8 : 4; }
+
+// a BCSR matrix whose four arrays were allocated here
+struct Owned {
+  dbcsr_amd_bcsr m;
+  bool live = false;
+  Owned() {
+    m.nblkrows = m.nblkcols = 0;
+    m.row_blk_size = m.col_blk_size = nullptr;
+    m.row_p = m.col_i = nullptr;
+    m.blk_p = nullptr;
+    m.data = nullptr;
+    m.nblks = 0;
+  }
+  void release() {
+    if (!live) return;
+    (void)hipFree(m.row_p);
+    (void)hipFree(m.col_i);
+    (void)hipFree(m.blk_p);
+    (void)hipFree(m.data);
+    m.row_p = m.col_i = nullptr;
+    m.blk_p = nullptr;
+    m.data = nullptr;
+    live = false;
+  }
+  ~Owned() { release(); }
+  Owned(const Owned&) = delete;
+  Owned& operator=(const Owned&) = delete;
+};
+
+int alloc_arrays(Owned& o, int nbr, int nbc, const int32_t* rs, const int32_t* cs, int64_t nblks, int64_t nze, size_t esz, bool with_row_p) {
+  o.m.nblkrows = nbr;
+  o.m.nblkcols = nbc;
+  o.m.row_blk_size = rs;
+  o.m.col_blk_size = cs;
+  o.m.nblks = nblks;
+  o.live = true;
+  if (with_row_p && hipMalloc(reinterpret_cast<void**>(&o.m.row_p), sizeof(int32_t) * ((size_t)nbr + 1)) != hipSuccess) return -1;
+  if (hipMalloc(reinterpret_cast<void**>(&o.m.col_i), sizeof(int32_t) * (size_t)(nblks > 0 ? nblks : 1)) != hipSuccess) return -1;
+  if (hipMalloc(reinterpret_cast<void**>(&o.m.blk_p), sizeof(int64_t) * (size_t)(nblks > 0 ? nblks : 1)) != hipSuccess) return -1;
+  if (hipMalloc(&o.m.data, esz * (size_t)(nze > 0 ? nze : 1)) != hipSuccess) return -1;
+  return 0;
+}
+
+int alloc_row_p(Owned& o, int nbr) {
+  o.live = true;
+  return hipMalloc(reinterpret_cast<void**>(&o.m.row_p), sizeof(int32_t) * ((size_t)nbr + 1)) == hipSuccess ? 0 : -1;
+}
+
+// copy of src restricted to a window (negative bound = unbounded); also the way to learn nblks / nze of a matrix
+int crop(void* h, libsmm_acc_data_t dt, const dbcsr_amd_bcsr* src, int64_t r0, int64_t r1, int64_t c0, int64_t c1, Owned& dst, int64_t* nze_out,
+         void* stream) {
+  if (alloc_row_p(dst, src->nblkrows)) return -1;
+  int64_t nb = 0, nz = 0;
+  int rc = dbcsr_amd_bcsr_crop_count(h, dt, src, r0, r1, c0, c1, dst.m.row_p, &nb, &nz, stream);
+  if (rc) return rc;
+  if (alloc_arrays(dst, src->nblkrows, src->nblkcols, src->row_blk_size, src->col_blk_size, nb, nz, elem_size(dt), false)) return -1;
+  if (nze_out) *nze_out = nz;
+  return dbcsr_amd_bcsr_crop_apply(h, dt, src, &dst.m, stream);
+}
+
+int transposed(void* h, libsmm_acc_data_t dt, const dbcsr_amd_bcsr* src, Owned& dst, void* stream) {
+  // sizes of src: one counting pass over the whole matrix
+  Owned probe;
+  if (alloc_row_p(probe, src->nblkrows)) return -1;
+  int64_t nb = 0, nz = 0;
+  int rc = dbcsr_amd_bcsr_crop_count(h, dt, src, -1, -1, -1, -1, probe.m.row_p, &nb, &nz, stream);
+  if (rc) return rc;
+  if (alloc_arrays(dst, src->nblkcols, src->nblkrows, src->col_blk_size, src->row_blk_size, nb, nz, elem_size(dt), true)) return -1;
+  return dbcsr_amd_bcsr_transpose(h, dt, src, &dst.m, stream);
+}
+
+int symbolic_numeric(void* h, libsmm_acc_data_t dt, double alpha, const dbcsr_amd_bcsr* a, const dbcsr_amd_bcsr* b, double beta,
+                     const dbcsr_amd_bcsr* c_in, int retain, double eps, Owned& out, dbcsr_amd_mm_counts* counts, void* stream) {
+  if (alloc_row_p(out, c_in->nblkrows)) return -1;
+  int rc = dbcsr_amd_mm_symbolic_filtered(h, dt, alpha, eps, a, b, c_in, retain, out.m.row_p, counts, stream);
+  if (rc) return rc;
+  if (alloc_arrays(out, c_in->nblkrows, c_in->nblkcols, c_in->row_blk_size, c_in->col_blk_size, counts->c_nblks, counts->c_nze, elem_size(dt),
+                   false))
+    return -1;
+  return dbcsr_amd_mm_numeric(h, dt, alpha, a, b, beta, c_in, &out.m, stream);
+}
+
+}  // namespace
+
+extern "C" {
+
+int dbcsr_amd_bcsr_release(dbcsr_amd_bcsr* m) {
+  if (!m) return -1;
+  (void)hipFree(m->row_p);
+  (void)hipFree(m->col_i);
+  (void)hipFree(m->blk_p);
+  (void)hipFree(m->data);
+  m->row_p = m->col_i = nullptr;
+  m->blk_p = nullptr;
+  m->data = nullptr;
+  m->nblks = 0;
+  return 0;
+}
+
+int dbcsr_amd_multiply(void* handle, char transa, char transb, libsmm_acc_data_t datatype, double alpha, const dbcsr_amd_bcsr* matrix_a,
+                       const dbcsr_amd_bcsr* matrix_b, double beta, const dbcsr_amd_bcsr* matrix_c, const int64_t* limits, int retain_sparsity,
+                       double filter_eps, dbcsr_amd_bcsr* c_out, int64_t* flop, void* stream) {
+  if (!handle || !matrix_a || !matrix_b || !matrix_c || !c_out) return -1;
+  if (datatype != dbcsr_type_real_8 && datatype != dbcsr_type_real_4) return -10;
+  auto is_n = [](char t) { return t == 'N' || t == 'n'; };
+  auto is_t = [](char t) { return t == 'T' || t == 't' || t == 'C' || t == 'c'; };  // real data: 'C' == 'T'
+  if ((!is_n(transa) && !is_t(transa)) || (!is_n(transb) && !is_t(transb))) {
+    fprintf(stderr, "dbcsr_amd_multiply: invalid transpose flag\n");
+    return -1;
+  }
+  hipStream_t st = stream_of(stream);
+  const size_t esz = elem_size(datatype);
+  int rc = 0;
+  // op(A), op(B)
+  Owned ta, tb;
+  const dbcsr_amd_bcsr* A = matrix_a;
+  const dbcsr_amd_bcsr* B = matrix_b;
+  if (is_t(transa)) {
+    if ((rc = transposed(handle, datatype, matrix_a, ta, stream))) return rc;
+    A = &ta.m;
+  }
+  if (is_t(transb)) {
+    if ((rc = transposed(handle, datatype, matrix_b, tb, stream))) return rc;
+    B = &tb.m;
+  }
+  if (A->nblkcols != B->nblkrows || A->nblkrows != matrix_c->nblkrows || B->nblkcols != matrix_c->nblkcols) {
+    fprintf(stderr, "dbcsr_amd_multiply: incompatible block dimensions\n");
+    return -1;
+  }
+  // submatrix limits: 1-based inclusive full-matrix indices, 0 = not given
+  Owned ca, cb, cc;
+  const dbcsr_amd_bcsr* Cin = matrix_c;
+  double beta_eff = beta;
+  bool limited = false;
+  if (limits)
+    for (int i = 0; i < 6; ++i) limited = limited || limits[i] != 0;
+  if (limited) {
+    for (int i = 0; i < 6; i += 2)
+      if (limits[i] < 0 || limits[i + 1] < 0 || (limits[i + 1] != 0 && limits[i] > limits[i + 1])) {
+        fprintf(stderr, "dbcsr_amd_multiply: invalid limits\n");
+        return -1;
+      }
+    const int64_t r0 = limits[0] ? limits[0] - 1 : -1, r1 = limits[1] ? limits[1] - 1 : -1;
+    const int64_t c0 = limits[2] ? limits[2] - 1 : -1, c1 = limits[3] ? limits[3] - 1 : -1;
+    const int64_t k0 = limits[4] ? limits[4] - 1 : -1, k1 = limits[5] ? limits[5] - 1 : -1;
+    if ((rc = crop(handle, datatype, A, r0, r1, k0, k1, ca, nullptr, stream))) return rc;
+    if ((rc = crop(handle, datatype, B, k0, k1, c0, c1, cb, nullptr, stream))) return rc;
+    A = &ca.m;
+    B = &cb.m;
+    if (beta != 1.0) {  // dbcsr_scale(matrix_c, beta, limits): on a copy, the caller's C stays as it is
+      int64_t nz = 0;
+      if ((rc = crop(handle, datatype, matrix_c, -1, -1, -1, -1, cc, &nz, stream))) return rc;
+      if ((rc = dbcsr_amd_bcsr_scale_window(handle, datatype, &cc.m, beta, r0, r1, c0, c1, stream))) return rc;
+      Cin = &cc.m;
+    }
+    beta_eff = 1.0;
+  }
+  // the product (with the on-the-fly filter), then the final block filter
+  Owned prod;
+  dbcsr_amd_mm_counts counts;
+  if ((rc = symbolic_numeric(handle, datatype, alpha, A, B, beta_eff, Cin, retain_sparsity, filter_eps, prod, &counts, stream))) return rc;
+  if (flop) *flop = counts.flop;
+  Owned* result = &prod;
+  Owned filtered;
+  if (filter_eps > 0.0 && !retain_sparsity) {
+    if (alloc_row_p(filtered, prod.m.nblkrows)) return -1;
+    int64_t nb = 0, nz = 0;
+    if ((rc = dbcsr_amd_bcsr_filter_count(handle, datatype, &prod.m, filter_eps, filtered.m.row_p, &nb, &nz, stream))) return rc;
+    if (alloc_arrays(filtered, prod.m.nblkrows, prod.m.nblkcols, prod.m.row_blk_size, prod.m.col_blk_size, nb, nz, esz, false)) return -1;
+    if ((rc = dbcsr_amd_bcsr_filter_apply(handle, datatype, &prod.m, &filtered.m, stream))) return rc;
+    result = &filtered;
+  }
+  // temporaries are freed when this function returns: everything that reads them must have finished
+  if (hipStreamSynchronize(st) != hipSuccess) return -1;
+  *c_out = result->m;
+  c_out->row_blk_size = matrix_c->row_blk_size;
+  c_out->col_blk_size = matrix_c->col_blk_size;
+  result->live = false;  // ownership passes to the caller (dbcsr_amd_bcsr_release)
+  return 0;
+}
+
+}  // extern "C"

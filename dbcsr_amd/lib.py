@@ -31,6 +31,7 @@ MM_SYMBOLS = [
     "dbcsr_amd_bcsr_checksum", "dbcsr_amd_bcsr_fill_random", "dbcsr_amd_mm_kernel_name", "dbcsr_amd_mm_timing", "dbcsr_amd_mm_init_c", "dbcsr_amd_bcsr_fill_random_dist",
     "dbcsr_amd_mm_symbolic_filtered", "dbcsr_amd_bcsr_filter_count", "dbcsr_amd_bcsr_filter_apply",
     "dbcsr_amd_bcsr_crop_count", "dbcsr_amd_bcsr_crop_apply", "dbcsr_amd_bcsr_scale_window",
+    "dbcsr_amd_multiply", "dbcsr_amd_bcsr_release",
 ]
 
 
@@ -109,6 +110,9 @@ def load_library():
     L.dbcsr_amd_bcsr_crop_count.argtypes = [vp, i32, BP, i64, i64, i64, i64, vp, C.POINTER(i64), C.POINTER(i64), vp]
     L.dbcsr_amd_bcsr_crop_apply.argtypes = [vp, i32, BP, BP, vp]
     L.dbcsr_amd_bcsr_scale_window.argtypes = [vp, i32, BP, C.c_double, i64, i64, i64, i64, vp]
+    L.dbcsr_amd_multiply.argtypes = [vp, C.c_char, C.c_char, i32, C.c_double, BP, BP, C.c_double, BP, C.POINTER(i64), i32, C.c_double, BP,
+                                     C.POINTER(i64), vp]
+    L.dbcsr_amd_bcsr_release.argtypes = [BP]
     L.dbcsr_amd_mm_init_c.argtypes = [vp, i32, C.c_double, BP, BP, vp]
     L.dbcsr_amd_bcsr_fill_random_dist.argtypes = [vp, i32, BP, i32, vp, vp, i32, vp]
     L.dbcsr_amd_mm_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]

@@ -130,6 +130,18 @@ int dbcsr_amd_bcsr_fill_random(void* handle, libsmm_acc_data_t datatype, const d
 int dbcsr_amd_bcsr_fill_random_dist(void* handle, libsmm_acc_data_t datatype, const dbcsr_amd_bcsr* m, int counter,
   const int32_t* row_gid, const int32_t* col_gid, int32_t nblkrows_global, void* stream);
 
+/* dbcsr_multiply for one rank as one call (src/dbcsr_api.F:1411-1433 -> src/mm/dbcsr_mm.F:336 dbcsr_multiply_generic):
+ *   C_out = beta*C + alpha*op(A)*op(B)
+ * transa/transb 'N' | 'T' | 'C' (real data: 'C' == 'T'); limits = {first_row, last_row, first_column, last_column, first_k,
+ * last_k}, 1-based inclusive full-matrix indices, 0 = not given, NULL = no limits (inside the window beta scales C, outside it C
+ * is unchanged); retain_sparsity and filter_eps as in the reference.  c_out: row_p / col_i / blk_p / data are allocated by the
+ * library (hipMalloc) and belong to the caller afterwards -- dbcsr_amd_bcsr_release frees them; the size arrays are borrowed
+ * from matrix_c.  *flop (may be NULL) receives the reference's flop count.  Returns when the result is complete. */
+int dbcsr_amd_multiply(void* handle, char transa, char transb, libsmm_acc_data_t datatype, double alpha, const dbcsr_amd_bcsr* matrix_a,
+  const dbcsr_amd_bcsr* matrix_b, double beta, const dbcsr_amd_bcsr* matrix_c, const int64_t* limits, int retain_sparsity,
+  double filter_eps, dbcsr_amd_bcsr* c_out, int64_t* flop, void* stream);
+int dbcsr_amd_bcsr_release(dbcsr_amd_bcsr* m);
+
 /* HIP-event timing of the last dbcsr_amd_mm_numeric call on this handle, taken
  * on the stream the kernels were launched on: ms_fill = product-list/index
  * emission kernel, ms_numeric = the block-GEMM kernel.  Waits for that call to
