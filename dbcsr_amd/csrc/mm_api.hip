@@ -103,6 +103,73 @@ int symbolic_numeric(void* h, libsmm_acc_data_t dt, double alpha, const dbcsr_am
   return dbcsr_amd_mm_numeric(h, dt, alpha, a, b, beta, c_in, &out.m, stream);
 }
 
+// L2 blocking over k (see MultiplyEngine.multiply_local in dbcsr_amd/multiply.py for the measurements): when A's average block
+// row is larger than 1.5 MB neither operand stays L2-resident; the product is then formed as one symbolic product of the whole
+// operands (C's final structure, C = beta*C_in on it) followed by passes over k ranges that accumulate in place.
+int k_passes(void* h, libsmm_acc_data_t dt, const dbcsr_amd_bcsr* a, double filter_eps, void* stream) {
+  if (filter_eps > 0.0) return 1;  // the on-the-fly filter counts the blocks of a whole A row
+  if (const char* f = getenv("DBCSR_AMD_MM_KCHUNKS")) return atoi(f) > 1 ? atoi(f) : 1;
+  if (a->nblkcols < 64 || a->nblkrows < 1) return 1;
+  Owned probe;
+  if (alloc_row_p(probe, a->nblkrows)) return 1;
+  int64_t nb = 0, nz = 0;
+  if (dbcsr_amd_bcsr_crop_count(h, dt, a, -1, -1, -1, -1, probe.m.row_p, &nb, &nz, stream)) return 1;
+  const double row_bytes = (double)nz * (double)elem_size(dt) / (double)a->nblkrows;
+  if (row_bytes <= 1.5 * 1048576.0) return 1;
+  const int n = (int)std::ceil(row_bytes / 1048576.0);
+  return n > 8 ? 8 : n;
+}
+
+int multiply_in_k_passes(void* h, libsmm_acc_data_t dt, double alpha, const dbcsr_amd_bcsr* a, const dbcsr_amd_bcsr* b, double beta,
+                         const dbcsr_amd_bcsr* c_in, int retain, int npass, Owned& out, dbcsr_amd_mm_counts* counts, void* stream) {
+  hipStream_t st = stream_of(stream);
+  if (alloc_row_p(out, c_in->nblkrows)) return -1;
+  int rc = dbcsr_amd_mm_symbolic(h, a, b, c_in, retain, out.m.row_p, counts, stream);
+  if (rc) return rc;
+  if (alloc_arrays(out, c_in->nblkrows, c_in->nblkcols, c_in->row_blk_size, c_in->col_blk_size, counts->c_nblks, counts->c_nze, elem_size(dt),
+                   false))
+    return -1;
+  if ((rc = dbcsr_amd_mm_init_c(h, dt, beta, c_in, &out.m, stream))) return rc;
+  // k ranges on block boundaries: element offsets of A's block columns
+  const int nbk = a->nblkcols;
+  int32_t* ksz = static_cast<int32_t*>(malloc(sizeof(int32_t) * (size_t)nbk));
+  if (!ksz) return -1;
+  if (hipMemcpyAsync(ksz, a->col_blk_size, sizeof(int32_t) * (size_t)nbk, hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipStreamSynchronize(st) != hipSuccess) {
+    free(ksz);
+    return -1;
+  }
+  int64_t* off = static_cast<int64_t*>(malloc(sizeof(int64_t) * ((size_t)nbk + 1)));
+  off[0] = 0;
+  for (int k = 0; k < nbk; ++k) off[k + 1] = off[k] + ksz[k];
+  free(ksz);
+  Owned tmp_row_p;
+  if (alloc_row_p(tmp_row_p, c_in->nblkrows)) {
+    free(off);
+    return -1;
+  }
+  int64_t flop = 0, nprod = 0;
+  for (int p = 0; p < npass && rc == 0; ++p) {
+    const int kb0 = (int)((int64_t)p * nbk / npass), kb1 = (int)((int64_t)(p + 1) * nbk / npass);
+    if (kb1 <= kb0) continue;
+    Owned ac, bc;
+    if ((rc = crop(h, dt, a, -1, -1, off[kb0], off[kb1] - 1, ac, nullptr, stream))) break;
+    if ((rc = crop(h, dt, b, off[kb0], off[kb1] - 1, -1, -1, bc, nullptr, stream))) break;
+    dbcsr_amd_mm_counts cnt;
+    if ((rc = dbcsr_amd_mm_symbolic(h, &ac.m, &bc.m, &out.m, 1, tmp_row_p.m.row_p, &cnt, stream))) break;
+    dbcsr_amd_bcsr acc = out.m;  // same arrays, in place
+    acc.row_p = tmp_row_p.m.row_p;
+    if ((rc = dbcsr_amd_mm_numeric(h, dt, alpha, &ac.m, &bc.m, 1.0, &out.m, &acc, stream))) break;
+    flop += cnt.flop;
+    nprod += cnt.nproducts;
+    if (hipStreamSynchronize(st) != hipSuccess) rc = -1;  // the cropped operands are freed at the end of this iteration
+  }
+  free(off);
+  counts->flop = flop;
+  counts->nproducts = nprod;
+  return rc;
+}
+
 }  // namespace
 
 extern "C" {
@@ -181,7 +248,12 @@ int dbcsr_amd_multiply(void* handle, char transa, char transb, libsmm_acc_data_t
   // the product (with the on-the-fly filter), then the final block filter
   Owned prod;
   dbcsr_amd_mm_counts counts;
-  if ((rc = symbolic_numeric(handle, datatype, alpha, A, B, beta_eff, Cin, retain_sparsity, filter_eps, prod, &counts, stream))) return rc;
+  const int npass = k_passes(handle, datatype, A, filter_eps, stream);
+  if (npass > 1) {
+    if ((rc = multiply_in_k_passes(handle, datatype, alpha, A, B, beta_eff, Cin, retain_sparsity, npass, prod, &counts, stream))) return rc;
+  } else if ((rc = symbolic_numeric(handle, datatype, alpha, A, B, beta_eff, Cin, retain_sparsity, filter_eps, prod, &counts, stream))) {
+    return rc;
+  }
   if (flop) *flop = counts.flop;
   Owned* result = &prod;
   Owned filtered;

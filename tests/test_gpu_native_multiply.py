@@ -111,3 +111,13 @@ def test_plain_c_host_example():
     r = subprocess.run([C_EXAMPLE], capture_output=True, timeout=120)
     assert r.returncode == 0, (r.stdout.decode()[-500:], r.stderr.decode()[-1500:])
     assert b"multiply_example:" in r.stdout
+
+
+@pytest.mark.parametrize("npass", [2, 5])
+def test_native_multiply_k_passes(npass, monkeypatch):
+    monkeypatch.setenv("DBCSR_AMD_MM_KCHUNKS", str(npass))
+    A, B, Cm = O.perf_case(260, 240, 300, 0.5, 0.6, 0.7, [1, 13, 1, 5], [1, 23, 1, 4], [1, 7, 1, 32, 1, 9])
+    ref, info = O.multiply("N", "N", -1.5, A, B, 0.5, Cm)
+    got, flop = native_multiply("N", "N", -1.5, A, B, 0.5, Cm)
+    same(got, ref, 1e-10)
+    assert flop == info["flop"]
