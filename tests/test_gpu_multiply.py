@@ -241,3 +241,36 @@ def test_exact_size_kernels_every_cube_with_tails(size):
     out = dev_to_bcsr(dC)
     assert np.array_equal(out.row_p, ref.row_p) and np.array_equal(out.col_i, ref.col_i) and np.array_equal(out.blk_p, ref.blk_p)
     assert float(np.max(np.abs(out.data - ref.data))) <= 1e-5 * float(np.max(np.abs(ref.data)))
+
+
+def test_two_engines_on_two_streams_concurrently():
+    """One engine handle per stream (the reference gives every OpenMP thread its own stream): two multiplies in flight at once."""
+    import threading
+    cases = [O.perf_case(460, 460, 460, 0.6, 0.6, 0.6, [1, 23], [1, 23], [1, 23]),
+             O.perf_case(390, 420, 400, 0.5, 0.5, 0.5, [1, 13, 1, 5], [1, 32, 1, 7], [1, 9, 1, 23])]
+    refs = [O.multiply("N", "N", 1.0, A, B, 1.0, Cm)[0] for A, B, Cm in cases]
+    outs, errs = [None, None], []
+
+    def work(i):
+        try:
+            st = torch.cuda.Stream()
+            E = MultiplyEngine()
+            A, B, Cm = cases[i]
+            with torch.cuda.stream(st):
+                dA, dB, dC = to_dev(A), to_dev(B), to_dev(Cm)
+                for _ in range(5):
+                    out, _ = E.multiply_local(1.0, dA, dB, 1.0, dC, stream=st)
+                st.synchronize()
+                outs[i] = dev_to_bcsr(out)
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    for got, ref in zip(outs, refs):
+        assert np.array_equal(got.row_p, ref.row_p) and np.array_equal(got.col_i, ref.col_i)
+        assert rel_err(got.data, ref.data) <= TOL
