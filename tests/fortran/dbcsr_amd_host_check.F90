@@ -8,8 +8,13 @@
 ! It runs one parameter stack of 23x23x23 products through libsmm_acc_transpose + libsmm_acc_process and
 ! compares with MATMUL.  Exit code 0 = pass.
 MODULE dbcsr_amd_c_abi
-   USE ISO_C_BINDING, ONLY: C_INT, C_SIZE_T, C_PTR, C_CHAR
+   USE ISO_C_BINDING, ONLY: C_INT, C_SIZE_T, C_PTR, C_CHAR, C_INT32_T, C_INT64_T, C_DOUBLE
    IMPLICIT NONE
+   TYPE, BIND(C) :: dbcsr_amd_bcsr   ! struct dbcsr_amd_bcsr of include/dbcsr_amd_mm.h (device pointers)
+      INTEGER(C_INT32_T) :: nblkrows, nblkcols
+      TYPE(C_PTR)        :: row_blk_size, col_blk_size, row_p, col_i, blk_p, data
+      INTEGER(C_INT64_T) :: nblks
+   END TYPE
    INTERFACE
       FUNCTION acc_init() RESULT(istat) BIND(C, name="c_dbcsr_acc_init")
          IMPORT; INTEGER(C_INT) :: istat
@@ -55,6 +60,23 @@ MODULE dbcsr_amd_c_abi
          IMPORT; TYPE(C_PTR), VALUE :: param_stack_host, param_stack_dev, a_data, b_data, c_data, stack_stream_ptr, c_stream_ptr
          INTEGER(C_INT), VALUE :: stack_size, data_type, m_max, n_max, k_max, max_kernel_dim, def_mnk; INTEGER(C_INT) :: istat
       END FUNCTION
+      FUNCTION mm_create(handle) RESULT(istat) BIND(C, name="dbcsr_amd_mm_create")
+         IMPORT; TYPE(C_PTR) :: handle; INTEGER(C_INT) :: istat
+      END FUNCTION
+      FUNCTION mm_destroy(handle) RESULT(istat) BIND(C, name="dbcsr_amd_mm_destroy")
+         IMPORT; TYPE(C_PTR), VALUE :: handle; INTEGER(C_INT) :: istat
+      END FUNCTION
+      ! the whole operator of one rank in one call (include/dbcsr_amd_mm.h)
+      FUNCTION amd_multiply(handle, transa, transb, datatype, alpha, a, b, beta, c, limits, retain_sparsity, filter_eps, &
+                            c_out, flop, stream) RESULT(istat) BIND(C, name="dbcsr_amd_multiply")
+         IMPORT; TYPE(C_PTR), VALUE :: handle, stream; CHARACTER(KIND=C_CHAR), VALUE :: transa, transb
+         INTEGER(C_INT), VALUE :: datatype, retain_sparsity; REAL(C_DOUBLE), VALUE :: alpha, beta, filter_eps
+         TYPE(dbcsr_amd_bcsr), INTENT(IN) :: a, b, c; INTEGER(C_INT64_T), DIMENSION(6), INTENT(IN) :: limits
+         TYPE(dbcsr_amd_bcsr) :: c_out; INTEGER(C_INT64_T) :: flop; INTEGER(C_INT) :: istat
+      END FUNCTION
+      FUNCTION bcsr_release(m) RESULT(istat) BIND(C, name="dbcsr_amd_bcsr_release")
+         IMPORT; TYPE(dbcsr_amd_bcsr) :: m; INTEGER(C_INT) :: istat
+      END FUNCTION
    END INTERFACE
 END MODULE dbcsr_amd_c_abi
 
@@ -68,7 +90,13 @@ PROGRAM dbcsr_amd_host_check
    INTEGER(C_INT32_T), ALLOCATABLE, TARGET :: stack(:, :), trs(:)
    TYPE(C_PTR) :: stream, da, db, dc, ds, dt
    INTEGER :: s, ia, ib, ic, ndev, istat, i
-   REAL(C_DOUBLE) :: err, r
+   REAL(C_DOUBLE) :: err, r, err2
+   INTERFACE
+      SUBROUTINE check_native_multiply(err_out)
+         USE ISO_C_BINDING, ONLY: C_DOUBLE
+         REAL(C_DOUBLE), INTENT(OUT) :: err_out
+      END SUBROUTINE
+   END INTERFACE
    REAL(C_DOUBLE) :: ablk(m, k), bblk(k, n), cblk(m, n)
 
    ndev = dbcsr_acc_get_ndevices()          ! reference: src/acc/dbcsr_acc_device.F
@@ -114,8 +142,128 @@ PROGRAM dbcsr_amd_host_check
    err = MAXVAL(ABS(c - cref)/MAX(ABS(cref), 1.0D-300))
    istat = dev_mem_dealloc(da) + dev_mem_dealloc(db) + dev_mem_dealloc(dc) + dev_mem_dealloc(ds) + dev_mem_dealloc(dt)
    istat = istat + stream_destroy(stream)
+   CALL check_native_multiply(err2)
+   WRITE (*, '(A,ES10.3)') "fortran host check: dbcsr_amd_multiply max abs err vs MATMUL = ", err2
+   IF (err2 > 1.0D-12) STOP 15
    CALL dbcsr_acc_clear_errors()
    IF (acc_finalize() /= 0) STOP 13
    WRITE (*, '(A,I0,A,ES10.3)') "fortran host check: devices=", ndev, " max rel err vs MATMUL = ", err
    IF (err > 1.0D-10 .OR. istat /= 0) STOP 14
 END PROGRAM dbcsr_amd_host_check
+
+! Second part: dbcsr_amd_multiply through its ISO_C_BINDING interface on small block-sparse matrices built in Fortran
+! (1-based Fortran arrays, 0-based BCSR index as the C-ABI wants it), checked against MATMUL on dense copies.
+SUBROUTINE check_native_multiply(err_out)
+   USE ISO_C_BINDING
+   USE dbcsr_amd_c_abi
+   IMPLICIT NONE
+   REAL(C_DOUBLE), INTENT(OUT) :: err_out
+   INTEGER, PARAMETER :: nb = 5, nfull = 21
+   INTEGER(C_INT32_T), TARGET :: sizes(nb) = (/3, 5, 2, 7, 4/)
+   INTEGER :: off(nb + 1), i
+   TYPE host_mat
+      INTEGER(C_INT32_T), ALLOCATABLE :: row_p(:), col_i(:)
+      INTEGER(C_INT64_T), ALLOCATABLE :: blk_p(:)
+      REAL(C_DOUBLE), ALLOCATABLE :: dat(:)
+      REAL(C_DOUBLE) :: dense(nfull, nfull)
+   END TYPE
+   TYPE(host_mat), TARGET :: ha, hb, hc, hr
+   TYPE(dbcsr_amd_bcsr) :: da, db, dc, dr
+   TYPE(C_PTR) :: dsizes, handle
+   INTEGER(C_INT64_T) :: limits(6), flop, nze
+   REAL(C_DOUBLE), PARAMETER :: alpha = 0.5D0, beta = -2.0D0
+   REAL(C_DOUBLE) :: expect(nfull, nfull)
+   INTEGER :: r, c, b, j
+
+   off(1) = 0
+   DO i = 1, nb
+      off(i + 1) = off(i) + sizes(i)
+   END DO
+   CALL build(ha, 1); CALL build(hb, 2); CALL build(hc, 3)
+   IF (dev_mem_alloc(dsizes, INT(4*nb, C_SIZE_T)) /= 0) STOP 20
+   IF (memcpy_h2d(C_LOC(sizes), dsizes, INT(4*nb, C_SIZE_T), C_NULL_PTR) /= 0) STOP 20
+   CALL upload(ha, da); CALL upload(hb, db); CALL upload(hc, dc)
+   handle = C_NULL_PTR
+   IF (mm_create(handle) /= 0) STOP 21
+   limits = 0
+   IF (amd_multiply(handle, 'N', 'N', 3, alpha, da, db, beta, dc, limits, 0, 0.0D0, dr, flop, C_NULL_PTR) /= 0) STOP 22
+   ! download the result
+   ALLOCATE (hr%row_p(nb + 1), hr%col_i(dr%nblks), hr%blk_p(dr%nblks))
+   IF (memcpy_d2h(dr%row_p, C_LOC(hr%row_p), INT(4*(nb + 1), C_SIZE_T), C_NULL_PTR) /= 0) STOP 23
+   IF (memcpy_d2h(dr%col_i, C_LOC(hr%col_i), INT(4*dr%nblks, C_SIZE_T), C_NULL_PTR) /= 0) STOP 23
+   IF (memcpy_d2h(dr%blk_p, C_LOC(hr%blk_p), INT(8*dr%nblks, C_SIZE_T), C_NULL_PTR) /= 0) STOP 23
+   IF (stream_sync(C_NULL_PTR) /= 0) STOP 23
+   nze = 0
+   DO r = 1, nb
+      DO b = hr%row_p(r) + 1, hr%row_p(r + 1)
+         nze = nze + sizes(r)*sizes(hr%col_i(b) + 1)
+      END DO
+   END DO
+   ALLOCATE (hr%dat(nze))
+   IF (memcpy_d2h(dr%data, C_LOC(hr%dat), INT(8*nze, C_SIZE_T), C_NULL_PTR) /= 0) STOP 23
+   IF (stream_sync(C_NULL_PTR) /= 0) STOP 23
+   hr%dense = 0.0D0
+   DO r = 1, nb
+      DO b = hr%row_p(r) + 1, hr%row_p(r + 1)
+         c = hr%col_i(b) + 1
+         DO j = 1, sizes(c)
+            DO i = 1, sizes(r)
+               hr%dense(off(r) + i, off(c) + j) = hr%dat(hr%blk_p(b) + i + sizes(r)*(j - 1))
+            END DO
+         END DO
+      END DO
+   END DO
+   expect = beta*hc%dense + alpha*MATMUL(ha%dense, hb%dense)
+   err_out = MAXVAL(ABS(hr%dense - expect))
+   IF (bcsr_release(dr) /= 0) STOP 24
+   IF (mm_destroy(handle) /= 0) STOP 24
+CONTAINS
+   SUBROUTINE build(h, which)
+      TYPE(host_mat), INTENT(INOUT) :: h
+      INTEGER, INTENT(IN) :: which
+      INTEGER :: rr, cc, nblk, ii, jj
+      INTEGER(C_INT64_T) :: pos
+      LOGICAL :: keep
+      ALLOCATE (h%row_p(nb + 1), h%col_i(nb*nb), h%blk_p(nb*nb), h%dat(nfull*nfull))
+      h%dense = 0.0D0
+      nblk = 0; pos = 0
+      DO rr = 1, nb
+         h%row_p(rr) = nblk
+         DO cc = 1, nb
+            SELECT CASE (which)
+            CASE (1); keep = MOD(rr + cc, 2) == 0
+            CASE (2); keep = MOD(rr*cc + 1, 3) /= 0
+            CASE DEFAULT; keep = rr == cc
+            END SELECT
+            IF (.NOT. keep) CYCLE
+            nblk = nblk + 1
+            h%col_i(nblk) = cc - 1
+            h%blk_p(nblk) = pos
+            DO jj = 1, sizes(cc)
+               DO ii = 1, sizes(rr)
+                  pos = pos + 1
+                  h%dat(pos) = REAL(MOD(7*ii + 3*jj + 11*rr + 5*cc + which, 17), C_DOUBLE)/8.0D0 - 1.0D0
+                  h%dense(off(rr) + ii, off(cc) + jj) = h%dat(pos)
+               END DO
+            END DO
+         END DO
+      END DO
+      h%row_p(nb + 1) = nblk
+   END SUBROUTINE
+   SUBROUTINE upload(h, d)
+      TYPE(host_mat), INTENT(IN), TARGET :: h
+      TYPE(dbcsr_amd_bcsr), INTENT(OUT) :: d
+      INTEGER :: nblk
+      nblk = h%row_p(nb + 1)
+      d%nblkrows = nb; d%nblkcols = nb; d%nblks = nblk
+      d%row_blk_size = dsizes; d%col_blk_size = dsizes
+      IF (dev_mem_alloc(d%row_p, INT(4*(nb + 1), C_SIZE_T)) /= 0) STOP 25
+      IF (dev_mem_alloc(d%col_i, INT(4*nb*nb, C_SIZE_T)) /= 0) STOP 25
+      IF (dev_mem_alloc(d%blk_p, INT(8*nb*nb, C_SIZE_T)) /= 0) STOP 25
+      IF (dev_mem_alloc(d%data, INT(8*nfull*nfull, C_SIZE_T)) /= 0) STOP 25
+      IF (memcpy_h2d(C_LOC(h%row_p), d%row_p, INT(4*(nb + 1), C_SIZE_T), C_NULL_PTR) /= 0) STOP 26
+      IF (memcpy_h2d(C_LOC(h%col_i), d%col_i, INT(4*nb*nb, C_SIZE_T), C_NULL_PTR) /= 0) STOP 26
+      IF (memcpy_h2d(C_LOC(h%blk_p), d%blk_p, INT(8*nb*nb, C_SIZE_T), C_NULL_PTR) /= 0) STOP 26
+      IF (memcpy_h2d(C_LOC(h%dat), d%data, INT(8*nfull*nfull, C_SIZE_T), C_NULL_PTR) /= 0) STOP 26
+   END SUBROUTINE
+END SUBROUTINE check_native_multiply
