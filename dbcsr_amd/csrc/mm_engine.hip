@@ -1935,6 +1935,10 @@ __global__ void __launch_bounds__(256) scale_window(const int* __restrict__ row_
   }
 }
 
+}  // namespace dbcsr_amd
+#include "mm_dma.h"
+namespace dbcsr_amd {
+
 // ----------------------------------------------------------------------------
 // host side
 // ----------------------------------------------------------------------------
@@ -1943,6 +1947,8 @@ __global__ void __launch_bounds__(256) scale_window(const int* __restrict__ row_
 // up to 8 are left to it).
 #define DBCSR_AMD_HOT_SIZES(X) \
   X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32)
+
+#define DBCSR_AMD_DMA_SIZES(X) X(13) X(16) X(23) X(32)
 
 static bool launch_hot_f64(int m, int n, int k, dim3 grid, size_t lds_bytes, hipStream_t st, const Desc* descs, int64_t nblk,
                            const Entry* entries, const double* a_data, const double* b_data, double* c_out, const double* c_in,
@@ -1956,6 +1962,34 @@ static bool launch_hot_f64(int m, int n, int k, dim3 grid, size_t lds_bytes, hip
     return true;
     DBCSR_AMD_HOT_SIZES(DBCSR_HOT_CASE)
 #undef DBCSR_HOT_CASE
+    default: return false;
+  }
+}
+
+// LDS-DMA variant of the exact-size kernel (mm_dma.h): S ring slots per wave, one wave per workgroup
+template <int S_>
+static bool launch_dma_f64_s(int m, int n, int k, unsigned npos, hipStream_t st, const Desc* descs, int64_t nblk, const Entry* entries,
+                             const double* a_data, const double* b_data, double* c_out, const double* c_in, double alpha, double beta,
+                             int skip_empty, const int* order) {
+  if (m != n || m != k) return false;
+  switch (m) {
+#define DBCSR_DMA_CASE(S__)                                                                                                   \
+  case S__:                                                                                                                   \
+    hipLaunchKernelGGL((mm_numeric_f64_dma<S__, S__, S__, S_>), dim3(npos), dim3(64), (DmaRing<S__, S__, S__, S_>::BYTES), st, descs, \
+                       nblk, entries, a_data, b_data, c_out, c_in, alpha, beta, skip_empty, order);                           \
+    return true;
+    DBCSR_AMD_DMA_SIZES(DBCSR_DMA_CASE)
+#undef DBCSR_DMA_CASE
+    default: return false;
+  }
+}
+static bool launch_dma_f64(int S, int m, int n, int k, unsigned npos, hipStream_t st, const Desc* descs, int64_t nblk,
+                           const Entry* entries, const double* a_data, const double* b_data, double* c_out, const double* c_in,
+                           double alpha, double beta, int skip_empty, const int* order) {
+  switch (S) {
+    case 2: return launch_dma_f64_s<2>(m, n, k, npos, st, descs, nblk, entries, a_data, b_data, c_out, c_in, alpha, beta, skip_empty, order);
+    case 3: return launch_dma_f64_s<3>(m, n, k, npos, st, descs, nblk, entries, a_data, b_data, c_out, c_in, alpha, beta, skip_empty, order);
+    case 4: return launch_dma_f64_s<4>(m, n, k, npos, st, descs, nblk, entries, a_data, b_data, c_out, c_in, alpha, beta, skip_empty, order);
     default: return false;
   }
 }
@@ -2010,6 +2044,7 @@ struct Engine {
   bool grid_kernels = false, force_word_kernels = false;  // DBCSR_AMD_MM_SYMBOLIC=word forces the per-word symbolic kernels
   int dbg = 0;      // DBCSR_AMD_MM_DBG: ablation switches of the LDS kernel (profiling only)
   int use_pipe = -1, pipe_g = 8;  // multi-block pipelined kernel: -1 automatic (short product lists only), DBCSR_AMD_MM_KERNEL=pipe|lds1 forces; DBCSR_AMD_MM_PIPE_G = blocks per wave
+  int dma_stages = 0;  // DBCSR_AMD_MM_KERNEL=dma2|dma3|dma4: LDS-DMA exact-size kernel with that many ring slots (0: off)
   int use_lds = 1;  // DBCSR_AMD_MM_KERNEL=direct selects the v1 kernel (A/B experiments)
 };
 
@@ -2048,6 +2083,7 @@ int dbcsr_amd_mm_create(void** handle) {
   if (const char* k = getenv("DBCSR_AMD_MM_KERNEL")) {
     E->use_lds = strcmp(k, "direct") != 0;
     E->use_pipe = strcmp(k, "pipe") == 0 ? 1 : (strcmp(k, "lds1") == 0 ? 0 : -1);
+    if (strncmp(k, "dma", 3) == 0 && k[3] >= '2' && k[3] <= '4') E->dma_stages = k[3] - '0';
   }
   if (const char* k = getenv("DBCSR_AMD_MM_PIPE_G")) E->pipe_g = std::max(1, atoi(k));
   if (const char* k = getenv("DBCSR_AMD_MM_DBG")) E->dbg = atoi(k);
@@ -2319,7 +2355,12 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
                      static_cast<const double*>(c_in->data), alpha, beta, lds_a, lds_wave, E->dbg | (skip_empty ? 32 : 0), E->order.p)
       // measured: the pipelined kernel wins when C blocks have few products (config 3: 3.7 per block, 10.4 vs 11.8 ms) and
       // loses when they have many (config 2: 14.4 per block, 32 vs 22 ms)
-      if (E->use_hot && E->use_pipe != 1 && E->hot_m > 0 &&
+      if (E->use_hot && E->use_pipe != 1 && E->hot_m > 0 && E->dma_stages > 0 &&
+          launch_dma_f64(E->dma_stages, E->hot_m, E->hot_n, E->hot_k, (unsigned)(8 * E->order_len), st, E->descs.p, nblk, E->entries.p,
+                         static_cast<const double*>(a->data), static_cast<const double*>(b->data), static_cast<double*>(c_out->data),
+                         static_cast<const double*>(c_in->data), alpha, beta, skip_empty, E->order.p)) {
+        // LDS-DMA exact-size kernel launched
+      } else if (E->use_hot && E->use_pipe != 1 && E->hot_m > 0 &&
           launch_hot_f64(E->hot_m, E->hot_n, E->hot_k, dim3(nwg_o), lds_bytes, st, E->descs.p, nblk, E->entries.p,
                          static_cast<const double*>(a->data), static_cast<const double*>(b->data), static_cast<double*>(c_out->data),
                          static_cast<const double*>(c_in->data), alpha, beta, lds_a, lds_wave, E->dbg | (skip_empty ? 32 : 0), E->order.p)) {
