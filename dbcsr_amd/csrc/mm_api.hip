@@ -92,6 +92,37 @@ int transposed(void* h, libsmm_acc_data_t dt, const dbcsr_amd_bcsr* src, Owned& 
   return dbcsr_amd_bcsr_transpose(h, dt, src, &dst.m, stream);
 }
 
+
+// sum of the block sizes of one dimension (device array of n int32): dbcsr_nfullrows_total / dbcsr_nfullcols_total
+int full_extent(const int32_t* sizes, int n, int64_t* out, hipStream_t st) {
+  *out = 0;
+  if (n <= 0) return 0;
+  int32_t* h = static_cast<int32_t*>(malloc(sizeof(int32_t) * (size_t)n));
+  if (!h) return -1;
+  if (hipMemcpyAsync(h, sizes, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+    free(h);
+    return -1;
+  }
+  int64_t t = 0;
+  for (int i = 0; i < n; ++i) t += h[i];
+  free(h);
+  *out = t;
+  return 0;
+}
+
+// C without any block (what dbcsr_multiply_generic makes of the product matrix when keep_product_data is false,
+// src/mm/dbcsr_mm.F:865-870): only row_p exists, all zeros
+int empty_like(const dbcsr_amd_bcsr* c, Owned& e, hipStream_t st) {
+  if (alloc_row_p(e, c->nblkrows)) return -1;
+  if (hipMemsetAsync(e.m.row_p, 0, sizeof(int32_t) * ((size_t)c->nblkrows + 1), st) != hipSuccess) return -1;
+  e.m.nblkrows = c->nblkrows;
+  e.m.nblkcols = c->nblkcols;
+  e.m.row_blk_size = c->row_blk_size;
+  e.m.col_blk_size = c->col_blk_size;
+  e.m.nblks = 0;
+  return 0;
+}
+
 int symbolic_numeric(void* h, libsmm_acc_data_t dt, double alpha, const dbcsr_amd_bcsr* a, const dbcsr_amd_bcsr* b, double beta,
                      const dbcsr_amd_bcsr* c_in, int retain, double eps, Owned& out, dbcsr_amd_mm_counts* counts, void* stream) {
   if (alloc_row_p(out, c_in->nblkrows)) return -1;
@@ -217,27 +248,55 @@ int dbcsr_amd_multiply(void* handle, char transa, char transb, libsmm_acc_data_t
     fprintf(stderr, "dbcsr_amd_multiply: incompatible block dimensions\n");
     return -1;
   }
-  // submatrix limits: 1-based inclusive full-matrix indices, 0 = not given
-  Owned ca, cb, cc;
+  // submatrix limits: 1-based inclusive full-matrix indices, 0 = not given.  Validation and the "optimise the defaults away"
+  // step are the reference's (src/mm/dbcsr_mm.F:631-692): an invalid limit is an error there (DBCSR_ABORT), never clamped.
+  Owned ca, cb, cc, cempty;
   const dbcsr_amd_bcsr* Cin = matrix_c;
   double beta_eff = beta;
   bool limited = false;
   if (limits)
     for (int i = 0; i < 6; ++i) limited = limited || limits[i] != 0;
+  int64_t f_row = 0, l_row = 0, f_col = 0, l_col = 0, f_k = 0, l_k = 0;
+  bool window_keeps = false;  // a row / column window that ends inside C: blocks outside it must survive
   if (limited) {
-    for (int i = 0; i < 6; i += 2)
-      if (limits[i] < 0 || limits[i + 1] < 0 || (limits[i + 1] != 0 && limits[i] > limits[i + 1])) {
-        fprintf(stderr, "dbcsr_amd_multiply: invalid limits\n");
-        return -1;
-      }
-    const int64_t r0 = limits[0] ? limits[0] - 1 : -1, r1 = limits[1] ? limits[1] - 1 : -1;
-    const int64_t c0 = limits[2] ? limits[2] - 1 : -1, c1 = limits[3] ? limits[3] - 1 : -1;
-    const int64_t k0 = limits[4] ? limits[4] - 1 : -1, k1 = limits[5] ? limits[5] - 1 : -1;
+    int64_t nr = 0, nc = 0, nk = 0;
+    if (full_extent(matrix_c->row_blk_size, matrix_c->nblkrows, &nr, st) || full_extent(matrix_c->col_blk_size, matrix_c->nblkcols, &nc, st) ||
+        full_extent(A->col_blk_size, A->nblkcols, &nk, st))
+      return -1;
+    f_row = limits[0]; l_row = limits[1]; f_col = limits[2]; l_col = limits[3]; f_k = limits[4]; l_k = limits[5];
+    if (f_row < 0 || f_row > nr || l_row < 0 || l_row > nr || f_col < 0 || f_col > nc || l_col < 0 || l_col > nc || f_k < 0 || f_k > nk || l_k < 0 ||
+        l_k > nk || (l_row && f_row > l_row) || (l_col && f_col > l_col) || (l_k && f_k > l_k)) {
+      fprintf(stderr, "dbcsr_amd_multiply: invalid limits (rows %lld..%lld of %lld, columns %lld..%lld of %lld, k %lld..%lld of %lld)\n",
+              (long long)f_row, (long long)l_row, (long long)nr, (long long)f_col, (long long)l_col, (long long)nc, (long long)f_k, (long long)l_k,
+              (long long)nk);
+      return -1;
+    }
+    if (f_row == 1) f_row = 0;
+    if (l_row == nr) l_row = 0;
+    if (f_col == 1) f_col = 0;
+    if (l_col == nc) l_col = 0;
+    if (f_k == 1) f_k = 0;
+    if (l_k == nk) l_k = 0;
+    window_keeps = (l_col > 0 && l_col < nc) || (l_row > 0 && l_row < nr);
+    limited = f_row || l_row || f_col || l_col || f_k || l_k;
+  }
+  // Product data is retained when retain_sparsity, beta != 0, or the row / column window ends inside C (dbcsr_mm.F:695-704);
+  // otherwise the old C is discarded before the multiplication: its blocks disappear and their values are never read.
+  const bool keep_product_data = retain_sparsity || beta != 0.0 || window_keeps;
+  if (!keep_product_data) {
+    if (empty_like(matrix_c, cempty, st)) return -1;
+    Cin = &cempty.m;
+    beta_eff = 1.0;
+  }
+  if (limited) {
+    const int64_t r0 = f_row ? f_row - 1 : -1, r1 = l_row ? l_row - 1 : -1;
+    const int64_t c0 = f_col ? f_col - 1 : -1, c1 = l_col ? l_col - 1 : -1;
+    const int64_t k0 = f_k ? f_k - 1 : -1, k1 = l_k ? l_k - 1 : -1;
     if ((rc = crop(handle, datatype, A, r0, r1, k0, k1, ca, nullptr, stream))) return rc;
     if ((rc = crop(handle, datatype, B, k0, k1, c0, c1, cb, nullptr, stream))) return rc;
     A = &ca.m;
     B = &cb.m;
-    if (beta != 1.0) {  // dbcsr_scale(matrix_c, beta, limits): on a copy, the caller's C stays as it is
+    if (beta != 1.0 && keep_product_data) {  // dbcsr_scale(matrix_c, beta, limits): on a copy, the caller's C stays as it is
       int64_t nz = 0;
       if ((rc = crop(handle, datatype, matrix_c, -1, -1, -1, -1, cc, &nz, stream))) return rc;
       if ((rc = dbcsr_amd_bcsr_scale_window(handle, datatype, &cc.m, beta, r0, r1, c0, c1, stream))) return rc;

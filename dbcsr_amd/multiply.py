@@ -160,6 +160,11 @@ class MultiplyEngine:
             raise RuntimeError("dbcsr_amd_bcsr_filter_apply failed (%d)" % rc)
         return out
 
+    @staticmethod
+    def empty_like(M):
+        """C without any block, same block sizes (the product matrix after the reference has discarded it, dbcsr_mm.F:865-870)."""
+        return DbcsrMatrix.empty_like_pattern(M.row_blk_size, M.col_blk_size, M.dtype, device=M.data.device, name=M.name)
+
     def cropped(self, M, row_bounds=None, col_bounds=None, stream=None):
         """dbcsr_crop_matrix (src/ops/dbcsr_operations.F:1652-1833): copy of M restricted to the window given as 0-based
         inclusive element bounds (None = no bound); boundary blocks keep their size, their outside part is zero."""
@@ -283,24 +288,40 @@ def dbcsr_multiply(transa, transb, alpha, matrix_a, matrix_b, beta, matrix_c, fi
     if A.nblkcols != B.nblkrows or A.nblkrows != matrix_c.nblkrows or B.nblkcols != matrix_c.nblkcols:
         raise ValueError("dbcsr_multiply: incompatible block dimensions")
     limits = (first_row, last_row, first_column, last_column, first_k, last_k)
+    # Submatrix selection (src/mm/dbcsr_mm.F:625-692, 1-based inclusive full-matrix indices, None/0 = not given): invalid limits
+    # are an error (DBCSR_ABORT in the reference), the default values are "optimised away" exactly as there.
+    fr = lr = fc = lc = fk = lk = 0
+    window_keeps = False
     if any(v is not None and v != 0 for v in limits):
-        # Submatrix selection (src/mm/dbcsr_mm.F:631-709, 1-based inclusive full-matrix indices, None/0 = not given): the left
-        # matrix is cropped to (rows, k), the right one to (k, columns) (make_m2s, dbcsr_mm_cannon.F:194-214), beta acts on the
-        # window of C only (dbcsr_scale with limits) and everything outside the window stays as it is.
         nr, nc, nk = int(A.row_blk_size.sum()), int(B.col_blk_size.sum()), int(A.col_blk_size.sum())
         fr, lr, fc, lc, fk, lk = [int(v or 0) for v in limits]
-        if fr < 0 or fr > nr or lr > nr or (lr and fr > lr):
+        if fr < 0 or fr > nr or lr < 0 or lr > nr or (lr and fr > lr):
             raise ValueError("dbcsr_multiply: invalid row limits")
-        if fc < 0 or fc > nc or lc > nc or (lc and fc > lc):
+        if fc < 0 or fc > nc or lc < 0 or lc > nc or (lc and fc > lc):
             raise ValueError("dbcsr_multiply: invalid column limits")
-        if fk < 0 or fk > nk or lk > nk or (lk and fk > lk):
+        if fk < 0 or fk > nk or lk < 0 or lk > nk or (lk and fk > lk):
             raise ValueError("dbcsr_multiply: invalid k limits")
+        fr, lr = (0 if fr == 1 else fr), (0 if lr == nr else lr)
+        fc, lc = (0 if fc == 1 else fc), (0 if lc == nc else lc)
+        fk, lk = (0 if fk == 1 else fk), (0 if lk == nk else lk)
+        window_keeps = (0 < lc < nc) or (0 < lr < nr)
+    limited = any((fr, lr, fc, lc, fk, lk))
+    # Product data is retained when retain_sparsity, beta != 0, or a row / column window ends inside C (dbcsr_mm.F:695-704);
+    # otherwise the reference empties C before the multiplication (:865-870): old blocks vanish, their values are never read.
+    keep_product_data = bool(retain_sparsity) or beta != 0.0 or window_keeps
+    matrix_in, beta_eff = matrix_c, beta
+    if not keep_product_data:
+        matrix_in, beta_eff = E.empty_like(matrix_c), 1.0
+    if limited:
+        # the left matrix is cropped to (rows, k), the right one to (k, columns) (make_m2s, dbcsr_mm_cannon.F:194-214), beta acts
+        # on the window of C only (dbcsr_scale with limits) and everything outside the window stays as it is
+        nr, nc, nk = int(A.row_blk_size.sum()), int(B.col_blk_size.sum()), int(A.col_blk_size.sum())
         rb, cb, kb = ((fr or 1) - 1, (lr or nr) - 1), ((fc or 1) - 1, (lc or nc) - 1), ((fk or 1) - 1, (lk or nk) - 1)
         A, B = E.cropped(A, rb, kb), E.cropped(B, kb, cb)
-        matrix_in = E.scaled_window(matrix_c, beta, rb, cb) if beta != 1.0 else matrix_c
-        out, counts = E.multiply_local(alpha, A, B, 1.0, matrix_in, retain_sparsity=retain_sparsity, filter_eps=filter_eps or 0.0)
-    else:
-        out, counts = E.multiply_local(alpha, A, B, beta, matrix_c, retain_sparsity=retain_sparsity, filter_eps=filter_eps or 0.0)
+        if keep_product_data and beta != 1.0:
+            matrix_in = E.scaled_window(matrix_c, beta, rb, cb)
+        beta_eff = 1.0
+    out, counts = E.multiply_local(alpha, A, B, beta_eff, matrix_in, retain_sparsity=retain_sparsity, filter_eps=filter_eps or 0.0)
     matrix_c.row_p, matrix_c.col_i, matrix_c.blk_p, matrix_c.data = out.row_p, out.col_i, out.blk_p, out.data
     if flop is not None:
         flop[:] = [counts.flop]

@@ -564,6 +564,16 @@ orc_result* orc_multiply_d(char transa, char transb, double alpha,
       }
   }
 
+  /* keep_product_data (dbcsr_mm.F:695-704): the old C is kept when retain_sparsity, beta != 0, or a row / column window
+   * ends inside C; otherwise the reference empties the product matrix before multiplying (dbcsr_mm.F:865-870) -- its
+   * blocks disappear and their values are never read. */
+  const int keep_product_data = retain_sparsity || beta != 0.0 || (lim[1] >= 0 && lim[1] < c_nbr - 1) || (lim[3] >= 0 && lim[3] < c_nbc - 1);
+  int* zero_row_p = NULL;
+  if (!keep_product_data) {
+    zero_row_p = (int*)calloc((size_t)c_nbr + 1, sizeof(int));
+    c_row_p = zero_row_p;
+  }
+
   orc_result* R = (orc_result*)calloc(1, sizeof(orc_result));
   R->nbr = c_nbr;
   R->nbc = c_nbc;
@@ -731,6 +741,7 @@ orc_result* orc_multiply_d(char transa, char transb, double alpha,
   free(keep);
   free(pre_start);
   free(lut);
+  free(zero_row_p);
   free(w_row);
   free(w_col);
   free(w_off);

@@ -343,9 +343,18 @@ def multiply_limits(transa, transb, alpha, A, B, beta, Cm, limits, retain_sparsi
     right = transposed(B) if transb.upper() != "N" else B
     nr, nc, nk = int(left.row_sizes.sum()), int(right.col_sizes.sum()), int(left.col_sizes.sum())
     fr, lr, fc, lc, fk, lk = [int(x) for x in limits]
+    # "optimise the default values away" and keep_product_data exactly as src/mm/dbcsr_mm.F:669-704
+    fr, lr = (0 if fr == 1 else fr), (0 if lr == nr else lr)
+    fc, lc = (0 if fc == 1 else fc), (0 if lc == nc else lc)
+    fk, lk = (0 if fk == 1 else fk), (0 if lk == nk else lk)
+    keep = bool(retain_sparsity) or beta != 0.0 or (0 < lc < nc) or (0 < lr < nr)
     rb = ((fr or 1) - 1, (lr or nr) - 1)
     cb = ((fc or 1) - 1, (lc or nc) - 1)
     kb = ((fk or 1) - 1, (lk or nk) - 1)
-    Cs = scale_window(Cm, beta, rb, cb)
+    if not keep:  # the product matrix is emptied before the multiplication (dbcsr_mm.F:865-870)
+        Cs = Bcsr(Cm.row_sizes, Cm.col_sizes, np.zeros(Cm.nbr + 1, np.int32), np.zeros(0, np.int32), np.zeros(0, np.int64),
+                  np.zeros(0, Cm.data.dtype))
+    else:
+        Cs = scale_window(Cm, beta, rb, cb) if beta != 1.0 else Cm
     return multiply("N", "N", alpha, crop(left, rb, kb), crop(right, kb, cb), 1.0, Cs, retain_sparsity=retain_sparsity,
                     filter_eps=filter_eps)

@@ -1,0 +1,80 @@
+"""Row f4 of SURVEY.md section 8: the UNCHANGED reference Fortran host (DBCSR library + its own drivers, expanded with
+tools/fypp_lite.py and compiled with amdflang -D__DBCSR_ACC by tools/build_dbcsr_host.py) linked against this
+repository's libdbcsr_acc_amd.so, run on the GPU through the true dbcsr_multiply:
+  * the reference's performance driver on its own golden .perf inputs (it checks its checksums itself),
+  * the reference's unit tests dbcsr_unittest1 / dbcsr_unittest3 (GPU block-size mixes),
+  * this repository's dump driver on the cases of tests/golden/ref_dump.json: what the acc back end produces under the
+    real host equals what the reference's BLAS path produced (index identical, values 1e-10).
+The binaries are built in the build container (oracle/_ref/host_acc, git-ignored, they travel with the snapshot)."""
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests import ref_dump_util as R
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "oracle", "_ref", "host_acc")
+GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "perf_golden.json")))
+ENV = dict(os.environ, MKL_THREADING_LAYER="SEQUENTIAL", OMP_NUM_THREADS="4")
+
+needs_host = pytest.mark.skipif(not os.path.exists(os.path.join(HOST, "dbcsr_perf")),
+                                reason="reference Fortran host not built (tools/build_dbcsr_host.py acc)")
+
+
+def write_perf(c, path):
+    d = lambda x: ("%.17g" % x).replace("e", "d") if "e" in ("%.17g" % x) else "%.17gd0" % x
+    toks = [c["npcols"], c["use_rma"], c["operation"], c["M"], c["N"], c["K"], d(c["sparsity_a"]), d(c["sparsity_b"]), d(c["sparsity_c"]),
+            c["transa"], c["transb"], c["symm_a"], c["symm_b"], c["symm_c"], c["data_type"], d(c["alpha"][0]), d(c["alpha"][1]),
+            d(c["beta"][0]), d(c["beta"][1]), *c["limits"], c["retain_sparsity"], min(int(c["nrep"]), 2),
+            len(c["bs_m"]) // 2, len(c["bs_n"]) // 2, len(c["bs_k"]) // 2, *c["bs_m"], *c["bs_n"], *c["bs_k"],
+            c["check"], "%.3E" % c["threshold"], "%.15E" % c["checksum"], "%.15E" % c["checksum_pos"]]
+    with open(path, "w") as f:
+        f.write("\n".join(str(t) for t in toks) + "\n")
+
+
+@needs_host
+@pytest.mark.parametrize("name", sorted(k for k, v in GOLD.items() if v["check"] == "T" and v["data_type"] == 3))
+def test_reference_perf_driver_through_acc_backend(name, tmp_path):
+    c = GOLD[name]
+    write_perf(c, tmp_path / "case.perf")
+    r = subprocess.run([os.path.join(HOST, "dbcsr_perf"), str(tmp_path / "case.perf")], cwd=tmp_path, env=ENV, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    m = re.search(r"checksum\(C_out\)\s*=\s*([0-9.E+-]+)", r.stdout)
+    mp = re.search(r"checksum\(C_out\) POS\s*=\s*([0-9.E+-]+)", r.stdout)
+    assert m and mp, r.stdout[-3000:]
+    assert abs(float(m.group(1)) / c["checksum"] - 1.0) <= c["threshold"]
+    assert abs(float(mp.group(1)) / c["checksum_pos"] - 1.0) <= c["threshold"]
+    # the stacks really ran on the accelerator back end (DBCSR's own statistics: share of flops by driver)
+    acc = re.search(r"flops total\s+\S+\s+([0-9.]+)%\s+([0-9.]+)%\s+([0-9.]+)%", r.stdout)
+    assert acc, r.stdout[-3000:]
+    if max(c["bs_m"][1::2] + c["bs_n"][1::2] + c["bs_k"][1::2]) <= 80:
+        assert float(acc.group(3)) > 50.0, "less than half of the flops went through libsmm_acc_process:\n" + r.stdout[-3000:]
+
+
+@needs_host
+@pytest.mark.parametrize("prog", ["dbcsr_unittest1", "dbcsr_unittest3"])
+def test_reference_unittests_through_acc_backend(prog, tmp_path):
+    r = subprocess.run([os.path.join(HOST, prog)], cwd=tmp_path, env=ENV, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "ERROR" not in r.stdout.upper().replace("ERROR_TOLERANCE", "") or "PASSED" in r.stdout.upper(), r.stdout[-3000:]
+
+
+@needs_host
+@pytest.mark.parametrize("name", R.names(lambda p: p["values"]))
+def test_dump_driver_through_acc_backend(name):
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_ref_fixtures as F
+    ref = R.RefResult(name)
+    got = F.run_case(ref.params, exe=os.path.join(HOST, "dbcsr_ref_dump"), env={"OMP_NUM_THREADS": "4"})
+    assert got["nblks"] == ref.nblks and got["flop"] == ref.flop
+    assert np.array_equal(np.asarray(got["row"]) - 1, ref.rows) and np.array_equal(np.asarray(got["col"], np.int32) - 1, ref.col_i)
+    import base64
+    data = np.frombuffer(base64.b64decode(got["values_b64"]), "<f8") if ref.nblks else np.zeros(0)
+    scale = max(np.max(np.abs(ref.data)), 1e-300) if ref.nblks else 1.0
+    assert data.size == ref.data.size and np.max(np.abs(data - ref.data), initial=0.0) <= 1e-10 * scale
