@@ -28,7 +28,10 @@ needs_host = pytest.mark.skipif(not os.path.exists(os.path.join(HOST, "dbcsr_per
 
 
 def write_perf(c, path):
-    d = lambda x: ("%.17g" % x).replace("e", "d") if "e" in ("%.17g" % x) else "%.17gd0" % x
+    def d(x):  # the reference's ator() wants a decimal point: 1.0d0, not 1d0
+        m, _, e = ("%.17e" % x).partition("e")
+        m = m.rstrip("0")
+        return "%s%sd%d" % (m, "0" if m.endswith(".") else "", int(e))
     toks = [c["npcols"], c["use_rma"], c["operation"], c["M"], c["N"], c["K"], d(c["sparsity_a"]), d(c["sparsity_b"]), d(c["sparsity_c"]),
             c["transa"], c["transb"], c["symm_a"], c["symm_b"], c["symm_c"], c["data_type"], d(c["alpha"][0]), d(c["alpha"][1]),
             d(c["beta"][0]), d(c["beta"][1]), *c["limits"], c["retain_sparsity"], min(int(c["nrep"]), 2),
