@@ -2337,6 +2337,7 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
       // four C blocks per wave, one per MFMA sub-block; order[] is padded to a multiple of 4 per XCD stream, so a wave's
       // four positions never straddle two streams only if the stream length is a multiple of 16: the tail positions hold -1
       const unsigned nwg_t = (unsigned)((8 * E->order_len + 15) / 16);
+      snprintf(E->last_kernel, sizeof E->last_kernel, "mm_numeric_f64_tiny");
       hipLaunchKernelGGL(mm_numeric_f64_tiny, dim3(nwg_t), dim3(256), 0, st, E->descs.p, nblk, E->entries.p,
                          static_cast<const double*>(a->data), static_cast<const double*>(b->data), static_cast<double*>(c_out->data),
                          static_cast<const double*>(c_in->data), alpha, beta, skip_empty, E->order.p);
@@ -2360,12 +2361,13 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
           launch_dma_f64(E->dma_stages, E->hot_m, E->hot_n, E->hot_k, (unsigned)(8 * E->order_len), st, E->descs.p, nblk, E->entries.p,
                          static_cast<const double*>(a->data), static_cast<const double*>(b->data), static_cast<double*>(c_out->data),
                          static_cast<const double*>(c_in->data), alpha, beta, skip_empty, E->order.p)) {
-        // LDS-DMA exact-size kernel launched
+        snprintf(E->last_kernel, sizeof E->last_kernel, "mm_numeric_f64_dma<%d,%d,%d,%d>", E->hot_m, E->hot_n, E->hot_k, E->dma_stages);
       } else if (E->use_hot && E->use_pipe != 1 && E->hot_m > 0 &&
           launch_hot_f64(E->hot_m, E->hot_n, E->hot_k, dim3(nwg_o), lds_bytes, st, E->descs.p, nblk, E->entries.p,
                          static_cast<const double*>(a->data), static_cast<const double*>(b->data), static_cast<double*>(c_out->data),
                          static_cast<const double*>(c_in->data), alpha, beta, lds_a, lds_wave, E->dbg | (skip_empty ? 32 : 0), E->order.p)) {
         // launched: C blocks of the dominant size take the exact-size path, the others the generic one
+        snprintf(E->last_kernel, sizeof E->last_kernel, "mm_numeric_f64_hot<%d,%d,%d>", E->hot_m, E->hot_n, E->hot_k);
       } else {
       const bool pipe = E->use_pipe == 1 || (E->use_pipe < 0 && E->nproducts < 6 * nblk && E->nproducts > nblk + nblk / 2);
       if (pipe) {
@@ -2376,6 +2378,7 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
   hipLaunchKernelGGL(mm_numeric_f64_pipe<T_>, dim3(nwg_p), dim3(256), lds_bytes, st, E->descs.p, nblk, E->entries.p,             \
                      static_cast<const double*>(a->data), static_cast<const double*>(b->data), static_cast<double*>(c_out->data), \
                      static_cast<const double*>(c_in->data), alpha, beta, lds_a, lds_wave, skip_empty, E->order.p, npos, G)
+        snprintf(E->last_kernel, sizeof E->last_kernel, "mm_numeric_f64_pipe<%d>", maxt > 4 ? 4 : maxt);
         switch (maxt) {
           case 1: DBCSR_LAUNCH_P(1); break;
           case 2: DBCSR_LAUNCH_P(2); break;
@@ -2384,6 +2387,7 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
         }
 #undef DBCSR_LAUNCH_P
       } else {
+        snprintf(E->last_kernel, sizeof E->last_kernel, "mm_numeric_f64_lds<%d>", maxt > 4 ? 4 : maxt);
         switch (maxt) {
           case 1: DBCSR_LAUNCH(1); break;
           case 2: DBCSR_LAUNCH(2); break;
@@ -2394,6 +2398,7 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
       }
 #undef DBCSR_LAUNCH
     } else {
+      snprintf(E->last_kernel, sizeof E->last_kernel, "mm_numeric_f64");
       hipLaunchKernelGGL(mm_numeric_f64, dim3(nwg), dim3(256), 0, st, E->descs.p, nblk, E->entries.p,
                          static_cast<const double*>(a->data), static_cast<const double*>(b->data),
                          static_cast<double*>(c_out->data), static_cast<const double*>(c_in->data), alpha, beta, skip_empty);
@@ -2406,15 +2411,19 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
           launch_hot_f32(E->hot_m, E->hot_n, E->hot_k, dim3(nwg_o), st, E->descs.p, nblk, E->entries.p, static_cast<const float*>(a->data),
                          static_cast<const float*>(b->data), static_cast<float*>(c_out->data), static_cast<const float*>(c_in->data),
                          (float)alpha, (float)beta, skip_empty, E->order.p)) {
-        // exact-size kernel launched
-      } else
+        snprintf(E->last_kernel, sizeof E->last_kernel, "mm_numeric_f32_hot<%d,%d,%d>", E->hot_m, E->hot_n, E->hot_k);
+      } else {
+      snprintf(E->last_kernel, sizeof E->last_kernel, "mm_numeric_f32_lds");
       hipLaunchKernelGGL(mm_numeric_f32_lds, dim3(nwg_o), dim3(256), 0, st, E->descs.p, nblk, E->entries.p,
                          static_cast<const float*>(a->data), static_cast<const float*>(b->data), static_cast<float*>(c_out->data),
                          static_cast<const float*>(c_in->data), (float)alpha, (float)beta, skip_empty, E->order.p);
-    } else
+      }
+    } else {
+        snprintf(E->last_kernel, sizeof E->last_kernel, "mm_numeric_f32");
         hipLaunchKernelGGL(mm_numeric_f32, dim3(nwg), dim3(256), 0, st, E->descs.p, nblk, E->entries.p,
                        static_cast<const float*>(a->data), static_cast<const float*>(b->data), static_cast<float*>(c_out->data),
                        static_cast<const float*>(c_in->data), (float)alpha, (float)beta, skip_empty);
+    }
   }
   ACC_CHECK(hipEventRecord(E->ev[2], st));
   E->timed = true;
@@ -2681,6 +2690,11 @@ int dbcsr_amd_bcsr_transpose(void* handle, libsmm_acc_data_t datatype, const dbc
 
 const char* dbcsr_amd_mm_kernel_name(libsmm_acc_data_t datatype) {
   return datatype == dbcsr_type_real_4 ? "mm_numeric_f32" : "mm_numeric_f64";
+}
+
+const char* dbcsr_amd_mm_last_kernel(void* handle) {
+  Engine* E = static_cast<Engine*>(handle);
+  return E ? E->last_kernel : "";
 }
 
 }  // extern "C"

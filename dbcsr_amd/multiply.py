@@ -68,6 +68,11 @@ class MultiplyEngine:
         if rc != 0:
             raise RuntimeError("dbcsr_amd_bcsr_fill_random failed (%d)" % rc)
 
+    def last_kernel(self):
+        """name of the block-product kernel the last numeric call launched (dbcsr_amd_mm_last_kernel)"""
+        v = self.L.dbcsr_amd_mm_last_kernel(self.h)
+        return v.decode() if v else ""
+
     def last_timing(self):
         """(ms_fill, ms_numeric) of the last numeric call, from HIP events on its stream."""
         f, n = C.c_float(), C.c_float()

@@ -150,6 +150,8 @@ int dbcsr_amd_mm_timing(void* handle, float* ms_fill, float* ms_numeric);
 
 /* Symbol name of the dominant kernel, for profile look-up. */
 const char* dbcsr_amd_mm_kernel_name(libsmm_acc_data_t datatype);
+/* name (with its template arguments) of the block-product kernel the last dbcsr_amd_mm_numeric of this handle launched */
+const char* dbcsr_amd_mm_last_kernel(void* handle);
 
 #if defined(__cplusplus)
 }

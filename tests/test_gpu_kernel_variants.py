@@ -1,0 +1,91 @@
+"""Every block-product kernel variant forced through the oracle: the automatic choice of
+dbcsr_amd_mm_numeric picks one kernel per launch from the sizes of the case, so a parity suite that only uses the defaults
+covers the other variants by accident.  Here the switches DBCSR_AMD_MM_KERNEL / _HOT / _TINY (read when an engine is
+created) force each variant on cases it can run, the name of the kernel that ran is asserted, and the result is compared
+with the CPU oracle (index bit-exact, values 1e-10 fp64 / 1e-5 fp32)."""
+import numpy as np
+import pytest
+import torch
+
+from dbcsr_amd.multiply import MultiplyEngine, dbcsr_multiply
+from oracle import oracle as O
+from tests.gpu_util import dev_to_bcsr, rel_err, to_dev
+
+pytestmark = pytest.mark.gpu
+
+MIXED = (300, 280, 260, 0.5, 0.5, 0.6, [1, 13, 1, 23, 1, 32, 1, 7], [1, 23, 1, 5, 1, 32], [1, 13, 1, 32, 1, 9])
+H2O = (23 * 20 + 16, 23 * 18 + 16, 23 * 22 + 16, 0.6, 0.6, 0.7, [1, 23], [1, 23], [1, 23])
+TINY = (240, 240, 240, 0.7, 0.7, 0.7, [1, 4], [1, 4, 1, 3], [1, 4, 1, 2])
+BIG = (300, 270, 280, 0.5, 0.5, 0.5, [1, 45, 1, 13], [1, 67, 1, 5], [1, 40, 1, 23])
+
+# (environment, case, expected kernel-name prefix)
+VARIANTS = [
+    ({}, H2O, "mm_numeric_f64_hot<23,23,23>"),
+    ({"DBCSR_AMD_MM_HOT": "0", "DBCSR_AMD_MM_KERNEL": "lds1"}, H2O, "mm_numeric_f64_lds<3>"),
+    ({"DBCSR_AMD_MM_KERNEL": "pipe"}, H2O, "mm_numeric_f64_pipe<3>"),
+    ({"DBCSR_AMD_MM_KERNEL": "dma2"}, H2O, "mm_numeric_f64_dma<23,23,23,2>"),
+    ({"DBCSR_AMD_MM_KERNEL": "dma3"}, H2O, "mm_numeric_f64_dma<23,23,23,3>"),
+    ({"DBCSR_AMD_MM_KERNEL": "direct"}, H2O, "mm_numeric_f64"),
+    ({"DBCSR_AMD_MM_KERNEL": "lds1"}, MIXED, "mm_numeric_f64_lds<4>"),
+    ({"DBCSR_AMD_MM_KERNEL": "pipe"}, MIXED, "mm_numeric_f64_pipe<4>"),
+    ({"DBCSR_AMD_MM_KERNEL": "pipe", "DBCSR_AMD_MM_PIPE_G": "3"}, MIXED, "mm_numeric_f64_pipe<4>"),
+    ({"DBCSR_AMD_MM_KERNEL": "direct"}, MIXED, "mm_numeric_f64"),
+    ({}, TINY, "mm_numeric_f64_tiny"),
+    ({"DBCSR_AMD_MM_TINY": "0", "DBCSR_AMD_MM_KERNEL": "lds1"}, TINY, "mm_numeric_f64_lds<1>"),
+    ({"DBCSR_AMD_MM_TINY": "0", "DBCSR_AMD_MM_KERNEL": "pipe"}, TINY, "mm_numeric_f64_pipe<1>"),
+    ({}, BIG, "mm_numeric_f64"),
+    ({"DBCSR_AMD_MM_SYMBOLIC": "word"}, MIXED, "mm_numeric_f64"),
+]
+
+
+def run_case(monkeypatch, env, case, dtype, tol, expect, alpha=0.7, beta=1.3, retain=False, in_place_twice=False):
+    for k in ("DBCSR_AMD_MM_KERNEL", "DBCSR_AMD_MM_HOT", "DBCSR_AMD_MM_TINY", "DBCSR_AMD_MM_PIPE_G", "DBCSR_AMD_MM_SYMBOLIC"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    eng = MultiplyEngine()  # reads the switches now
+    A, B, Cm = O.perf_case(*case)
+    ref, info = O.multiply("N", "N", alpha, A, B, beta, Cm, retain_sparsity=retain)
+    cast = lambda M: O.Bcsr(M.row_sizes, M.col_sizes, M.row_p, M.col_i, M.blk_p, M.data.astype(dtype))
+    dA, dB, dC = to_dev(cast(A)), to_dev(cast(B)), to_dev(cast(Cm))
+    flop = [0]
+    dbcsr_multiply("N", "N", alpha, dA, dB, beta, dC, retain_sparsity=retain, flop=flop, engine=eng)
+    torch.cuda.synchronize()
+    assert eng.last_kernel().replace(" ", "").startswith(expect.replace(" ", "")), (eng.last_kernel(), expect)
+    out = dev_to_bcsr(dC)
+    assert np.array_equal(out.row_p, ref.row_p) and np.array_equal(out.col_i, ref.col_i) and np.array_equal(out.blk_p, ref.blk_p)
+    assert flop[0] == info["flop"]
+    assert rel_err(out.data, ref.data) <= tol
+    if in_place_twice:  # accumulate a second product into the result (retain_sparsity, beta = 1: the Cannon tick path)
+        ref2, _ = O.multiply("N", "N", alpha, A, B, 1.0, ref, retain_sparsity=True)
+        dbcsr_multiply("N", "N", alpha, dA, dB, 1.0, dC, retain_sparsity=True, engine=eng)
+        torch.cuda.synchronize()
+        out2 = dev_to_bcsr(dC)
+        assert np.array_equal(out2.col_i, ref2.col_i) and rel_err(out2.data, ref2.data) <= tol
+
+
+@pytest.mark.parametrize("env,case,expect", VARIANTS, ids=lambda v: "-".join("%s=%s" % (k[13:], x) for k, x in v.items()) if isinstance(v, dict) else None)
+def test_fp64_variant_matches_oracle(monkeypatch, env, case, expect):
+    run_case(monkeypatch, env, case, np.float64, 1e-10, expect)
+
+
+@pytest.mark.parametrize("env,case,expect", [v for v in VARIANTS if v[1] in (H2O, MIXED)][:9],
+                         ids=lambda v: "-".join("%s=%s" % (k[13:], x) for k, x in v.items()) if isinstance(v, dict) else None)
+def test_fp64_variant_retain_and_in_place(monkeypatch, env, case, expect):
+    run_case(monkeypatch, env, case, np.float64, 1e-10, expect, alpha=1.0, beta=1.0, retain=True, in_place_twice=True)
+
+
+F32 = (32 * 12, 32 * 11, 32 * 13, 0.6, 0.6, 0.6, [1, 32], [1, 32], [1, 32])
+F32_MIXED = (300, 280, 260, 0.5, 0.5, 0.6, [1, 13, 1, 32, 1, 7], [1, 23, 1, 32], [1, 13, 1, 32, 1, 9])
+
+
+@pytest.mark.parametrize("env,case,expect", [
+    ({}, F32, "mm_numeric_f32_hot<32,32,32>"),
+    ({"DBCSR_AMD_MM_HOT": "0"}, F32, "mm_numeric_f32_lds"),
+    ({"DBCSR_AMD_MM_KERNEL": "direct"}, F32, "mm_numeric_f32"),
+    ({}, F32_MIXED, "mm_numeric_f32_lds"),
+    ({"DBCSR_AMD_MM_KERNEL": "direct"}, F32_MIXED, "mm_numeric_f32"),
+    ({}, BIG, "mm_numeric_f32"),
+], ids=lambda v: "-".join("%s=%s" % (k[13:], x) for k, x in v.items()) if isinstance(v, dict) else None)
+def test_fp32_variant_matches_oracle(monkeypatch, env, case, expect):
+    run_case(monkeypatch, env, case, np.float32, 2e-5, expect, alpha=1.0, beta=1.0)
