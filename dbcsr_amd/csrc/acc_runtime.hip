@@ -103,16 +103,24 @@ int c_dbcsr_acc_stream_create(void** stream_p, const char* name, int priority) {
   if (!stream_p) return -1;
   hipStream_t* s = static_cast<hipStream_t*>(malloc(sizeof(hipStream_t)));
   if (!s) return -1;
-  int lo = 0, hi = 0;
-  (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // lo = least (numerically larger), hi = greatest
-  int prio = priority;
-  if (prio > lo) prio = lo;
-  if (prio < hi) prio = hi;
-  hipError_t e = hipStreamCreateWithPriority(s, hipStreamNonBlocking, prio);
+  // As the reference (src/acc/cuda_hip/acc_stream.cpp:46-52): an explicit positive priority gives a non-blocking stream with
+  // that priority (clamped to the device's range: lo = least = numerically largest); anything else -- the Fortran default
+  // is -1 -- gives a plain stream at the default priority, so that the host's "priority" / default distinction survives.
+  hipError_t e;
+  if (priority > 0) {
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    int prio = priority;
+    if (prio > lo) prio = lo;
+    if (prio < hi) prio = hi;
+    e = hipStreamCreateWithPriority(s, hipStreamNonBlocking, prio);
+  } else {
+    e = hipStreamCreate(s);
+  }
   if (e != hipSuccess) {
     free(s);
     *stream_p = nullptr;
-    return dbcsr_amd::check(e, "hipStreamCreateWithPriority", __FILE__, __LINE__);
+    return dbcsr_amd::check(e, "hipStreamCreate", __FILE__, __LINE__);
   }
   *stream_p = s;
   return 0;

@@ -29,6 +29,7 @@
 #include <cstring>
 #include <algorithm>
 #include <new>
+#include <vector>
 
 #include "../../include/dbcsr_amd_mm.h"
 #include "common.h"
@@ -1935,6 +1936,43 @@ __global__ void __launch_bounds__(256) scale_window(const int* __restrict__ row_
   }
 }
 
+
+// ---- per-(m, n, k) statistics (dbcsr_mm_sched.F:392-461): histogram over the product lists, open addressing ------------
+constexpr int kStatSlots = 8192;  // power of two
+__global__ void __launch_bounds__(256) mnk_histogram(const Desc* __restrict__ descs, int64_t nblk, const Entry* __restrict__ entries,
+                                                     unsigned long long* __restrict__ keys, unsigned long long* __restrict__ counts,
+                                                     int* __restrict__ overflow) {
+  const int64_t cb = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (cb >= nblk) return;
+  const Desc d = descs[cb];
+  const Entry* e = entries + d.prod_start;
+  unsigned long long run_key = 0, run_cnt = 0;
+  auto flush = [&]() {
+    if (!run_cnt) return;
+    unsigned h = (unsigned)((run_key * 0x9E3779B97F4A7C15ull) >> 40) & (kStatSlots - 1);
+    for (int probe = 0; probe < kStatSlots; ++probe) {
+      const unsigned long long prev = atomicCAS(&keys[h], 0ull, run_key);
+      if (prev == 0ull || prev == run_key) {
+        atomicAdd(&counts[h], run_cnt);
+        return;
+      }
+      h = (h + 1) & (kStatSlots - 1);
+    }
+    *overflow = 1;
+  };
+  for (int p = 0; p < d.prod_cnt; ++p) {
+    // key: m | n << 16 | k << 32, plus bit 63 so that no key is 0
+    const unsigned long long key = (unsigned long long)(uint16_t)d.m | ((unsigned long long)(uint16_t)d.n << 16) |
+                                   ((unsigned long long)(unsigned)e[p].ks() << 32) | (1ull << 63);
+    if (key != run_key) {
+      flush();
+      run_key = key;
+      run_cnt = 0;
+    }
+    ++run_cnt;
+  }
+  flush();
+}
 }  // namespace dbcsr_amd
 #include "mm_dma.h"
 namespace dbcsr_amd {
@@ -2032,7 +2070,7 @@ struct Engine {
   int lds_pad = 0;                      // DBCSR_AMD_MM_LDS_PAD: extra LDS bytes per workgroup (occupancy experiments)
   int64_t panel_bytes = 160ll << 20;  // DBCSR_AMD_MM_PANEL_MB: target size of a B column panel
   int row_group = 0;                 // DBCSR_AMD_MM_ROW_GROUP: rows walked together per XCD (0 = automatic)
-  DevBuf<unsigned long long> dev_scalars;
+  DevBuf<unsigned long long> dev_scalars, stat_table;
   int64_t* host_scalars = nullptr;  // pinned: [0]=c_nblks [1]=c_nze [2]=nproducts [3]=flop
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};  // around fill_products and the numeric kernel
   bool timed = false;
@@ -2123,6 +2161,7 @@ int dbcsr_amd_mm_destroy(void* handle) {
   E->prod_start.release(); E->c_blk_p_ws.release(); E->partial.release(); E->off_a.release(); E->off_b.release();
   E->entries.release(); E->descs.release(); E->row_sums.release(); E->dev_scalars.release();
   E->order.release(); E->order_cnt.release(); E->order_base.release();
+  E->stat_table.release();
   E->norms64.release(); E->a_norms.release(); E->b_norms.release(); E->keep.release();
   if (E->host_scalars) (void)hipHostFree(E->host_scalars);
   for (int i = 0; i < 3; ++i)
@@ -2234,8 +2273,8 @@ int dbcsr_amd_mm_symbolic_filtered(void* handle, libsmm_acc_data_t datatype, dou
     E->max_m = mx[0]; E->min_m = -mx[1];
     E->max_k = mx[2]; E->min_k = -mx[3];
     E->max_n = mx[4]; E->min_n = -mx[5];
-    if (E->max_k > 0xffff) {
-      fprintf(stderr, "dbcsr_amd_mm_symbolic: block sizes above 65535 are not supported (k extent is packed in 16 bits)\n");
+    if (E->max_k > 0xffff || E->max_m > 0x7fff || E->max_n > 0x7fff) {
+      fprintf(stderr, "dbcsr_amd_mm_symbolic: block sizes above 32767 (m, n) / 65535 (k) are not supported (packed 16-bit extents)\n");
       return -1;
     }
     // exact-size kernel: only when one (m, n, k) covers at least 90 % of the block rows / columns of each dimension
@@ -2686,6 +2725,45 @@ int dbcsr_amd_bcsr_transpose(void* handle, libsmm_acc_data_t datatype, const dbc
   }
   dst->nblks = src->nblks;
   return check(hipGetLastError(), "dbcsr_amd_bcsr_transpose", __FILE__, __LINE__);
+}
+
+int dbcsr_amd_mm_stats(void* handle, dbcsr_amd_mnk_stat* out, int max_entries, int* n_entries, void* stream) {
+  Engine* E = static_cast<Engine*>(handle);
+  if (!E || !n_entries || (max_entries > 0 && !out)) return -1;
+  *n_entries = 0;
+  if (!E->valid || !E->timed || E->c_nblks == 0) return 0;  // no numeric call yet / nothing to count
+  hipStream_t st = stream_of(stream);
+  if (E->stat_table.ensure(2 * (size_t)kStatSlots + 2)) return -1;
+  unsigned long long* keys = E->stat_table.p;
+  unsigned long long* counts = keys + kStatSlots;
+  int* overflow = reinterpret_cast<int*>(counts + kStatSlots);
+  ACC_CHECK(hipMemsetAsync(keys, 0, sizeof(unsigned long long) * (2 * (size_t)kStatSlots + 2), st));
+  hipLaunchKernelGGL(mnk_histogram, grid_for(E->c_nblks), dim3(256), 0, st, E->descs.p, E->c_nblks, E->entries.p, keys, counts, overflow);
+  std::vector<unsigned long long> host(2 * (size_t)kStatSlots + 2);
+  ACC_CHECK(hipMemcpyAsync(host.data(), keys, sizeof(unsigned long long) * host.size(), hipMemcpyDeviceToHost, st));
+  ACC_CHECK(hipStreamSynchronize(st));
+  if (*reinterpret_cast<const int*>(&host[2 * (size_t)kStatSlots])) {
+    fprintf(stderr, "dbcsr_amd_mm_stats: more than %d distinct (m, n, k) triples\n", kStatSlots);
+    return -1;
+  }
+  std::vector<dbcsr_amd_mnk_stat> all;
+  for (int i = 0; i < kStatSlots; ++i)
+    if (host[i]) {
+      dbcsr_amd_mnk_stat r;
+      r.m = (int32_t)(host[i] & 0xffffu);
+      r.n = (int32_t)((host[i] >> 16) & 0xffffu);
+      r.k = (int32_t)((host[i] >> 32) & 0x7fffffffu);
+      r.reserved = 0;
+      r.nproducts = (int64_t)host[kStatSlots + i];
+      r.flop = 2ll * r.m * r.n * r.k * r.nproducts;
+      all.push_back(r);
+    }
+  std::sort(all.begin(), all.end(), [](const dbcsr_amd_mnk_stat& a, const dbcsr_amd_mnk_stat& b) {
+    return a.flop != b.flop ? a.flop > b.flop : (a.m != b.m ? a.m < b.m : (a.n != b.n ? a.n < b.n : a.k < b.k));
+  });
+  *n_entries = (int)all.size();
+  for (int i = 0; i < (int)all.size() && i < max_entries; ++i) out[i] = all[i];
+  return 0;
 }
 
 const char* dbcsr_amd_mm_kernel_name(libsmm_acc_data_t datatype) {

@@ -28,7 +28,7 @@ LIBSMM_SYMBOLS = [
 ]
 MM_SYMBOLS = [
     "dbcsr_amd_mm_create", "dbcsr_amd_mm_destroy", "dbcsr_amd_mm_symbolic", "dbcsr_amd_mm_numeric", "dbcsr_amd_bcsr_transpose",
-    "dbcsr_amd_bcsr_checksum", "dbcsr_amd_bcsr_fill_random", "dbcsr_amd_mm_kernel_name", "dbcsr_amd_mm_last_kernel", "dbcsr_amd_mm_timing", "dbcsr_amd_mm_init_c", "dbcsr_amd_bcsr_fill_random_dist",
+    "dbcsr_amd_bcsr_checksum", "dbcsr_amd_bcsr_fill_random", "dbcsr_amd_mm_kernel_name", "dbcsr_amd_mm_last_kernel", "dbcsr_amd_mm_stats", "dbcsr_amd_mm_timing", "dbcsr_amd_mm_init_c", "dbcsr_amd_bcsr_fill_random_dist",
     "dbcsr_amd_mm_symbolic_filtered", "dbcsr_amd_bcsr_filter_count", "dbcsr_amd_bcsr_filter_apply",
     "dbcsr_amd_bcsr_crop_count", "dbcsr_amd_bcsr_crop_apply", "dbcsr_amd_bcsr_scale_window",
     "dbcsr_amd_multiply", "dbcsr_amd_bcsr_release",
@@ -39,6 +39,10 @@ class BcsrDesc(C.Structure):
     """struct dbcsr_amd_bcsr (include/dbcsr_amd_mm.h); device pointers."""
     _fields_ = [("nblkrows", C.c_int32), ("nblkcols", C.c_int32), ("row_blk_size", C.c_void_p), ("col_blk_size", C.c_void_p),
                 ("row_p", C.c_void_p), ("col_i", C.c_void_p), ("blk_p", C.c_void_p), ("data", C.c_void_p), ("nblks", C.c_int64)]
+
+
+class MnkStat(C.Structure):
+    _fields_ = [("m", C.c_int32), ("n", C.c_int32), ("k", C.c_int32), ("reserved", C.c_int32), ("nproducts", C.c_int64), ("flop", C.c_int64)]
 
 
 class MmCounts(C.Structure):
@@ -118,6 +122,7 @@ def load_library():
     L.dbcsr_amd_mm_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.dbcsr_amd_mm_kernel_name.argtypes = [i32]
     L.dbcsr_amd_mm_kernel_name.restype = C.c_char_p
+    L.dbcsr_amd_mm_stats.argtypes = [vp, C.POINTER(MnkStat), i32, C.POINTER(i32), vp]
     L.dbcsr_amd_mm_last_kernel.argtypes = [vp]
     L.dbcsr_amd_mm_last_kernel.restype = C.c_char_p
     _LIB = L

@@ -68,6 +68,43 @@ class MultiplyEngine:
         if rc != 0:
             raise RuntimeError("dbcsr_amd_bcsr_fill_random failed (%d)" % rc)
 
+    # -- statistics (dbcsr_mm_sched.F:392-461 / dbcsr_print_statistics) -------------------------------------------
+    def mnk_statistics(self, stream=None, max_entries=4096):
+        """[(m, n, k, nproducts, flop)] of the last numeric call, largest flop first (dbcsr_amd_mm_stats)."""
+        st = StreamHandle(stream)
+        buf = (_lib.MnkStat * max_entries)()
+        n = C.c_int32(0)
+        rc = self.L.dbcsr_amd_mm_stats(self.h, buf, max_entries, C.byref(n), st.ptr)
+        if rc != 0:
+            raise RuntimeError("dbcsr_amd_mm_stats failed (%d)" % rc)
+        return [(r.m, r.n, r.k, r.nproducts, r.flop) for r in buf[:min(n.value, max_entries)]]
+
+    def accumulate_statistics(self, stream=None):
+        """Adds the last multiply to this engine's running totals (the reference accumulates until dbcsr_print_statistics)."""
+        tot = self.__dict__.setdefault("stats_total", {})
+        for m, n, k, cnt, fl in self.mnk_statistics(stream):
+            c0, f0 = tot.get((m, n, k), (0, 0))
+            tot[(m, n, k)] = (c0 + cnt, f0 + fl)
+        self.__dict__["stats_multiplications"] = self.__dict__.get("stats_multiplications", 0) + 1
+        return tot
+
+    def print_statistics(self, file=None):
+        """The 'flops m x n x k' table of dbcsr_print_statistics (src/mm/dbcsr_mm_sched.F:463-560); every product ran on the ACC."""
+        import sys as _sys
+        f = file or _sys.stdout
+        tot = self.__dict__.get("stats_total", {})
+        total = sum(v[1] for v in tot.values())
+        print(" " + "-" * 79, file=f)
+        print(" -%s-" % "DBCSR STATISTICS".center(77), file=f)
+        print(" " + "-" * 79, file=f)
+        print(" COUNTER                                    TOTAL       BLAS       SMM       ACC", file=f)
+        for (m, n, k), (cnt, fl) in sorted(tot.items(), key=lambda kv: -kv[1][1]):
+            print(" flops %5d x %5d x %5d %20d       0.0%%      0.0%%    100.0%%" % (m, n, k, fl), file=f)
+        print(" flops total %30.6E       0.0%%      0.0%%    100.0%%" % float(total), file=f)
+        print(" matmuls total %28d       0.0%%      0.0%%    100.0%%" % sum(v[0] for v in tot.values()), file=f)
+        print(" # multiplications %24d" % self.__dict__.get("stats_multiplications", 0), file=f)
+        print(" " + "-" * 79, file=f)
+
     def last_kernel(self):
         """name of the block-product kernel the last numeric call launched (dbcsr_amd_mm_last_kernel)"""
         v = self.L.dbcsr_amd_mm_last_kernel(self.h)
@@ -226,6 +263,8 @@ class MultiplyEngine:
     def multiply_local(self, alpha, A, B, beta, Cm, retain_sparsity=False, stream=None, filter_eps=0.0, kchunks=None):
         """C_out = beta*Cm + alpha*A*B for already-oriented operands; returns (C_out, counts)."""
         n = self._auto_kchunks(A, filter_eps) if kchunks is None else int(kchunks)
+        if filter_eps and filter_eps > 0.0 and n > 1:
+            raise ValueError("multiply_local: k passes cannot be combined with filter_eps (the on-the-fly filter counts the blocks of a whole A row)")
         if n > 1 and A.nblkcols >= n:
             # structure once (symbolic product of the whole operands, C = beta*Cm on it), then one in-place pass per k range
             row_p, total = self.symbolic(A, B, Cm, retain_sparsity=retain_sparsity, stream=stream)

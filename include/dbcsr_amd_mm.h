@@ -51,6 +51,14 @@ typedef struct dbcsr_amd_mm_counts {
   int64_t flop;      /* sum 2*m*n*k over products == dbcsr_multiply's flop (dbcsr_mm_csr.F:350) */
 } dbcsr_amd_mm_counts;
 
+/* Per-(m, n, k) statistics of a multiply: what dbcsr_mm_sched keeps per stack (src/mm/dbcsr_mm_sched.F:392-461, the
+ * "flops m x n x k" table of dbcsr_print_statistics); here every product runs on the accelerator. */
+typedef struct dbcsr_amd_mnk_stat {
+  int32_t m, n, k, reserved;
+  int64_t nproducts; /* block products of this size ("matmuls") */
+  int64_t flop;      /* 2*m*n*k*nproducts */
+} dbcsr_amd_mnk_stat;
+
 int dbcsr_amd_mm_create(void** handle);
 int dbcsr_amd_mm_destroy(void* handle);
 
@@ -92,7 +100,10 @@ int dbcsr_amd_bcsr_scale_window(void* handle, libsmm_acc_data_t datatype, dbcsr_
 /* Numeric phase.  c_out->row_p is the array written by the symbolic call;
  * col_i [c_nblks], blk_p [c_nblks] and data [c_nze] are allocated by the caller
  * and filled here (blocks laid out in index order).  c_out->data may alias
- * c_in->data only when retain_sparsity was set (same pattern, in place).
+ * c_in->data only when retain_sparsity was set (same pattern, in place) AND c_in's blocks are already laid out
+ * packed in index order (blk_p = running sum of the block sizes) -- which is how every matrix produced by this
+ * library is laid out; a C_in with another placement must not be aliased (c_out->blk_p is rewritten to the packed
+ * offsets).
  * datatype: dbcsr_type_real_8 or dbcsr_type_real_4.  Asynchronous on stream. */
 int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha, const dbcsr_amd_bcsr* a, const dbcsr_amd_bcsr* b,
   double beta, const dbcsr_amd_bcsr* c_in, dbcsr_amd_bcsr* c_out, void* stream);
@@ -149,6 +160,11 @@ int dbcsr_amd_bcsr_release(dbcsr_amd_bcsr* m);
 int dbcsr_amd_mm_timing(void* handle, float* ms_fill, float* ms_numeric);
 
 /* Symbol name of the dominant kernel, for profile look-up. */
+/* Statistics of the last dbcsr_amd_mm_numeric of this handle, by (m, n, k): at most max_entries records are written to
+ * `out` (host memory), *n_entries receives the number of distinct triples (larger than max_entries = truncated).
+ * Counted on the device from the product lists of that call; synchronises `stream`. */
+int dbcsr_amd_mm_stats(void* handle, dbcsr_amd_mnk_stat* out, int max_entries, int* n_entries, void* stream);
+
 const char* dbcsr_amd_mm_kernel_name(libsmm_acc_data_t datatype);
 /* name (with its template arguments) of the block-product kernel the last dbcsr_amd_mm_numeric of this handle launched */
 const char* dbcsr_amd_mm_last_kernel(void* handle);

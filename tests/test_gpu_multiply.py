@@ -274,3 +274,29 @@ def test_two_engines_on_two_streams_concurrently():
     for got, ref in zip(outs, refs):
         assert np.array_equal(got.row_p, ref.row_p) and np.array_equal(got.col_i, ref.col_i)
         assert rel_err(got.data, ref.data) <= TOL
+
+
+def test_mnk_statistics_match_enumeration():
+    # per-(m, n, k) product and flop counts (reference: dbcsr_mm_sched.F:392-461) against a direct enumeration of the products
+    A, B, Cm = O.perf_case(300, 280, 260, 0.5, 0.5, 0.6, [1, 13, 1, 23, 1, 32, 1, 7], [1, 23, 1, 5, 1, 32], [1, 13, 1, 32, 1, 9])
+    eng = MultiplyEngine()
+    dA, dB, dC = to_dev(A), to_dev(B), to_dev(Cm)
+    flop = [0]
+    dbcsr_multiply("N", "N", 1.0, dA, dB, 1.0, dC, flop=flop, engine=eng)
+    got = {(m, n, k): (c, f) for m, n, k, c, f in eng.mnk_statistics()}
+    want = {}
+    rows = A.rows()
+    for ab in range(A.nblks):
+        i, kb = rows[ab], A.col_i[ab]
+        for bb in range(B.row_p[kb], B.row_p[kb + 1]):
+            key = (int(A.row_sizes[i]), int(B.col_sizes[B.col_i[bb]]), int(A.col_sizes[kb]))
+            c, f = want.get(key, (0, 0))
+            want[key] = (c + 1, f + 2 * key[0] * key[1] * key[2])
+    assert got == want
+    assert sum(f for _, f in got.values()) == flop[0]
+    tot = eng.accumulate_statistics()
+    assert tot == got
+    import io
+    buf = io.StringIO()
+    eng.print_statistics(buf)
+    assert "flops total" in buf.getvalue() and "100.0%" in buf.getvalue()
