@@ -43,6 +43,16 @@ from . import randmat
 from .matrix import DbcsrMatrix
 
 
+class _EventWork:
+    """wait() makes the current (compute) stream wait for a transfer posted on the communication stream"""
+
+    def __init__(self, ev):
+        self.ev = ev
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.ev)
+
+
 def dims_create(n):
     """MPI_Dims_create-like 2-D factorisation, non-increasing (8 -> 4 x 2), as the reference's
     default grid (src/mpi/dbcsr_mpiwrap.F:1107)."""
@@ -135,7 +145,22 @@ class CannonMultiply:
     (process column c, images v = r mod nprows)."""
 
     def __init__(self, M=0, N=0, K=0, sparsities=(0, 0, 0), mix=(1, 1), dtype=torch.float64, engine=None, device=None, grid=None,
-                 mix_n=None, mix_k=None, mode="gather", local_first=True, matrices=None):
+                 mix_n=None, mix_k=None, mode="gather", local_first=True, matrices=None, transport="torch"):
+        # transport: "torch" = torch.distributed point-to-point (RCCL under the nccl backend, gloo on CPU);
+        #            "native" = the C-ABI exchange of include/dbcsr_amd_comm.h (RCCL group on a dedicated HIP stream);
+        #            "auto"   = native when it can be set up (GPU tensors, more than one rank), else torch
+        self.comm = None
+        self.transport = "torch"
+        if transport in ("native", "auto") and dist.is_initialized() and dist.get_world_size() > 1 and torch.cuda.is_available():
+            try:
+                from .comm import NativeComm
+                self.comm = NativeComm()
+                self.transport = "native"
+            except Exception as e:  # noqa: BLE001
+                if transport == "native":
+                    raise
+                import sys
+                sys.stderr.write("dbcsr_amd.cannon: native RCCL transport unavailable (%r), using torch.distributed\n" % (e,))
         self.mode = mode
         self.local_first = local_first
         self._host = None
@@ -282,7 +307,7 @@ class CannonMultiply:
         """gather mode: one batch with every image this rank misses (and every send the others expect)."""
         g, r, c = self.grid, self.grid.myprow, self.grid.mypcol
         ops, staged = [], []
-        host = g.world > 1 and self.device.type == "cuda" and dist.get_backend() != "nccl"  # debug transport
+        host = self.comm is None and g.world > 1 and self.device.type == "cuda" and dist.get_backend() != "nccl"  # debug transport
         if host:
             torch.cuda.synchronize()
 
@@ -300,6 +325,10 @@ class CannonMultiply:
             else:
                 ops.append(dist.P2POp(dist.irecv, t, peer))
 
+        nsends, nrecvs = [], []
+        if self.comm is not None:  # native transport: collect (tensor, peer), post ONE RCCL group on the communication stream
+            send = lambda t, peer: nsends.append((t, peer))
+            recv = lambda t, peer: nrecvs.append((t, peer))
         for v in range(g.nvirt):
             na, nb = self.A_img[v].data_numel, self.B_img[v].data_numel
             a_own, b_own = g.a_owner(r, v), g.b_owner(v, c)
@@ -317,6 +346,8 @@ class CannonMultiply:
                             send(self.B_img[v].data, g.rank_of(pr, c))
                 else:
                     recv(self._b_all[self._b_base[v]:self._b_base[v] + nb], b_own)
+        if self.comm is not None:
+            return ([_EventWork(self.comm.exchange(nsends, nrecvs))] if (nsends or nrecvs) else []), staged
         works = dist.batch_isend_irecv(ops) if ops else []
         return works, staged
 
@@ -365,10 +396,11 @@ class CannonMultiply:
     # ------------------------------------------------------------------
     def _post(self, tick, parity):
         """Send/receive the panels of `tick`.  Returns (ops work handles, A data, B data)."""
-        if self.grid.world > 1 and self.device.type == "cuda" and dist.get_backend() != "nccl":
+        if self.comm is None and self.grid.world > 1 and self.device.type == "cuda" and dist.get_backend() != "nccl":
             return self._post_host_staged(tick, parity)
         g, r, c = self.grid, self.grid.myprow, self.grid.mypcol
         ops = []
+        nsends, nrecvs = [], []
         v = g.v_at(r, c, tick)
         a_src, b_src = g.a_owner(r, v), g.b_owner(v, c)
         a_data = self.A_img[v].data if a_src == g.rank else self._abuf[parity][:self.A_img[v].data_numel]
@@ -379,17 +411,22 @@ class CannonMultiply:
                 continue
             vv = g.v_at(r, pc, tick)
             if g.a_owner(r, vv) == g.rank and self.A_img[vv].data_numel:
-                ops.append(dist.P2POp(dist.isend, self.A_img[vv].data, g.rank_of(r, pc)))
+                nsends.append((self.A_img[vv].data, g.rank_of(r, pc)))
         for pr in range(g.nprows):  # my process column: B images I own
             if pr == r:
                 continue
             vv = g.v_at(pr, c, tick)
             if g.b_owner(vv, c) == g.rank and self.B_img[vv].data_numel:
-                ops.append(dist.P2POp(dist.isend, self.B_img[vv].data, g.rank_of(pr, c)))
+                nsends.append((self.B_img[vv].data, g.rank_of(pr, c)))
         if a_src != g.rank and self.A_img[v].data_numel:
-            ops.append(dist.P2POp(dist.irecv, a_data, a_src))
+            nrecvs.append((a_data, a_src))
         if b_src != g.rank and self.B_img[v].data_numel:
-            ops.append(dist.P2POp(dist.irecv, b_data, b_src))
+            nrecvs.append((b_data, b_src))
+        if self.comm is not None:  # one RCCL group on the communication stream; it first waits for the compute stream, so the
+            # receive buffer of this parity is no longer read by the multiply of two ticks ago
+            works = [_EventWork(self.comm.exchange(nsends, nrecvs))] if (nsends or nrecvs) else []
+            return works, v, a_data, b_data
+        ops = [dist.P2POp(dist.isend, t, p) for t, p in nsends] + [dist.P2POp(dist.irecv, t, p) for t, p in nrecvs]
         works = dist.batch_isend_irecv(ops) if ops else []
         return works, v, a_data, b_data
 

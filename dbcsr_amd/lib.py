@@ -35,6 +35,15 @@ MM_SYMBOLS = [
 ]
 
 
+COMM_SYMBOLS = ["dbcsr_amd_comm_unique_id", "dbcsr_amd_comm_create", "dbcsr_amd_comm_destroy", "dbcsr_amd_comm_rank", "dbcsr_amd_comm_exchange",
+                "dbcsr_amd_comm_allgather"]
+
+
+class CommOp(C.Structure):
+    """struct dbcsr_amd_comm_op (include/dbcsr_amd_comm.h)"""
+    _fields_ = [("buf", C.c_void_p), ("bytes", C.c_int64), ("peer", C.c_int32), ("reserved", C.c_int32)]
+
+
 class BcsrDesc(C.Structure):
     """struct dbcsr_amd_bcsr (include/dbcsr_amd_mm.h); device pointers."""
     _fields_ = [("nblkrows", C.c_int32), ("nblkcols", C.c_int32), ("row_blk_size", C.c_void_p), ("col_blk_size", C.c_void_p),
@@ -123,6 +132,12 @@ def load_library():
     L.dbcsr_amd_mm_kernel_name.argtypes = [i32]
     L.dbcsr_amd_mm_kernel_name.restype = C.c_char_p
     L.dbcsr_amd_mm_stats.argtypes = [vp, C.POINTER(MnkStat), i32, C.POINTER(i32), vp]
+    L.dbcsr_amd_comm_unique_id.argtypes = [C.c_char_p]
+    L.dbcsr_amd_comm_create.argtypes = [C.POINTER(vp), C.c_char_p, i32, i32]
+    L.dbcsr_amd_comm_destroy.argtypes = [vp]
+    L.dbcsr_amd_comm_rank.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
+    L.dbcsr_amd_comm_exchange.argtypes = [vp, C.POINTER(CommOp), i32, C.POINTER(CommOp), i32, vp]
+    L.dbcsr_amd_comm_allgather.argtypes = [vp, vp, vp, i64, vp]
     L.dbcsr_amd_mm_last_kernel.argtypes = [vp]
     L.dbcsr_amd_mm_last_kernel.restype = C.c_char_p
     _LIB = L

@@ -34,7 +34,7 @@ def native():
 def test_header_declares_reference_abi():
     from dbcsr_amd import lib
     names = declared_functions()
-    for s in lib.ACC_SYMBOLS + lib.LIBSMM_SYMBOLS + lib.MM_SYMBOLS:
+    for s in lib.ACC_SYMBOLS + lib.LIBSMM_SYMBOLS + lib.MM_SYMBOLS + lib.COMM_SYMBOLS:
         assert s in names, s
     # the 26 acc.h functions + 2 imported timing hooks, 6 (+1) libsmm functions
     assert len(lib.ACC_SYMBOLS) == 28 and len(lib.LIBSMM_SYMBOLS) == 7
