@@ -133,6 +133,73 @@ def _sub_index(rows, cols, keep, row_local, col_local, nrows_local, row_sizes, c
     return np.cumsum(row_p).astype(np.int32), c.astype(np.int32), blk_p, int(nze.sum())
 
 
+class DistBlocks:
+    """The part of a distributed matrix that ONE rank holds before the multiply: any subset of the blocks, in any order,
+    addressed by GLOBAL block coordinates (the counterpart of a rank-local dbcsr_type: src/core/dbcsr_types.F:362-461).
+    rows / cols: int32 arrays, data: the blocks concatenated (column-major each) in the same order."""
+
+    def __init__(self, rows, cols, data):
+        self.rows, self.cols = np.ascontiguousarray(rows, np.int32), np.ascontiguousarray(cols, np.int32)
+        self.data = np.ascontiguousarray(data)
+
+
+def redistribute(loc, dest_of, row_sizes, col_sizes, dtype):
+    """make_images for one matrix (reference src/mm/dbcsr_mm_cannon.F:292-750): every block travels from the rank that
+    holds it to the rank that owns its target image, as an (index, data) pair -- sizes first (one allgather, :532),
+    then int32 block coordinates and the block data (:674-678, :1036).  Collective over the default process group.
+    Returns (rows, cols, offsets, data) of the blocks this rank now owns, sorted by (row, col), and the coordinates
+    of EVERY block of the matrix with its owner (the index metadata the other ranks need to address those images)."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    nze = row_sizes[loc.rows].astype(np.int64) * col_sizes[loc.cols].astype(np.int64) if len(loc.rows) else np.zeros(0, np.int64)
+    off = np.concatenate([[0], np.cumsum(nze)]).astype(np.int64)
+    dest = np.asarray(dest_of(loc.rows, loc.cols), np.int64) if len(loc.rows) else np.zeros(0, np.int64)
+    out_idx, out_dat = [], []
+    for d in range(world):
+        sel = np.nonzero(dest == d)[0]
+        out_idx.append(np.stack([loc.rows[sel], loc.cols[sel]]).astype(np.int32) if len(sel) else np.zeros((2, 0), np.int32))
+        out_dat.append(np.concatenate([loc.data[off[b]:off[b + 1]] for b in sel]) if len(sel) else np.zeros(0, loc.data.dtype))
+    if world > 1:
+        # sizes: what every rank will send to every rank (blocks, elements)
+        mine = torch.tensor([[out_idx[d].shape[1], out_dat[d].size] for d in range(world)], dtype=torch.int64)
+        allsz = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allsz, mine)
+        ops, rbuf = [], {}
+        for d in range(world):
+            if d == rank:
+                continue
+            if out_idx[d].shape[1]:
+                ops.append(dist.P2POp(dist.isend, torch.from_numpy(np.ascontiguousarray(out_idx[d])), d))
+                ops.append(dist.P2POp(dist.isend, torch.from_numpy(np.ascontiguousarray(out_dat[d])), d))
+            nb, ne = int(allsz[d][rank][0]), int(allsz[d][rank][1])
+            if nb:
+                rbuf[d] = (torch.empty((2, nb), dtype=torch.int32), torch.empty(ne, dtype=dtype))
+                ops.append(dist.P2POp(dist.irecv, rbuf[d][0], d))
+                ops.append(dist.P2POp(dist.irecv, rbuf[d][1], d))
+        for w in (dist.batch_isend_irecv(ops) if ops else []):
+            w.wait()
+        idx = [out_idx[rank]] + [rbuf[d][0].numpy() for d in sorted(rbuf)]
+        dat = [out_dat[rank]] + [rbuf[d][1].numpy() for d in sorted(rbuf)]
+    else:
+        idx, dat = [out_idx[0]], [out_dat[0]]
+    rows = np.concatenate([x[0] for x in idx]).astype(np.int32)
+    cols = np.concatenate([x[1] for x in idx]).astype(np.int32)
+    data = np.concatenate(dat) if dat else np.zeros(0)
+    n_in = row_sizes[rows].astype(np.int64) * col_sizes[cols].astype(np.int64) if len(rows) else np.zeros(0, np.int64)
+    o_in = np.concatenate([[0], np.cumsum(n_in)]).astype(np.int64)
+    order = np.lexsort((cols, rows))
+    rows, cols = rows[order], cols[order]
+    sdata = np.concatenate([data[o_in[b]:o_in[b + 1]] for b in order]) if len(order) else np.zeros(0, data.dtype)
+    soff = np.concatenate([[0], np.cumsum(n_in[order])]).astype(np.int64)
+    # index metadata of the whole matrix: every rank publishes the coordinates of the blocks it now owns
+    if world > 1:
+        everyone = [None] * world
+        dist.all_gather_object(everyone, (rows, cols))
+    else:
+        everyone = [(rows, cols)]
+    return (rows, cols, soff, sdata), everyone
+
+
 class CannonMultiply:
     """Distributed C <- beta*C + alpha*A*B.
 
@@ -145,7 +212,7 @@ class CannonMultiply:
     (process column c, images v = r mod nprows)."""
 
     def __init__(self, M=0, N=0, K=0, sparsities=(0, 0, 0), mix=(1, 1), dtype=torch.float64, engine=None, device=None, grid=None,
-                 mix_n=None, mix_k=None, mode="gather", local_first=True, matrices=None, transport="torch"):
+                 mix_n=None, mix_k=None, mode="gather", local_first=True, matrices=None, transport="torch", distributed=None):
         # transport: "torch" = torch.distributed point-to-point (RCCL under the nccl backend, gloo on CPU);
         #            "native" = the C-ABI exchange of include/dbcsr_amd_comm.h (RCCL group on a dedicated HIP stream);
         #            "auto"   = native when it can be set up (GPU tensors, more than one rank), else torch
@@ -164,6 +231,7 @@ class CannonMultiply:
         self.mode = mode
         self.local_first = local_first
         self._host = None
+        self._owned = None
         world = dist.get_world_size() if dist.is_initialized() else 1
         rank = dist.get_rank() if dist.is_initialized() else 0
         self.grid = grid or Grid(world, rank)
@@ -181,6 +249,33 @@ class CannonMultiply:
             rows_of = lambda m: np.repeat(np.arange(len(m.row_sizes), dtype=np.int32), np.diff(np.asarray(m.row_p)))
             self.pat = {w: (rows_of(m), np.asarray(m.col_i, np.int32)) for w, m in (("A", hA), ("B", hB), ("C", hC))}
             self._host = {"A": hA, "B": hB, "C": hC}
+        elif distributed is not None:
+            # ``distributed=((A_loc, B_loc, C_loc), (row_sizes, k_sizes, col_sizes))``: every rank holds only SOME blocks of
+            # each matrix (DistBlocks, global coordinates, any initial ownership); make_images moves them to the owners of
+            # their target images and tells every rank which blocks exist (index exchange), see redistribute().
+            (dA, dB, dC), (sm, sk, sn) = distributed
+            sm, sk, sn = (np.asarray(x, np.int32) for x in (sm, sk, sn))
+            P0 = Partition(sm, sk, sn, g)
+            dests = {"A": lambda rr, cc: np.asarray([g.a_owner(int(P0.row_dist[i]), int(P0.k_dist[k])) for i, k in zip(rr, cc)]),
+                     "B": lambda rr, cc: np.asarray([g.b_owner(int(P0.k_dist[k]), int(P0.col_dist[j])) for k, j in zip(rr, cc)]),
+                     "C": lambda rr, cc: np.asarray([g.rank_of(int(P0.row_dist[i]), int(P0.col_dist[j])) for i, j in zip(rr, cc)])}
+            np_dtype = np.float64 if dtype == torch.float64 else np.float32
+            self._owned, self.pat = {}, {}
+            for w, loc, (rsz, csz) in (("C", dC, (sm, sn)), ("A", dA, (sm, sk)), ("B", dB, (sk, sn))):
+                owned, everyone = redistribute(DistBlocks(loc.rows, loc.cols, np.asarray(loc.data, np_dtype)), dests[w], rsz, csz, dtype)
+                self._owned[w] = owned
+                rows_all = np.concatenate([e[0] for e in everyone]).astype(np.int32)
+                cols_all = np.concatenate([e[1] for e in everyone]).astype(np.int32)
+                # this rank only ever addresses its process row of A, its process column of B and its own tile of C
+                rr, cc = g.myprow, g.mypcol
+                if w == "A":
+                    keep = P0.row_dist[rows_all] == rr
+                elif w == "B":
+                    keep = P0.col_dist[cols_all] == cc
+                else:
+                    keep = (P0.row_dist[rows_all] == rr) & (P0.col_dist[cols_all] == cc)
+                order = np.lexsort((cols_all[keep], rows_all[keep]))
+                self.pat[w] = (rows_all[keep][order], cols_all[keep][order])
         else:
             sm = randmat.make_random_block_sizes(M, mix)
             sn = randmat.make_random_block_sizes(N, mix_n or mix)
@@ -258,7 +353,15 @@ class CannonMultiply:
         M = DbcsrMatrix(rs_t, cs_t, t(row_p, torch.int32), t(col_i, torch.int32), t(blk_p, torch.int64), data, which)
         M.data_numel = nze
         if fill and nze:
-            if self._host is not None:  # cut the kept blocks out of the replicated global matrix
+            if self._owned is not None:  # the blocks this rank received in make_images (sorted by global (row, col))
+                orow, ocol, ooff, odat = self._owned[which]
+                ncol_t = len(csizes)
+                okey = orow.astype(np.int64) * ncol_t + ocol
+                kkey = rows[keep].astype(np.int64) * ncol_t + cols[keep]
+                pos = np.searchsorted(okey, kkey)
+                assert len(okey) and np.array_equal(okey[pos], kkey), "image block missing after redistribution"
+                M.data.copy_(torch.as_tensor(np.concatenate([odat[ooff[p]:ooff[p + 1]] for p in pos])).to(self.device))
+            elif self._host is not None:  # cut the kept blocks out of the replicated global matrix
                 h = self._host[which]
                 hb, hd = np.asarray(h.blk_p, np.int64), np.asarray(h.data)
                 sizes = rsizes[rows[keep]].astype(np.int64) * csizes[cols[keep]].astype(np.int64)

@@ -33,7 +33,19 @@ def _worker(rank, world, port, alpha, beta, q, mode):
     try:
         from dbcsr_amd import cannon
         from tests.cpu_backend import OracleBackend
-        if mode.endswith("+given"):  # replicated global host matrices instead of the built-in generator
+        if mode.endswith("+dist"):  # distributed input: every rank holds an arbitrary third / quarter ... of the blocks
+            A, B, Cm = O.perf_case(CASE["M"], CASE["N"], CASE["K"], *CASE["sp"], CASE["mix"], CASE["mix_n"], CASE["mix_k"])
+
+            def part(M, salt):
+                rows = M.rows()
+                mine = [b for b in range(M.nblks) if (b * 7 + salt * 3 + int(rows[b])) % world == rank]
+                ne = [int(M.row_sizes[rows[b]]) * int(M.col_sizes[M.col_i[b]]) for b in mine]
+                data = np.concatenate([M.data[M.blk_p[b]:M.blk_p[b] + n] for b, n in zip(mine, ne)]) if mine else np.zeros(0)
+                return cannon.DistBlocks(rows[mine] if mine else np.zeros(0, np.int32), M.col_i[mine] if mine else np.zeros(0, np.int32), data)
+
+            plan = cannon.CannonMultiply(dtype=torch.float64, engine=OracleBackend(), device=torch.device("cpu"), mode=mode.split("+")[0],
+                                         distributed=((part(A, 1), part(B, 2), part(Cm, 3)), (A.row_sizes, A.col_sizes, B.col_sizes)))
+        elif mode.endswith("+given"):  # replicated global host matrices instead of the built-in generator
             A, B, Cm = O.perf_case(CASE["M"], CASE["N"], CASE["K"], *CASE["sp"], CASE["mix"], CASE["mix_n"], CASE["mix_k"])
             plan = cannon.CannonMultiply(dtype=torch.float64, engine=OracleBackend(), device=torch.device("cpu"),
                                          mode=mode.split("+")[0], matrices=(A, B, Cm))
@@ -51,7 +63,8 @@ def _worker(rank, world, port, alpha, beta, q, mode):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,mode", [(2, "gather"), (4, "gather+given"), (6, "gather"), (4, "ticks"), (6, "ticks+given")])
+@pytest.mark.parametrize("world,mode", [(2, "gather"), (4, "gather+given"), (6, "gather"), (4, "ticks"), (6, "ticks+given"),
+                                        (4, "ticks+dist"), (6, "gather+dist"), (2, "ticks+dist")])
 def test_cannon_matches_global_oracle(world, mode):
     alpha, beta = 0.75, -1.25
     ctx = mp.get_context("spawn")
