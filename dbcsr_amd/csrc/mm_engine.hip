@@ -34,31 +34,10 @@
 #include "../../include/dbcsr_amd_mm.h"
 #include "common.h"
 #include "smm_core.h"
+#include "mm_types.h"
+#include "mm_jit.h"
 
 namespace dbcsr_amd {
-
-struct Entry {  // one block product feeding a C block: 12 bytes, 40-bit element offsets (any operand that fits 288 GB)
-  uint32_t a_lo, b_lo;  // low 32 bits of the element offsets into the A / B data areas
-  uint32_t w;           // bits 0-15: k extent of this product; bits 16-23 / 24-31: bits 32-39 of the A / B offset
-  __device__ __forceinline__ uint64_t a_off() const { return (uint64_t)a_lo | ((uint64_t)((w >> 16) & 0xffu) << 32); }
-  __device__ __forceinline__ uint64_t b_off() const { return (uint64_t)b_lo | ((uint64_t)(w >> 24) << 32); }
-  __device__ __forceinline__ int ks() const { return (int)(w & 0xffffu); }
-  __device__ __forceinline__ static Entry make(int64_t a, int64_t b, int k) {
-    Entry e;
-    e.a_lo = (uint32_t)a;
-    e.b_lo = (uint32_t)b;
-    e.w = ((uint32_t)k & 0xffffu) | ((uint32_t)(((uint64_t)a >> 32) & 0xffu) << 16) | ((uint32_t)(((uint64_t)b >> 32) & 0xffu) << 24);
-    return e;
-  }
-};
-
-struct Desc {  // one C block
-  int64_t c_off;       // element offset in C_out data
-  int64_t cin_off;     // element offset in C_in data, -1 if the block is new
-  int64_t prod_start;  // first Entry
-  int32_t prod_cnt;
-  int16_t m, n;
-};
 
 // ----------------------------------------------------------------------------
 // small utilities
@@ -85,15 +64,6 @@ struct DevBuf {
   }
 };
 
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-  // Workgroup b is dispatched to XCD b % 8 (MI355X_MICROARCH.md); give each XCD a
-  // contiguous range of C blocks so that the A block-row it works on stays in
-  // that XCD's L2.  Bijective for any nwg.  Speed only, never correctness.
-  const int xcd = bid & 7, idx = bid >> 3;
-  const int q = nwg >> 3, r = nwg & 7;
-  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-  return base + idx;
-}
 
 // ----------------------------------------------------------------------------
 // exclusive scan (int32 in -> TO out), three small kernels
@@ -731,7 +701,6 @@ __global__ void __launch_bounds__(256) mm_numeric_f64(const Desc* __restrict__ d
 // slice (no barrier: one wave, in-order LDS queue) and reads fragments with
 // ds_read_b64; the next product's blocks are already in flight in registers
 // while the current one is multiplied.
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 template <int MA, int NC>
 __device__ __forceinline__ void cblock_f64_lds(const Desc& d, const Entry* __restrict__ entries, const double* __restrict__ a_data,
@@ -1937,6 +1906,124 @@ __global__ void __launch_bounds__(256) scale_window(const int* __restrict__ row_
 }
 
 
+// ----------------------------------------------------------------------------
+// (m, n) classes of C blocks (mixed block sizes): order[] in one segment per class
+//
+// The reference sorts block products into homogeneous stacks by the three most common sizes of each dimension
+// (map_most_common, src/dist/dbcsr_dist_util.F:753-812; stack_map in dbcsr_mm_csr.F:497-525) and runs each stack on the
+// kernel compiled for its (m, n, k).  Here a C block is the unit of work, so C blocks are bucketed by (m, n): class
+// c = 3 * rank(m) + rank(n) for the three most common row and column block sizes (ranks 0..2), class 9 = everything else.
+// order[] becomes ten segments, each laid out like the single list of the other kernels (eight XCD streams padded to a
+// common length, column panels, row i on XCD i mod 8), and each segment is one launch of the kernel for its class.
+// ----------------------------------------------------------------------------
+constexpr int kNumClasses = 10;
+
+__global__ void __launch_bounds__(256) size_hist(const int* __restrict__ sizes, int n, int* __restrict__ hist /* 33 */) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int s = sizes[i];
+  atomicAdd(&hist[(s >= 1 && s <= 32) ? s : 0], 1);
+}
+
+__global__ void __launch_bounds__(256) class_ids(const int* __restrict__ sizes, int n, int s0, int s1, int s2, unsigned char* __restrict__ cls) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int s = sizes[i];
+  cls[i] = (unsigned char)(s == s0 ? 0 : (s == s1 ? 1 : (s == s2 ? 2 : 3)));
+}
+
+// ncls_bm[q * W + w]: bit j of word w set iff column 32 w + j has class q (q = 0..3)
+__global__ void __launch_bounds__(256) class_col_bitmaps(const unsigned char* __restrict__ ncls, int nbc, int W, uint32_t* __restrict__ bm) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= W) return;
+  uint32_t m[4] = {0u, 0u, 0u, 0u};
+  for (int b = 0; b < 32; ++b) {
+    const int j = 32 * w + b;
+    if (j < nbc) m[ncls[j]] |= 1u << b;
+  }
+  for (int q = 0; q < 4; ++q) bm[(size_t)q * W + w] = m[q];
+}
+
+// columns of row i (class rc) that belong to class `cls`, as a mask on bitmap word w
+__device__ __forceinline__ uint32_t class_mask(int cls, int rc, const uint32_t* __restrict__ ncls_bm, int W, int w) {
+  if (cls < 9) return rc == cls / 3 ? ncls_bm[(size_t)(cls % 3) * W + w] : 0u;
+  return rc == 3 ? 0xffffffffu : ncls_bm[(size_t)3 * W + w];
+}
+
+// key = ((cls * 8 + x) * NP + p) * R + g : the C blocks of class cls in row i = 8 g + x inside column panel p
+__global__ void __launch_bounds__(256) order_count_cls(const uint32_t* __restrict__ c_bm, const unsigned char* __restrict__ rowcls,
+                                                       const uint32_t* __restrict__ ncls_bm, int nbr, int W, int PW, int NP, int R,
+                                                       int* __restrict__ cnt) {
+  const int key = blockIdx.x * blockDim.x + threadIdx.x;
+  if (key >= kNumClasses * 8 * NP * R) return;
+  const int g = key % R, p = (key / R) % NP, x = (key / (R * NP)) % 8, cls = key / (R * NP * 8);
+  const int i = 8 * g + x;
+  int c = 0;
+  if (i < nbr) {
+    const int rc = rowcls[i];
+    const int w1 = min(W, (p + 1) * PW);
+    for (int w = p * PW; w < w1; ++w) c += __popc(c_bm[(size_t)i * W + w] & class_mask(cls, rc, ncls_bm, W, w));
+  }
+  cnt[key] = c;
+}
+
+// per class: common padded length of its eight XCD streams (multiple of 4) and the offset of its segment in order[]
+__global__ void order_len_cls(const int64_t* __restrict__ base, int64_t total, int NP, int R, int64_t* __restrict__ lens /* 10 lens, 10 offsets, total */) {
+  int64_t off = 0;
+  for (int cls = 0; cls < kNumClasses; ++cls) {
+    int64_t mx = 0;
+    for (int x = 0; x < 8; ++x) {
+      const size_t k0 = ((size_t)cls * 8 + x) * NP * R, k1 = k0 + (size_t)NP * R;
+      const int64_t b1 = (cls == kNumClasses - 1 && x == 7) ? total : base[k1];
+      mx = b1 - base[k0] > mx ? b1 - base[k0] : mx;
+    }
+    const int64_t len = (mx + 3) & ~(int64_t)3;
+    lens[cls] = len;
+    lens[kNumClasses + cls] = off;
+    off += 8 * len;
+  }
+  lens[2 * kNumClasses] = off;
+}
+
+// thread per (row i, bitmap word w): position of each C block inside the stream of its class and XCD
+__global__ void __launch_bounds__(256) order_fill_cls(const uint32_t* __restrict__ c_bm, const int* __restrict__ c_pre,
+                                                      const int* __restrict__ c_row_p, const unsigned char* __restrict__ rowcls,
+                                                      const uint32_t* __restrict__ ncls_bm, const int64_t* __restrict__ base,
+                                                      const int64_t* __restrict__ lens, int nbr, int W, int PW, int NP, int R,
+                                                      int* __restrict__ order) {
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= (int64_t)nbr * W) return;
+  const int i = (int)(tid / W), w = (int)(tid % W);
+  uint32_t v = c_bm[tid];
+  if (!v) return;
+  const int x = i & 7, g = i >> 3, p = w / PW, rc = rowcls[i];
+  // blocks of each column class that precede word w inside the panel (class 9 of a row whose own size is unranked: all of them)
+  int before[4] = {0, 0, 0, 0};
+  for (int ww = p * PW; ww < w; ++ww) {
+    const uint32_t cw = c_bm[(size_t)i * W + ww];
+    if (rc == 3)
+      before[3] += __popc(cw);
+    else
+      for (int q = 0; q < 4; ++q) before[q] += __popc(cw & ncls_bm[(size_t)q * W + ww]);
+  }
+  int cb = c_row_p[i] + c_pre[tid];
+  while (v) {
+    const int bit = __ffs(v) - 1;
+    v &= v - 1;
+    int q = 3;
+    if (rc != 3)
+      for (int qq = 0; qq < 3; ++qq)
+        if ((ncls_bm[(size_t)qq * W + w] >> bit) & 1u) q = qq;
+    const int cls = (rc < 3 && q < 3) ? rc * 3 + q : 9;
+    const size_t key = (((size_t)cls * 8 + x) * NP + p) * R + g;
+    const size_t key0 = ((size_t)cls * 8 + x) * NP * R;
+    const int64_t pos = lens[kNumClasses + cls] + (int64_t)x * lens[cls] + (base[key] - base[key0]) + before[q];
+    order[pos] = cb;
+    ++before[q];
+    ++cb;
+  }
+}
+
 // ---- per-(m, n, k) statistics (dbcsr_mm_sched.F:392-461): histogram over the product lists, open addressing ------------
 constexpr int kStatSlots = 8192;  // power of two
 __global__ void __launch_bounds__(256) mnk_histogram(const Desc* __restrict__ descs, int64_t nblk, const Entry* __restrict__ entries,
@@ -2082,6 +2169,17 @@ struct Engine {
   bool grid_kernels = false, force_word_kernels = false;  // DBCSR_AMD_MM_SYMBOLIC=word forces the per-word symbolic kernels
   int dbg = 0;      // DBCSR_AMD_MM_DBG: ablation switches of the LDS kernel (profiling only)
   int use_pipe = -1, pipe_g = 8;  // multi-block pipelined kernel: -1 automatic (short product lists only), DBCSR_AMD_MM_KERNEL=pipe|lds1 forces; DBCSR_AMD_MM_PIPE_G = blocks per wave
+  // (m, n) classes (mixed block sizes, see order_count_cls): DBCSR_AMD_MM_CLASSES = 0 never, 1 automatic, 2 always when the sizes allow
+  int use_classes = 1;
+  bool cls_mode = false;
+  int cls_m[3] = {0, 0, 0}, cls_n[3] = {0, 0, 0}, cls_k[3] = {0, 0, 0};
+  int64_t cls_len[kNumClasses] = {0}, cls_off[kNumClasses] = {0};
+  DevBuf<int> cls_hist;
+  DevBuf<unsigned char> cls_row, cls_col;
+  DevBuf<uint32_t> cls_col_bm;
+  DevBuf<int64_t> cls_lens;
+  int* cls_host_hist = nullptr;       // pinned: 3 x 33 size histograms
+  int64_t* cls_host_lens = nullptr;   // pinned: 10 lengths, 10 offsets, total
   char last_kernel[96] = "";  // name of the numeric kernel of the last dbcsr_amd_mm_numeric (dbcsr_amd_mm_last_kernel)
   int dma_stages = 0;  // DBCSR_AMD_MM_KERNEL=dma2|dma3|dma4: LDS-DMA exact-size kernel with that many ring slots (0: off)
   int use_lds = 1;  // DBCSR_AMD_MM_KERNEL=direct selects the v1 kernel (A/B experiments)
@@ -2125,6 +2223,10 @@ int dbcsr_amd_mm_create(void** handle) {
     if (strncmp(k, "dma", 3) == 0 && k[3] >= '2' && k[3] <= '4') E->dma_stages = k[3] - '0';
   }
   if (const char* k = getenv("DBCSR_AMD_MM_PIPE_G")) E->pipe_g = std::max(1, atoi(k));
+  if (const char* k = getenv("DBCSR_AMD_MM_CLASSES")) E->use_classes = atoi(k);
+  if (hipHostMalloc(reinterpret_cast<void**>(&E->cls_host_hist), 3 * 33 * sizeof(int), hipHostMallocDefault) != hipSuccess ||
+      hipHostMalloc(reinterpret_cast<void**>(&E->cls_host_lens), (2 * kNumClasses + 1) * sizeof(int64_t), hipHostMallocDefault) != hipSuccess)
+    return -1;
   if (const char* k = getenv("DBCSR_AMD_MM_DBG")) E->dbg = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_HOT")) E->use_hot = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_TINY")) E->use_tiny = atoi(k);
@@ -2164,6 +2266,9 @@ int dbcsr_amd_mm_destroy(void* handle) {
   E->stat_table.release();
   E->norms64.release(); E->a_norms.release(); E->b_norms.release(); E->keep.release();
   if (E->host_scalars) (void)hipHostFree(E->host_scalars);
+  if (E->cls_host_hist) (void)hipHostFree(E->cls_host_hist);
+  if (E->cls_host_lens) (void)hipHostFree(E->cls_host_lens);
+  E->cls_hist.release(); E->cls_row.release(); E->cls_col.release(); E->cls_col_bm.release(); E->cls_lens.release();
   for (int i = 0; i < 3; ++i)
     if (E->ev[i]) (void)hipEventDestroy(E->ev[i]);
   delete E;
@@ -2264,6 +2369,16 @@ int dbcsr_amd_mm_symbolic_filtered(void* handle, libsmm_acc_data_t datatype, dou
     hipLaunchKernelGGL(mode_of, dim3(1), dim3(256), 0, st, a->col_blk_size, nbk, md + 2);
     hipLaunchKernelGGL(mode_of, dim3(1), dim3(256), 0, st, b->col_blk_size, nbc, md + 4);
   }
+  // block-size histograms (sizes 1..32) of the three dimensions: the (m, n) classes of a mixed-size multiply
+  E->cls_mode = false;
+  if (E->use_classes > 0) {
+    if (E->cls_hist.ensure(3 * 33)) return -1;
+    ACC_CHECK(hipMemsetAsync(E->cls_hist.p, 0, 3 * 33 * sizeof(int), st));
+    hipLaunchKernelGGL(size_hist, grid_for(nbr), dim3(256), 0, st, a->row_blk_size, nbr, E->cls_hist.p);
+    hipLaunchKernelGGL(size_hist, grid_for(nbc), dim3(256), 0, st, b->col_blk_size, nbc, E->cls_hist.p + 33);
+    hipLaunchKernelGGL(size_hist, grid_for(nbk), dim3(256), 0, st, a->col_blk_size, nbk, E->cls_hist.p + 66);
+    ACC_CHECK(hipMemcpyAsync(E->cls_host_hist, E->cls_hist.p, 3 * 33 * sizeof(int), hipMemcpyDeviceToHost, st));
+  }
   // need c_nblks (and the block-size extrema) on the host to size per-block work arrays
   ACC_CHECK(hipMemcpyAsync(E->host_scalars, dsc, 11 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
   ACC_CHECK(hipStreamSynchronize(st));
@@ -2284,6 +2399,26 @@ int dbcsr_amd_mm_symbolic_filtered(void* handle, libsmm_acc_data_t datatype, dou
     E->hot_k = dominant ? md[2] : 0;
     E->hot_n = dominant ? md[4] : 0;
   }
+  // (m, n) classes: blocks of at most 32 in every dimension, no single dominant size (that case has its ahead-of-time
+  // kernel), not the packed 4 x 4 case, and enough C blocks to pay for compiling the class kernels (forced with
+  // DBCSR_AMD_MM_CLASSES=2)
+  if (E->use_classes > 0 && E->max_m <= 32 && E->max_k <= 32 && E->max_n <= 32 && E->min_m >= 1 && E->min_k >= 1 && E->min_n >= 1 &&
+      !(E->max_m <= 4 && E->max_n <= 4) && (E->use_classes > 1 || (E->hot_m == 0 && c_nblks >= 200000))) {
+    auto top3 = [](const int* hist, int* out) {
+      int used[3] = {-1, -1, -1};
+      for (int r = 0; r < 3; ++r) {
+        int best = 0, bc = 0;
+        for (int sz = 1; sz <= 32; ++sz)
+          if (hist[sz] > bc && sz != used[0] && sz != used[1]) best = sz, bc = hist[sz];
+        out[r] = best;
+        used[r] = best ? best : -1;
+      }
+    };
+    top3(E->cls_host_hist, E->cls_m);
+    top3(E->cls_host_hist + 33, E->cls_n);
+    top3(E->cls_host_hist + 66, E->cls_k);
+    E->cls_mode = E->cls_m[0] > 0 && E->cls_n[0] > 0 && E->cls_k[0] > 0;
+  }
   // processing order of the numeric phase: column panels sized for the Infinity Cache, rows dealt to XCDs
   const int64_t b_bytes_est = b->nblks * (int64_t)E->max_k * E->max_n * (int64_t)sizeof(double);
   int NP = (int)std::min<int64_t>((b_bytes_est + E->panel_bytes - 1) / E->panel_bytes, (int64_t)W);
@@ -2296,11 +2431,25 @@ int dbcsr_amd_mm_symbolic_filtered(void* handle, libsmm_acc_data_t datatype, dou
   int RG = E->row_group > 0 ? E->row_group : 1;
   RG = std::max(1, std::min(RG, R));
   const int NG = (R + RG - 1) / RG;
-  const int nkeys = 8 * NP * NG;
+  const int nkeys = (E->cls_mode ? kNumClasses : 1) * 8 * NP * (E->cls_mode ? R : NG);
   if (E->order_cnt.ensure((size_t)nkeys + 1) || E->order_base.ensure((size_t)nkeys + 1)) return -1;
+  if (E->cls_mode) {
+    if (E->cls_row.ensure((size_t)nbr + 1) || E->cls_col.ensure((size_t)nbc + 1) || E->cls_col_bm.ensure((size_t)4 * W + 1) ||
+        E->cls_lens.ensure(2 * kNumClasses + 1))
+      return -1;
+    hipLaunchKernelGGL(class_ids, grid_for(nbr), dim3(256), 0, st, a->row_blk_size, nbr, E->cls_m[0], E->cls_m[1], E->cls_m[2], E->cls_row.p);
+    hipLaunchKernelGGL(class_ids, grid_for(nbc), dim3(256), 0, st, b->col_blk_size, nbc, E->cls_n[0], E->cls_n[1], E->cls_n[2], E->cls_col.p);
+    hipLaunchKernelGGL(class_col_bitmaps, grid_for(W), dim3(256), 0, st, E->cls_col.p, nbc, W, E->cls_col_bm.p);
+    hipLaunchKernelGGL(order_count_cls, grid_for(nkeys), dim3(256), 0, st, E->c_bm.p, E->cls_row.p, E->cls_col_bm.p, nbr, W, PW, NP, R,
+                       E->order_cnt.p);
+    if (exclusive_scan<int64_t>(E, E->order_cnt.p, nkeys, E->order_base.p, nullptr, false, st)) return -1;
+    hipLaunchKernelGGL(order_len_cls, dim3(1), dim3(1), 0, st, E->order_base.p, c_nblks, NP, R, E->cls_lens.p);
+    ACC_CHECK(hipMemcpyAsync(E->cls_host_lens, E->cls_lens.p, (2 * kNumClasses + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+  } else {
   hipLaunchKernelGGL(order_count, grid_for(nkeys), dim3(256), 0, st, E->c_pre.p, E->row_nnz.p, nbr, W, PW, NP, NG, RG, E->order_cnt.p);
   if (exclusive_scan<int64_t>(E, E->order_cnt.p, nkeys, E->order_base.p, nullptr, false, st)) return -1;
   hipLaunchKernelGGL(order_len, dim3(1), dim3(1), 0, st, E->order_base.p, c_nblks, NP, NG, dsc + 7);
+  }
   if (E->prod_cnt.ensure((size_t)c_nblks + 1) || E->blk_nze.ensure((size_t)c_nblks + 1) || E->prod_start.ensure((size_t)c_nblks + 1) ||
       E->c_blk_p_ws.ensure((size_t)c_nblks + 1))
     return -1;
@@ -2321,11 +2470,26 @@ int dbcsr_amd_mm_symbolic_filtered(void* handle, libsmm_acc_data_t datatype, dou
   ACC_CHECK(hipMemcpyAsync(E->host_scalars, dsc, 8 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
   ACC_CHECK(hipStreamSynchronize(st));
   E->order_len = E->host_scalars[7];
+  if (E->cls_mode) {
+    for (int c = 0; c < kNumClasses; ++c) {
+      E->cls_len[c] = E->cls_host_lens[c];
+      E->cls_off[c] = E->cls_host_lens[kNumClasses + c];
+    }
+    const int64_t total = E->cls_host_lens[2 * kNumClasses];
+    E->order_len = total / 8;  // (only its product with 8 is used below: the size of order[])
+    if (E->order.ensure((size_t)total + 64)) return -1;
+    if (total > 0) {
+      ACC_CHECK(hipMemsetAsync(E->order.p, 0xff, sizeof(int) * ((size_t)total + 64), st));
+      hipLaunchKernelGGL(order_fill_cls, grid_for((int64_t)nbr * W), dim3(256), 0, st, E->c_bm.p, E->c_pre.p, c_out_row_p, E->cls_row.p,
+                         E->cls_col_bm.p, E->order_base.p, E->cls_lens.p, nbr, W, PW, NP, R, E->order.p);
+    }
+  } else {
   if (E->order.ensure((size_t)(8 * E->order_len) + 64)) return -1;
   if (E->order_len > 0) {
     ACC_CHECK(hipMemsetAsync(E->order.p, 0xff, sizeof(int) * ((size_t)(8 * E->order_len) + 64), st));  // padding included
     hipLaunchKernelGGL(order_fill, grid_for((int64_t)nbr * W), dim3(256), 0, st, E->c_bm.p, E->c_pre.p, E->row_nnz.p, c_out_row_p,
                        E->order_base.p, nbr, W, PW, NP, NG, RG, E->order_len, E->order.p);
+  }
   }
   counts->c_nblks = E->host_scalars[0];
   counts->c_nze = E->host_scalars[1];
@@ -2380,6 +2544,51 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
       hipLaunchKernelGGL(mm_numeric_f64_tiny, dim3(nwg_t), dim3(256), 0, st, E->descs.p, nblk, E->entries.p,
                          static_cast<const double*>(a->data), static_cast<const double*>(b->data), static_cast<double*>(c_out->data),
                          static_cast<const double*>(c_in->data), alpha, beta, skip_empty, E->order.p);
+    } else if (small && E->use_lds && E->cls_mode) {
+      // one launch per (m, n) class on its segment of order[]: the run-time compiled exact-size kernel of the class
+      // (mm_exact.h, mm_jit.hip), the generic LDS kernel for class 9 (other sizes) and for classes hiprtc could not serve
+      const int g_lds_a = (E->max_m * ((E->max_k + 3) & ~3) + 1) & ~1, g_lds_b = ((E->max_k * E->max_n + 127) / 128) * 128;
+      const int g_lds_wave = g_lds_a + g_lds_b;
+      const int g_maxt = (std::max(E->max_m, E->max_n) + 7) / 8;
+      const int dbgv = E->dbg | (skip_empty ? 32 : 0);
+      int njit = 0, ngen = 0;
+      for (int c = 0; c < kNumClasses; ++c) {
+        if (E->cls_len[c] == 0) continue;
+        const int* ord = E->order.p + E->cls_off[c];
+        const unsigned nwg_c = (unsigned)(8 * E->cls_len[c] / 4);
+        ClassKernel ck;
+        const int cm = c < 9 ? E->cls_m[c / 3] : 0, cn = c < 9 ? E->cls_n[c % 3] : 0;
+        if (c < 9 && cm > 0 && cn > 0 && jit_class_kernel(cm, cn, E->cls_k[0], E->cls_k[1], E->cls_k[2], &ck) == 0) {
+          const Desc* p_descs = E->descs.p;
+          long p_nblk = (long)nblk;
+          const Entry* p_entries = E->entries.p;
+          const double* p_a = static_cast<const double*>(a->data);
+          const double* p_b = static_cast<const double*>(b->data);
+          double* p_c = static_cast<double*>(c_out->data);
+          const double* p_ci = static_cast<const double*>(c_in->data);
+          double p_alpha = alpha, p_beta = beta;
+          int p_skip = skip_empty;
+          void* args[] = {&p_descs, &p_nblk, &p_entries, &p_a, &p_b, &p_c, &p_ci, &p_alpha, &p_beta, &p_skip, &ord};
+          ACC_CHECK(hipModuleLaunchKernel(ck.fn, nwg_c, 1, 1, 256, 1, 1, (unsigned)(4 * ck.wave_lds), st, args, nullptr));
+          ++njit;
+        } else {
+          const size_t lb = (size_t)4 * g_lds_wave * sizeof(double);
+#define DBCSR_LAUNCH_G(T_)                                                                                                         \
+  hipLaunchKernelGGL(mm_numeric_f64_lds<T_>, dim3(nwg_c), dim3(256), lb, st, E->descs.p, nblk, E->entries.p,                         \
+                     static_cast<const double*>(a->data), static_cast<const double*>(b->data), static_cast<double*>(c_out->data),   \
+                     static_cast<const double*>(c_in->data), alpha, beta, g_lds_a, g_lds_wave, dbgv, ord)
+          switch (g_maxt) {
+            case 1: DBCSR_LAUNCH_G(1); break;
+            case 2: DBCSR_LAUNCH_G(2); break;
+            case 3: DBCSR_LAUNCH_G(3); break;
+            default: DBCSR_LAUNCH_G(4); break;
+          }
+#undef DBCSR_LAUNCH_G
+          ++ngen;
+        }
+      }
+      snprintf(E->last_kernel, sizeof E->last_kernel, "mm_numeric_f64_class[%d jit + %d generic launches; m {%d,%d,%d} n {%d,%d,%d} k {%d,%d,%d}]", njit,
+               ngen, E->cls_m[0], E->cls_m[1], E->cls_m[2], E->cls_n[0], E->cls_n[1], E->cls_n[2], E->cls_k[0], E->cls_k[1], E->cls_k[2]);
     } else if (small && E->use_lds) {
       // per-wave LDS slice.  Staging writes whole 1 KiB chunks (128 doubles), A's chunks first, then B's: the B part may
       // start right after A's (zero-padded) block -- the tail of A's last chunk is simply overwritten by B's first chunk
@@ -2444,7 +2653,15 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
     }
   } else {
     const bool small32 = E->max_m <= 32 && E->max_k <= 32 && E->max_n <= 32 && E->min_m >= 1 && E->min_k >= 1 && E->min_n >= 1;
-    if (small32 && E->use_lds) {
+    if (small32 && E->use_lds && E->cls_mode) {
+      for (int c = 0; c < kNumClasses; ++c) {
+        if (E->cls_len[c] == 0) continue;
+        hipLaunchKernelGGL(mm_numeric_f32_lds, dim3((unsigned)(8 * E->cls_len[c] / 4)), dim3(256), 0, st, E->descs.p, nblk, E->entries.p,
+                           static_cast<const float*>(a->data), static_cast<const float*>(b->data), static_cast<float*>(c_out->data),
+                           static_cast<const float*>(c_in->data), (float)alpha, (float)beta, skip_empty, E->order.p + E->cls_off[c]);
+      }
+      snprintf(E->last_kernel, sizeof E->last_kernel, "mm_numeric_f32_lds[per class segment]");
+    } else if (small32 && E->use_lds) {
       const unsigned nwg_o = (unsigned)(8 * E->order_len / 4);
       if (E->use_hot && E->hot_m > 0 &&
           launch_hot_f32(E->hot_m, E->hot_n, E->hot_k, dim3(nwg_o), st, E->descs.p, nblk, E->entries.p, static_cast<const float*>(a->data),

@@ -1,0 +1,20 @@
+// mm_jit.h -- run-time compilation (hiprtc) of the exact-size class kernels of mm_exact.h, cached per process.
+// The reference does the same per (m, n, k) triple (src/acc/libsmm_acc/libsmm_acc.cpp:90-195, ~0.5 s per kernel there).
+#ifndef DBCSR_AMD_MM_JIT_H
+#define DBCSR_AMD_MM_JIT_H
+#include <hip/hip_runtime.h>
+
+namespace dbcsr_amd {
+
+struct ClassKernel {
+  hipFunction_t fn = nullptr;
+  int wave_lds = 0;  // LDS bytes per wave (4 waves per workgroup)
+};
+
+// 0 on success; the kernel for C blocks of m x n whose products have inner sizes k0, k1, k2 (0 = absent, k0 > 0).
+// Thread-safe; compiles on first use (~1 s), then served from the cache.  Non-zero when hiprtc is unavailable or fails
+// (the caller then runs the generic kernel on that class).
+int jit_class_kernel(int m, int n, int k0, int k1, int k2, ClassKernel* out);
+
+}  // namespace dbcsr_amd
+#endif

@@ -1,0 +1,131 @@
+// mm_jit.hip -- hiprtc front end for mm_exact.h (see mm_jit.h).  libhiprtc is opened lazily: a process that never meets a
+// mixed-size multiply does not load it.
+#include "mm_jit.h"
+
+#include <dlfcn.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "mm_exact.h"  // class_wave_lds(): the same constexpr function the kernel sizes its LDS slice with
+
+namespace dbcsr_amd {
+namespace {
+
+#include "jit_sources.inc"  // kJitSrc_mm_types, kJitSrc_smm_core, kJitSrc_mm_exact: the texts of the three headers
+
+typedef struct _hiprtcProgram* rtc_program;
+struct Rtc {
+  void* lib = nullptr;
+  int (*CreateProgram)(rtc_program*, const char*, const char*, int, const char**, const char**) = nullptr;
+  int (*CompileProgram)(rtc_program, int, const char**) = nullptr;
+  int (*GetProgramLogSize)(rtc_program, size_t*) = nullptr;
+  int (*GetProgramLog)(rtc_program, char*) = nullptr;
+  int (*GetCodeSize)(rtc_program, size_t*) = nullptr;
+  int (*GetCode)(rtc_program, char*) = nullptr;
+  int (*DestroyProgram)(rtc_program*) = nullptr;
+  bool ok = false;
+};
+
+Rtc& rtc() {
+  static Rtc r;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    for (const char* name : {"libhiprtc.so", "libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so"}) {
+      r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (r.lib) break;
+    }
+    if (!r.lib) {
+      fprintf(stderr, "dbcsr_amd: cannot load libhiprtc (%s): mixed block sizes run the generic kernels\n", dlerror());
+      return;
+    }
+#define DBCSR_SYM(field, sym)                               \
+  *reinterpret_cast<void**>(&r.field) = dlsym(r.lib, sym);  \
+  if (!r.field) return;
+    DBCSR_SYM(CreateProgram, "hiprtcCreateProgram")
+    DBCSR_SYM(CompileProgram, "hiprtcCompileProgram")
+    DBCSR_SYM(GetProgramLogSize, "hiprtcGetProgramLogSize")
+    DBCSR_SYM(GetProgramLog, "hiprtcGetProgramLog")
+    DBCSR_SYM(GetCodeSize, "hiprtcGetCodeSize")
+    DBCSR_SYM(GetCode, "hiprtcGetCode")
+    DBCSR_SYM(DestroyProgram, "hiprtcDestroyProgram")
+#undef DBCSR_SYM
+    r.ok = true;
+  });
+  return r;
+}
+
+struct Cached {
+  hipModule_t mod = nullptr;
+  ClassKernel k;
+  bool failed = false;
+};
+std::mutex g_mu;
+std::map<std::tuple<int, int, int, int, int, int>, Cached> g_cache;  // (device, m, n, k0, k1, k2)
+
+}  // namespace
+
+int jit_class_kernel(int m, int n, int k0, int k1, int k2, ClassKernel* out) {
+  if (!out || m < 1 || n < 1 || k0 < 1 || m > 32 || n > 32 || k0 > 32 || k1 > 32 || k2 > 32) return -1;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return -1;
+  std::lock_guard<std::mutex> lock(g_mu);
+  auto key = std::make_tuple(dev, m, n, k0, k1, k2);
+  auto it = g_cache.find(key);
+  if (it != g_cache.end()) {
+    if (it->second.failed) return -1;
+    *out = it->second.k;
+    return 0;
+  }
+  Cached& c = g_cache[key];
+  c.failed = true;
+  Rtc& r = rtc();
+  if (!r.ok) return -1;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+  const int wave_lds = class_wave_lds(m, n, k0, k1, k2);
+  // waves per SIMD the LDS allows (4 waves per workgroup, 160 KiB per CU): the register allocation is asked to allow as many
+  int wgs = (160 * 1024) / (4 * wave_lds);
+  int minw = wgs > 4 ? 4 : (wgs < 1 ? 1 : wgs);
+  char defs[512];
+  snprintf(defs, sizeof defs,
+           "#define DBCSR_AMD_JIT_M %d\n#define DBCSR_AMD_JIT_N %d\n#define DBCSR_AMD_JIT_K0 %d\n#define DBCSR_AMD_JIT_K1 %d\n"
+           "#define DBCSR_AMD_JIT_K2 %d\n#define DBCSR_AMD_JIT_MINW %d\n#include \"mm_exact.h\"\n",
+           m, n, k0, k1, k2, minw);
+  const char* hsrc[] = {kJitSrc_mm_types, kJitSrc_smm_core, kJitSrc_mm_exact};
+  const char* hname[] = {"mm_types.h", "smm_core.h", "mm_exact.h"};
+  rtc_program prog = nullptr;
+  if (r.CreateProgram(&prog, defs, "mm_class.hip", 3, hsrc, hname) != 0) return -1;
+  std::string arch = std::string("--offload-arch=") + prop.gcnArchName;
+  const char* opts[] = {arch.c_str(), "-O3", "-std=c++17"};
+  const int rc = r.CompileProgram(prog, 3, opts);
+  if (rc != 0) {
+    size_t ls = 0;
+    r.GetProgramLogSize(prog, &ls);
+    std::string log(ls + 1, 0);
+    if (ls) r.GetProgramLog(prog, &log[0]);
+    fprintf(stderr, "dbcsr_amd: hiprtc failed for class (%d, %d; %d, %d, %d):\n%s\n", m, n, k0, k1, k2, log.c_str());
+    r.DestroyProgram(&prog);
+    return -1;
+  }
+  size_t cs = 0;
+  r.GetCodeSize(prog, &cs);
+  std::vector<char> code(cs);
+  r.GetCode(prog, code.data());
+  r.DestroyProgram(&prog);
+  if (hipModuleLoadData(&c.mod, code.data()) != hipSuccess) return -1;
+  if (hipModuleGetFunction(&c.k.fn, c.mod, "mm_numeric_f64_class") != hipSuccess) return -1;
+  c.k.wave_lds = wave_lds;
+  c.failed = false;
+  if (getenv("DBCSR_AMD_MM_VERBOSE")) fprintf(stderr, "dbcsr_amd: compiled class kernel (%d, %d; %d, %d, %d), %zu bytes, %d B LDS per wave\n", m, n, k0, k1, k2, cs, wave_lds);
+  *out = c.k;
+  return 0;
+}
+
+}  // namespace dbcsr_amd

@@ -23,8 +23,10 @@
 #ifndef DBCSR_AMD_SMM_CORE_H
 #define DBCSR_AMD_SMM_CORE_H
 
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#endif
 
 namespace dbcsr_amd {
 

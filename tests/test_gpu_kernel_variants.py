@@ -16,6 +16,8 @@ pytestmark = pytest.mark.gpu
 MIXED = (300, 280, 260, 0.5, 0.5, 0.6, [1, 13, 1, 23, 1, 32, 1, 7], [1, 23, 1, 5, 1, 32], [1, 13, 1, 32, 1, 9])
 H2O = (23 * 20 + 16, 23 * 18 + 16, 23 * 22 + 16, 0.6, 0.6, 0.7, [1, 23], [1, 23], [1, 23])
 TINY = (240, 240, 240, 0.7, 0.7, 0.7, [1, 4], [1, 4, 1, 3], [1, 4, 1, 2])
+CONFIG3 = (68 * 9 + 24, 68 * 8 + 24, 68 * 10 + 24, 0.8, 0.8, 0.8, [1, 13, 1, 23, 1, 32], [1, 13, 1, 23, 1, 32], [1, 13, 1, 23, 1, 32])
+POW2 = (16 * 20 + 9, 32 * 10 + 5, 16 * 18 + 3, 0.6, 0.6, 0.6, [1, 16, 1, 32], [1, 32, 1, 16, 1, 8], [1, 16, 1, 32, 1, 24])  # padded LDS pitches
 BIG = (300, 270, 280, 0.5, 0.5, 0.5, [1, 45, 1, 13], [1, 67, 1, 5], [1, 40, 1, 23])
 
 # (environment, case, expected kernel-name prefix)
@@ -35,11 +37,16 @@ VARIANTS = [
     ({"DBCSR_AMD_MM_TINY": "0", "DBCSR_AMD_MM_KERNEL": "pipe"}, TINY, "mm_numeric_f64_pipe<1>"),
     ({}, BIG, "mm_numeric_f64"),
     ({"DBCSR_AMD_MM_SYMBOLIC": "word"}, MIXED, "mm_numeric_f64"),
+    # (m, n) classes with run-time compiled exact-size kernels (forced: the cases are far below the automatic threshold)
+    ({"DBCSR_AMD_MM_CLASSES": "2"}, MIXED, "mm_numeric_f64_class["),
+    ({"DBCSR_AMD_MM_CLASSES": "2"}, H2O, "mm_numeric_f64_class["),
+    ({"DBCSR_AMD_MM_CLASSES": "2"}, CONFIG3, "mm_numeric_f64_class["),
+    ({"DBCSR_AMD_MM_CLASSES": "2"}, POW2, "mm_numeric_f64_class["),
 ]
 
 
 def run_case(monkeypatch, env, case, dtype, tol, expect, alpha=0.7, beta=1.3, retain=False, in_place_twice=False):
-    for k in ("DBCSR_AMD_MM_KERNEL", "DBCSR_AMD_MM_HOT", "DBCSR_AMD_MM_TINY", "DBCSR_AMD_MM_PIPE_G", "DBCSR_AMD_MM_SYMBOLIC"):
+    for k in ("DBCSR_AMD_MM_KERNEL", "DBCSR_AMD_MM_HOT", "DBCSR_AMD_MM_TINY", "DBCSR_AMD_MM_PIPE_G", "DBCSR_AMD_MM_SYMBOLIC", "DBCSR_AMD_MM_CLASSES"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -69,7 +76,7 @@ def test_fp64_variant_matches_oracle(monkeypatch, env, case, expect):
     run_case(monkeypatch, env, case, np.float64, 1e-10, expect)
 
 
-@pytest.mark.parametrize("env,case,expect", [v for v in VARIANTS if v[1] in (H2O, MIXED)][:9],
+@pytest.mark.parametrize("env,case,expect", [v for v in VARIANTS if v[1] in (H2O, MIXED)][:9] + [v for v in VARIANTS if "DBCSR_AMD_MM_CLASSES" in v[0]],
                          ids=lambda v: "-".join("%s=%s" % (k[13:], x) for k, x in v.items()) if isinstance(v, dict) else None)
 def test_fp64_variant_retain_and_in_place(monkeypatch, env, case, expect):
     run_case(monkeypatch, env, case, np.float64, 1e-10, expect, alpha=1.0, beta=1.0, retain=True, in_place_twice=True)
@@ -86,6 +93,7 @@ F32_MIXED = (300, 280, 260, 0.5, 0.5, 0.6, [1, 13, 1, 32, 1, 7], [1, 23, 1, 32],
     ({}, F32_MIXED, "mm_numeric_f32_lds"),
     ({"DBCSR_AMD_MM_KERNEL": "direct"}, F32_MIXED, "mm_numeric_f32"),
     ({}, BIG, "mm_numeric_f32"),
+    ({"DBCSR_AMD_MM_CLASSES": "2"}, F32_MIXED, "mm_numeric_f32_lds[per class"),
 ], ids=lambda v: "-".join("%s=%s" % (k[13:], x) for k, x in v.items()) if isinstance(v, dict) else None)
 def test_fp32_variant_matches_oracle(monkeypatch, env, case, expect):
     run_case(monkeypatch, env, case, np.float32, 2e-5, expect, alpha=1.0, beta=1.0)
