@@ -20,6 +20,18 @@
 #include "mm_types.h"
 #include "smm_core.h"
 
+// Tuning switches (run-time compiled kernels take them from DBCSR_AMD_JIT_DEFS, e.g. "-DDBCSR_EXACT_ALL_PIECES=1"):
+//  DBCSR_EXACT_ALL_PIECES   1: every product issues the loads / LDS copies of the LARGEST inner size of the class (pieces past
+//                              the block's end are bounds-checked away and copy zeros): no wave-uniform branches in the staging
+//                              code; 0: piece counts follow the product's inner size (one scalar branch per piece)
+//  DBCSR_EXACT_SCHED_BARRIER 1: scheduling barrier after every k step of the multiply (bounds the live fragment registers)
+#ifndef DBCSR_EXACT_ALL_PIECES
+#define DBCSR_EXACT_ALL_PIECES 0
+#endif
+#ifndef DBCSR_EXACT_SCHED_BARRIER
+#define DBCSR_EXACT_SCHED_BARRIER 1
+#endif
+
 namespace dbcsr_amd {
 
 template <int LD>
@@ -37,7 +49,7 @@ struct IntC {
 // LDS bytes one wave needs for class (m, n) with inner sizes k0, k1, k2 (0 = absent): also evaluated at run time by the host
 // (mm_jit.hip) to size the launch
 constexpr int class_wave_lds(int m, int n, int k0, int k1, int k2) {
-  int a_lds = 0, cb_max = 0;
+  int a_lds = 0, cb_max = 0, bpad = 0;
   const int ks[3] = {k0, k1, k2};
   for (int i = 0; i < 3; ++i) {
     const int k = ks[i];
@@ -45,10 +57,13 @@ constexpr int class_wave_lds(int m, int n, int k0, int k1, int k2) {
     const int k4 = 4 * ((k + 3) / 4), ap = m + ((m % 16 == 0) ? 2 : 0);
     a_lds = cmax(a_lds, ap * k4 * 8);
     cb_max = cmax(cb_max, (k * n * 8 + 1023) / 1024);
+    if (k % 16 == 0) bpad = 128;
   }
   a_lds = (a_lds + 15) & ~15;
   const int c_lds = ((m * n * 8 + 1023) / 1024) * 1024;
-  return (cmax(a_lds + cb_max * 1024 + 16 * n + 16, c_lds) + 15) & ~15;
+  // B is written in whole 1 KiB pieces; with a padded pitch (columns of 16 or 32 elements) a piece spans up to 8 columns,
+  // each shifted by 16 bytes more than the one before: 128 extra bytes per piece at most
+  return (cmax(a_lds + cb_max * (1024 + bpad) + 16, c_lds) + 15) & ~15;
 }
 
 template <int M, int N, int K>
@@ -71,7 +86,8 @@ struct ClassShape {
   static constexpr int CBMAX = cmax(KShape<M, N, K0>::CB, cmax(KShape<M, N, K1>::CB, KShape<M, N, K2>::CB));
   // B is written in whole 1 KiB pieces (plus the pitch padding of its columns); A's last piece may spill into B's region,
   // which is harmless: B's pieces are stored after A's (one wave, in-order LDS queue)
-  static constexpr int B_REGION = CBMAX * 1024 + 16 * N + 16;
+  static constexpr int BPAD = ((K0 % 16 == 0) || (K1 != 0 && K1 % 16 == 0) || (K2 != 0 && K2 % 16 == 0)) ? 128 : 0;
+  static constexpr int B_REGION = CBMAX * (1024 + BPAD) + 16;
   static constexpr int C_LDS = ((M * N * 8 + 1023) / 1024) * 1024;
   static constexpr int WAVE_LDS = (cmax(A_LDS + B_REGION, C_LDS) + 15) & ~15;
   static_assert(WAVE_LDS == class_wave_lds(M, N, K0, K1, K2), "host and device disagree on the LDS size of a class");
@@ -160,22 +176,22 @@ __device__ __forceinline__ void cblock_f64_classes(const Desc& d, const Entry* _
     const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)(b_data + en.b_off()), 0, bbytes, 0x00020000);
 #pragma unroll
     for (int c = 0; c < CS::CAMAX; ++c)
-      if (c < nca) ra[c] = __builtin_amdgcn_raw_buffer_load_b128(rsa, voff, c * 1024, 0);
+      if (DBCSR_EXACT_ALL_PIECES || c < nca) ra[c] = __builtin_amdgcn_raw_buffer_load_b128(rsa, voff, c * 1024, 0);
 #pragma unroll
     for (int c = 0; c < CS::CBMAX; ++c)
-      if (c < ncb) rb[c] = __builtin_amdgcn_raw_buffer_load_b128(rsb, voff, c * 1024, 0);
+      if (DBCSR_EXACT_ALL_PIECES || c < ncb) rb[c] = __builtin_amdgcn_raw_buffer_load_b128(rsb, voff, c * 1024, 0);
   };
   auto store = [&](int ks) {
     const int nca = __builtin_amdgcn_readfirstlane((M * ((ks + 3) & ~3) * 8 + 1023) >> 10);
     const int ncb = __builtin_amdgcn_readfirstlane((ks * N * 8 + 1023) >> 10);
 #pragma unroll
     for (int c = 0; c < CS::CAMAX; ++c)
-      if (c < nca) *reinterpret_cast<u32x4*>(lds_a + staged_offset<M>(c, lane)) = ra[c];
+      if (DBCSR_EXACT_ALL_PIECES || c < nca) *reinterpret_cast<u32x4*>(lds_a + staged_offset<M>(c, lane)) = ra[c];
     // B's columns have ks elements: padded pitch when ks is a multiple of 16 (then ks is 16 or 32 and divides 128)
     const int sh = __builtin_amdgcn_readfirstlane((ks & 15) == 0 ? (ks == 16 ? 4 : 5) : 31);
 #pragma unroll
     for (int c = 0; c < CS::CBMAX; ++c)
-      if (c < ncb) *reinterpret_cast<u32x4*>(lds_b + c * 1024 + lane * 16 + 16 * ((c * 128 + lane * 2) >> sh)) = rb[c];
+      if (DBCSR_EXACT_ALL_PIECES || c < ncb) *reinterpret_cast<u32x4*>(lds_b + c * 1024 + lane * 16 + 16 * ((c * 128 + lane * 2) >> sh)) = rb[c];
   };
   auto compute_k = [&](auto kc) {
     constexpr int K = decltype(kc)::value;
@@ -207,7 +223,7 @@ __device__ __forceinline__ void cblock_f64_classes(const Desc& d, const Entry* _
       for (int a = 0; a < MA; ++a)
 #pragma unroll
         for (int c = 0; c < NC; ++c) acc[a][c] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[s & 1][a], bv[s & 1][c], acc[a][c], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
+      if (DBCSR_EXACT_SCHED_BARRIER) __builtin_amdgcn_sched_barrier(0);
     }
   };
 

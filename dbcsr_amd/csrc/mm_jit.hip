@@ -103,8 +103,22 @@ int jit_class_kernel(int m, int n, int k0, int k1, int k2, ClassKernel* out) {
   rtc_program prog = nullptr;
   if (r.CreateProgram(&prog, defs, "mm_class.hip", 3, hsrc, hname) != 0) return -1;
   std::string arch = std::string("--offload-arch=") + prop.gcnArchName;
-  const char* opts[] = {arch.c_str(), "-O3", "-std=c++17"};
-  const int rc = r.CompileProgram(prog, 3, opts);
+  // DBCSR_AMD_JIT_DEFS: extra -D switches for the kernel text (tuning experiments, see mm_exact.h), space separated
+  std::vector<std::string> extra;
+  if (const char* d = getenv("DBCSR_AMD_JIT_DEFS")) {
+    std::string all(d);
+    size_t pos = 0;
+    while (pos < all.size()) {
+      const size_t e = all.find(' ', pos);
+      const std::string tok = all.substr(pos, e == std::string::npos ? std::string::npos : e - pos);
+      if (!tok.empty()) extra.push_back(tok);
+      if (e == std::string::npos) break;
+      pos = e + 1;
+    }
+  }
+  std::vector<const char*> opts = {arch.c_str(), "-O3", "-std=c++17"};
+  for (const std::string& t : extra) opts.push_back(t.c_str());
+  const int rc = r.CompileProgram(prog, (int)opts.size(), opts.data());
   if (rc != 0) {
     size_t ls = 0;
     r.GetProgramLogSize(prog, &ls);
