@@ -1773,6 +1773,60 @@ __global__ void __launch_bounds__(256) transpose_sizes(const uint32_t* __restric
 }
 
 
+// ---- desymmetrize (dbcsr_desymmetrize_deep, what make_images does to a symmetric operand: src/mm/dbcsr_mm_cannon.F:284,
+// 351-379): a symmetric / antisymmetric matrix stores one triangle; the full matrix has block (c, r) = +-block (r, c)^T too
+__global__ void __launch_bounds__(256) desym_mark(const int* __restrict__ s_row_p, const int* __restrict__ s_col_i, int nbr, int W,
+                                                  uint32_t* __restrict__ bm) {
+  const int lane = threadIdx.x & 63;
+  const int r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (r >= nbr) return;
+  for (int b = s_row_p[r] + lane; b < s_row_p[r + 1]; b += 64) {
+    const int c = s_col_i[b];
+    atomicOr(&bm[(size_t)r * W + (c >> 5)], 1u << (c & 31));
+    atomicOr(&bm[(size_t)c * W + (r >> 5)], 1u << (r & 31));
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+desym_fill(const int* __restrict__ s_row_p, const int* __restrict__ s_col_i, const int64_t* __restrict__ s_blk_p, const T* __restrict__ s_data,
+           const int* __restrict__ sizes, const uint32_t* __restrict__ bm, const int* __restrict__ pre, const int* __restrict__ d_row_p,
+           const int64_t* __restrict__ d_blk_p_ws, int nbr, int W, T sign, int* __restrict__ d_col_i, int64_t* __restrict__ d_blk_p,
+           T* __restrict__ d_data) {
+  const int lane = threadIdx.x & 63;
+  const int r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (r >= nbr) return;
+  const int m = sizes[r];
+  auto slot = [&](int row, int col) {
+    const uint32_t wv = bm[(size_t)row * W + (col >> 5)];
+    return d_row_p[row] + pre[(size_t)row * W + (col >> 5)] + __popc(wv & ((1u << (col & 31)) - 1u));
+  };
+  for (int b = s_row_p[r]; b < s_row_p[r + 1]; ++b) {
+    const int c = s_col_i[b];
+    const int n = sizes[c];
+    const T* src = s_data + s_blk_p[b];
+    const int t0 = slot(r, c);
+    if (lane == 0) {
+      d_col_i[t0] = c;
+      d_blk_p[t0] = d_blk_p_ws[t0];
+    }
+    T* d0 = d_data + d_blk_p_ws[t0];
+    for (int e = lane; e < m * n; e += 64) d0[e] = src[e];
+    if (c != r) {
+      const int t1 = slot(c, r);
+      if (lane == 0) {
+        d_col_i[t1] = r;
+        d_blk_p[t1] = d_blk_p_ws[t1];
+      }
+      T* d1 = d_data + d_blk_p_ws[t1];
+      for (int e = lane; e < m * n; e += 64) {
+        const int i = e % m, j = e / m;  // src(i, j) -> dst(j, i), dst is n x m
+        d1[j + (size_t)n * i] = sign * src[e];
+      }
+    }
+  }
+}
+
 // ---- block filter (dbcsr_mm_multrec.F:694-748 multrec_filtering / dbcsr_filter): drop blocks with ||blk||^2 < eps^2
 __global__ void __launch_bounds__(256) filter_flags(const double* __restrict__ norms64, int64_t nblks, const int* __restrict__ row_p,
                                                     const int* __restrict__ col_i, const int* __restrict__ rs, const int* __restrict__ cs,
@@ -2942,6 +2996,54 @@ int dbcsr_amd_bcsr_transpose(void* handle, libsmm_acc_data_t datatype, const dbc
   }
   dst->nblks = src->nblks;
   return check(hipGetLastError(), "dbcsr_amd_bcsr_transpose", __FILE__, __LINE__);
+}
+
+int dbcsr_amd_bcsr_desymmetrize_count(void* handle, const dbcsr_amd_bcsr* src, int32_t* dst_row_p, int64_t* nblks, int64_t* nze, void* stream) {
+  Engine* E = static_cast<Engine*>(handle);
+  if (!E || !src || !dst_row_p || !nblks || !nze || src->nblkrows != src->nblkcols) return -1;
+  hipStream_t st = stream_of(stream);
+  const int nbr = src->nblkrows, W = (nbr + 31) / 32;
+  E->valid = false;  // shares workspace with the symbolic phase
+  *nblks = *nze = 0;
+  if (nbr == 0) return 0;
+  if (E->c_bm.ensure((size_t)nbr * W + 1) || E->c_pre.ensure((size_t)nbr * W + 1) || E->row_nnz.ensure((size_t)nbr + 1) ||
+      E->blk_nze.ensure(2 * (size_t)src->nblks + 1) || E->c_blk_p_ws.ensure(2 * (size_t)src->nblks + 1) || E->dev_scalars.ensure(16))
+    return -1;
+  int64_t* dsc = reinterpret_cast<int64_t*>(E->dev_scalars.p);
+  ACC_CHECK(hipMemsetAsync(E->c_bm.p, 0, sizeof(uint32_t) * (size_t)nbr * W, st));
+  hipLaunchKernelGGL(desym_mark, grid_for((int64_t)nbr * 64), dim3(256), 0, st, src->row_p, src->col_i, nbr, W, E->c_bm.p);
+  hipLaunchKernelGGL(row_prefix, grid_for((int64_t)nbr * 64), dim3(256), 0, st, E->c_bm.p, nbr, W, E->c_pre.p, E->row_nnz.p);
+  if (exclusive_scan<int32_t>(E, E->row_nnz.p, nbr, dst_row_p, dsc + 0, true, st)) return -1;
+  // block sizes in index order (square matrix: the transposed-matrix helper with rows = columns = the same sizes)
+  hipLaunchKernelGGL(transpose_sizes, grid_for((int64_t)nbr * W), dim3(256), 0, st, E->c_bm.p, E->c_pre.p, dst_row_p, src->row_blk_size,
+                     src->col_blk_size, nbr, W, E->blk_nze.p);
+  ACC_CHECK(hipMemcpyAsync(E->host_scalars, dsc, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+  ACC_CHECK(hipStreamSynchronize(st));
+  *nblks = E->host_scalars[0];
+  if (exclusive_scan<int64_t>(E, E->blk_nze.p, *nblks, E->c_blk_p_ws.p, dsc + 1, false, st)) return -1;
+  ACC_CHECK(hipMemcpyAsync(E->host_scalars, dsc, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+  ACC_CHECK(hipStreamSynchronize(st));
+  *nze = E->host_scalars[1];
+  return check(hipGetLastError(), "dbcsr_amd_bcsr_desymmetrize_count", __FILE__, __LINE__);
+}
+
+int dbcsr_amd_bcsr_desymmetrize_apply(void* handle, libsmm_acc_data_t datatype, const dbcsr_amd_bcsr* src, int antisymmetric, dbcsr_amd_bcsr* dst,
+                                      void* stream) {
+  Engine* E = static_cast<Engine*>(handle);
+  if (!E || !src || !dst || src->nblkrows != src->nblkcols) return -1;
+  if (datatype != dbcsr_type_real_8 && datatype != dbcsr_type_real_4) return -10;
+  hipStream_t st = stream_of(stream);
+  const int nbr = src->nblkrows, W = (nbr + 31) / 32;
+  if (nbr == 0 || src->nblks == 0) return 0;
+  if (datatype == dbcsr_type_real_8)
+    hipLaunchKernelGGL((desym_fill<double>), grid_for((int64_t)nbr * 64), dim3(256), 0, st, src->row_p, src->col_i, src->blk_p,
+                       static_cast<const double*>(src->data), src->row_blk_size, E->c_bm.p, E->c_pre.p, dst->row_p, E->c_blk_p_ws.p, nbr, W,
+                       antisymmetric ? -1.0 : 1.0, dst->col_i, dst->blk_p, static_cast<double*>(dst->data));
+  else
+    hipLaunchKernelGGL((desym_fill<float>), grid_for((int64_t)nbr * 64), dim3(256), 0, st, src->row_p, src->col_i, src->blk_p,
+                       static_cast<const float*>(src->data), src->row_blk_size, E->c_bm.p, E->c_pre.p, dst->row_p, E->c_blk_p_ws.p, nbr, W,
+                       antisymmetric ? -1.0f : 1.0f, dst->col_i, dst->blk_p, static_cast<float*>(dst->data));
+  return check(hipGetLastError(), "dbcsr_amd_bcsr_desymmetrize_apply", __FILE__, __LINE__);
 }
 
 int dbcsr_amd_mm_stats(void* handle, dbcsr_amd_mnk_stat* out, int max_entries, int* n_entries, void* stream) {

@@ -31,7 +31,7 @@ MM_SYMBOLS = [
     "dbcsr_amd_bcsr_checksum", "dbcsr_amd_bcsr_fill_random", "dbcsr_amd_mm_kernel_name", "dbcsr_amd_mm_last_kernel", "dbcsr_amd_mm_stats", "dbcsr_amd_mm_timing", "dbcsr_amd_mm_init_c", "dbcsr_amd_bcsr_fill_random_dist",
     "dbcsr_amd_mm_symbolic_filtered", "dbcsr_amd_bcsr_filter_count", "dbcsr_amd_bcsr_filter_apply",
     "dbcsr_amd_bcsr_crop_count", "dbcsr_amd_bcsr_crop_apply", "dbcsr_amd_bcsr_scale_window",
-    "dbcsr_amd_multiply", "dbcsr_amd_bcsr_release",
+    "dbcsr_amd_multiply", "dbcsr_amd_bcsr_release", "dbcsr_amd_bcsr_desymmetrize_count", "dbcsr_amd_bcsr_desymmetrize_apply",
 ]
 
 
@@ -131,6 +131,8 @@ def load_library():
     L.dbcsr_amd_mm_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.dbcsr_amd_mm_kernel_name.argtypes = [i32]
     L.dbcsr_amd_mm_kernel_name.restype = C.c_char_p
+    L.dbcsr_amd_bcsr_desymmetrize_count.argtypes = [vp, BP, vp, C.POINTER(i64), C.POINTER(i64), vp]
+    L.dbcsr_amd_bcsr_desymmetrize_apply.argtypes = [vp, i32, BP, i32, BP, vp]
     L.dbcsr_amd_mm_stats.argtypes = [vp, C.POINTER(MnkStat), i32, C.POINTER(i32), vp]
     L.dbcsr_amd_comm_unique_id.argtypes = [C.c_char_p]
     L.dbcsr_amd_comm_create.argtypes = [C.POINTER(vp), C.c_char_p, i32, i32]

@@ -28,10 +28,13 @@ class StreamHandle:
 
 
 class DbcsrMatrix:
-    def __init__(self, row_blk_size, col_blk_size, row_p, col_i, blk_p, data, name=""):
+    def __init__(self, row_blk_size, col_blk_size, row_p, col_i, blk_p, data, name="", symmetry="N"):
         self.row_blk_size, self.col_blk_size = row_blk_size, col_blk_size
         self.row_p, self.col_i, self.blk_p, self.data = row_p, col_i, blk_p, data
         self.name = name
+        # matrix_type of the reference (src/core/dbcsr_types.F): 'N' no symmetry, 'S' symmetric, 'A' antisymmetric -- the latter
+        # two store one block per symmetric pair
+        self.symmetry = symmetry
 
     # -- construction -------------------------------------------------------
     @classmethod

@@ -202,6 +202,29 @@ class MultiplyEngine:
             raise RuntimeError("dbcsr_amd_bcsr_filter_apply failed (%d)" % rc)
         return out
 
+    def desymmetrized(self, M, stream=None):
+        """Full matrix of a symmetric ('S') / antisymmetric ('A') operand (dbcsr_desymmetrize_deep, done by the reference while
+        it builds the multiplication images, dbcsr_mm_cannon.F:284, 351-379)."""
+        if M.symmetry == "N":
+            return M
+        if M.symmetry not in ("S", "A"):
+            raise ValueError("unsupported matrix symmetry %r (real data: 'N', 'S', 'A')" % (M.symmetry,))
+        st = StreamHandle(stream)
+        src = M.desc()
+        row_p = torch.empty(M.nblkrows + 1, dtype=torch.int32, device=M.row_p.device)
+        nb, nz = C.c_int64(0), C.c_int64(0)
+        rc = self.L.dbcsr_amd_bcsr_desymmetrize_count(self.h, C.byref(src), row_p.data_ptr(), C.byref(nb), C.byref(nz), st.ptr)
+        if rc != 0:
+            raise RuntimeError("dbcsr_amd_bcsr_desymmetrize_count failed (%d)" % rc)
+        dev = M.row_p.device
+        out = DbcsrMatrix(M.row_blk_size, M.col_blk_size, row_p, torch.empty(nb.value, dtype=torch.int32, device=dev),
+                          torch.empty(nb.value, dtype=torch.int64, device=dev), torch.empty(nz.value, dtype=M.dtype, device=dev), M.name)
+        d = out.desc()
+        rc = self.L.dbcsr_amd_bcsr_desymmetrize_apply(self.h, M.dtype_code, C.byref(src), 1 if M.symmetry == "A" else 0, C.byref(d), st.ptr)
+        if rc != 0:
+            raise RuntimeError("dbcsr_amd_bcsr_desymmetrize_apply failed (%d)" % rc)
+        return out
+
     @staticmethod
     def empty_like(M):
         """C without any block, same block sizes (the product matrix after the reference has discarded it, dbcsr_mm.F:865-870)."""
@@ -327,6 +350,9 @@ def dbcsr_multiply(transa, transb, alpha, matrix_a, matrix_b, beta, matrix_c, fi
     if matrix_a.dtype != matrix_b.dtype or matrix_a.dtype != matrix_c.dtype:
         raise TypeError("dbcsr_multiply: data types of A, B and C differ")
     E = engine or default_engine()
+    if getattr(matrix_c, "symmetry", "N") != "N":
+        raise NotImplementedError("dbcsr_multiply: a symmetric product matrix is not supported (operands may be symmetric)")
+    matrix_a, matrix_b = E.desymmetrized(matrix_a), E.desymmetrized(matrix_b)
     A = E.transposed(matrix_a) if transa != "N" else matrix_a
     B = E.transposed(matrix_b) if transb != "N" else matrix_b
     if A.nblkcols != B.nblkrows or A.nblkrows != matrix_c.nblkrows or B.nblkcols != matrix_c.nblkcols:

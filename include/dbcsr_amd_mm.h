@@ -160,6 +160,15 @@ int dbcsr_amd_bcsr_release(dbcsr_amd_bcsr* m);
 int dbcsr_amd_mm_timing(void* handle, float* ms_fill, float* ms_numeric);
 
 /* Symbol name of the dominant kernel, for profile look-up. */
+/* Symmetric operands (src/core/dbcsr_types.F: matrix_type 'S' / 'A'; the reference desymmetrizes them while it builds the
+ * multiplication images, src/mm/dbcsr_mm_cannon.F:284, 351-379): src holds ONE block per symmetric pair (any mix of upper and
+ * lower blocks, square block structure); the full matrix gets block (c, r) = +block(r, c)^T (symmetric) or -block(r, c)^T
+ * (antisymmetric) in addition.  _count writes dst_row_p [nblkrows+1] (device) and the block / element counts (host,
+ * synchronises); _apply fills caller-allocated dst arrays (dst->row_p = that row_p), blocks packed in index order. */
+int dbcsr_amd_bcsr_desymmetrize_count(void* handle, const dbcsr_amd_bcsr* src, int32_t* dst_row_p, int64_t* nblks, int64_t* nze, void* stream);
+int dbcsr_amd_bcsr_desymmetrize_apply(void* handle, libsmm_acc_data_t datatype, const dbcsr_amd_bcsr* src, int antisymmetric,
+  dbcsr_amd_bcsr* dst, void* stream);
+
 /* Statistics of the last dbcsr_amd_mm_numeric of this handle, by (m, n, k): at most max_entries records are written to
  * `out` (host memory), *n_entries receives the number of distinct triples (larger than max_entries = truncated).
  * Counted on the device from the product lists of that call; synchronises `stream`. */

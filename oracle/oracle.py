@@ -169,6 +169,62 @@ def make_random_matrix(row_sizes, col_sizes, sparsity, counter, dtype=np.float64
     return Bcsr(row_sizes, col_sizes, row_p, cols, blk_p, data)
 
 
+def make_random_matrix_symmetric(sizes, sparsity, counter, symmetry):
+    """dbcsr_make_random_matrix with symmetry = 'S' / 'A' (src/ops/dbcsr_test_methods.F:394-458): the candidates (row, col)
+    of the geometric sequence left of the diagonal are dropped (dbcsr_get_stored_coordinates only names the owner, it does not
+    move the block), the others are filled from their own seed; a diagonal block gets its (negative) transpose added.
+    Returns the STORED (upper-triangle) matrix."""
+    sizes = np.ascontiguousarray(sizes, np.int32)
+    n = len(sizes)
+    rows, cols = random_pattern(n, n, sparsity, counter)
+    blocks = {}
+    for r, c in zip(rows.tolist(), cols.tolist()):
+        sr, sc = r + 1, c + 1
+        if sc < sr:
+            continue
+        m, k = int(sizes[sr - 1]), int(sizes[sc - 1])
+        v = np.empty(m * k, np.float64)
+        lib().orc_fill_blocks_d(1, np.asarray([r], np.int32), np.asarray([c], np.int32), n, n, int(counter),
+                                np.ascontiguousarray(np.where(np.arange(n) == r, m, sizes), np.int32),
+                                np.ascontiguousarray(np.where(np.arange(n) == c, k, sizes), np.int32), np.zeros(1, np.int64), v)
+        if sr == sc:
+            blk = v.reshape(k, m).T  # [i][j] of the m x m block
+            v = (blk + blk.T if symmetry == "S" else blk - blk.T).T.reshape(-1)
+        blocks[(sr - 1, sc - 1)] = v
+    keys = sorted(blocks)
+    rr = np.asarray([kk[0] for kk in keys], np.int32)
+    cc = np.asarray([kk[1] for kk in keys], np.int32)
+    nze = sizes[rr].astype(np.int64) * sizes[cc].astype(np.int64) if len(keys) else np.zeros(0, np.int64)
+    blk_p = np.concatenate([[0], np.cumsum(nze)[:-1]]).astype(np.int64) if len(keys) else np.zeros(0, np.int64)
+    data = np.concatenate([blocks[kk] for kk in keys]) if keys else np.zeros(0)
+    row_p = np.zeros(n + 1, np.int64)
+    np.add.at(row_p, rr.astype(np.int64) + 1, 1)
+    return Bcsr(sizes, sizes, np.cumsum(row_p).astype(np.int32), cc, blk_p, data)
+
+
+def desymmetrize(M, symmetry):
+    """dbcsr_desymmetrize_deep: the full matrix of a stored triangle (block (c, r) = +-block(r, c)^T)."""
+    sign = 1.0 if symmetry == "S" else -1.0
+    rows = M.rows()
+    blocks = {}
+    for b in range(M.nblks):
+        r, c = int(rows[b]), int(M.col_i[b])
+        m, n = int(M.row_sizes[r]), int(M.col_sizes[c])
+        v = M.data[M.blk_p[b]:M.blk_p[b] + m * n]
+        blocks[(r, c)] = v
+        if r != c:
+            blocks[(c, r)] = sign * v.reshape(n, m).T.reshape(-1)  # column-major n x m block of the transpose
+    keys = sorted(blocks)
+    rr = np.asarray([k[0] for k in keys], np.int32)
+    cc = np.asarray([k[1] for k in keys], np.int32)
+    nze = M.row_sizes[rr].astype(np.int64) * M.col_sizes[cc].astype(np.int64) if keys else np.zeros(0, np.int64)
+    blk_p = np.concatenate([[0], np.cumsum(nze)[:-1]]).astype(np.int64) if keys else np.zeros(0, np.int64)
+    data = np.concatenate([blocks[k] for k in keys]) if keys else np.zeros(0)
+    row_p = np.zeros(M.nbr + 1, np.int64)
+    np.add.at(row_p, rr.astype(np.int64) + 1, 1)
+    return Bcsr(M.row_sizes, M.col_sizes, np.cumsum(row_p).astype(np.int32), cc, blk_p, data)
+
+
 def checksum(M, pos=False):
     f = lib().orc_checksum_d if M.data.dtype == np.float64 else lib().orc_checksum_s
     return f(M.nbr, M.nbc, M.row_sizes, M.col_sizes, M.row_p, M.col_i, M.blk_p, M.data, 1 if pos else 0)

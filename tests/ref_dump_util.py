@@ -42,8 +42,38 @@ class RefResult:
 
 
 def oracle_inputs(p):
+    """(A, B, C) as the reference's generator makes them for the case (C, A, B in this order: the matrix counter advances);
+    a symmetric / antisymmetric operand is returned as the FULL matrix (desymmetrized), its stored triangle as 4th / 5th item."""
     from oracle import oracle as O
-    return O.perf_case(p["M"], p["N"], p["K"], p["sp"][0], p["sp"][1], p["sp"][2], p["bs_m"], p["bs_n"], p["bs_k"], p["transa"], p["transb"])
+    if nonsymmetric(p):
+        return O.perf_case(p["M"], p["N"], p["K"], p["sp"][0], p["sp"][1], p["sp"][2], p["bs_m"], p["bs_n"], p["bs_k"], p["transa"], p["transb"])
+    assert p["symm_c"] == "N"
+    sm, sn, sk = O.make_block_sizes(p["M"], p["bs_m"]), O.make_block_sizes(p["N"], p["bs_n"]), O.make_block_sizes(p["K"], p["bs_k"])
+    c0 = O.RANDMAT_SEED_INIT
+    Cm = O.make_random_matrix(sm, sn, p["sp"][2], c0 + 1)
+
+    def operand(symm, rs, cs, sp, counter):
+        if symm == "N":
+            return O.make_random_matrix(rs, cs, sp, counter)
+        assert np.array_equal(rs, cs)
+        return O.desymmetrize(O.make_random_matrix_symmetric(rs, sp, counter, symm), symm)
+
+    A = operand(p["symm_a"], *((sk, sm) if p["transa"] != "N" else (sm, sk)), p["sp"][0], c0 + 2)
+    B = operand(p["symm_b"], *((sn, sk) if p["transb"] != "N" else (sk, sn)), p["sp"][1], c0 + 3)
+    return A, B, Cm
+
+
+def stored_operands(p):
+    """the stored (one-triangle) form of the symmetric operands of a case: {"A": (Bcsr, symmetry), ...}"""
+    from oracle import oracle as O
+    sm, sn, sk = O.make_block_sizes(p["M"], p["bs_m"]), O.make_block_sizes(p["N"], p["bs_n"]), O.make_block_sizes(p["K"], p["bs_k"])
+    c0 = O.RANDMAT_SEED_INIT
+    out = {}
+    if p["symm_a"] != "N":
+        out["A"] = (O.make_random_matrix_symmetric(sm, p["sp"][0], c0 + 2, p["symm_a"]), p["symm_a"])
+    if p["symm_b"] != "N":
+        out["B"] = (O.make_random_matrix_symmetric(sk, p["sp"][1], c0 + 3, p["symm_b"]), p["symm_b"])
+    return out
 
 
 def oracle_run(p):

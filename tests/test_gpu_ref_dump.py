@@ -1,6 +1,6 @@
 """GPU paths against outputs of the REAL reference library (tests/golden/ref_dump.json: true dbcsr_multiply on the
-BLAS path, built unchanged with tools/build_dbcsr_host.py): the dbcsr_multiply mirror and the one-call native
-dbcsr_amd_multiply.  Block index identical, flop identical, values within 1e-10 relative (north star)."""
+BLAS path, built unchanged with tools/build_dbcsr_host.py): the dbcsr_multiply mirror (symmetric / antisymmetric operands
+included: they are passed as stored, one triangle, and desymmetrized on the device) and the one-call native dbcsr_amd_multiply.  Block index identical, flop identical, values within 1e-10 relative (north star)."""
 import numpy as np
 import pytest
 import torch
@@ -22,12 +22,19 @@ def compare(out, flop, ref):
         assert np.max(np.abs(out.data - ref.data)) <= 1e-10 * scale
 
 
-@pytest.mark.parametrize("name", R.names(R.nonsymmetric))
+@pytest.mark.parametrize("name", R.names())
 def test_mirror_matches_reference_dump(name):
     ref = R.RefResult(name)
     p = ref.params
     A, B, Cm = R.oracle_inputs(p)
     dA, dB, dC = to_dev(A), to_dev(B), to_dev(Cm)
+    for which, (stored, symm) in R.stored_operands(p).items():  # symmetric operands go in as the reference stores them: one triangle
+        d = to_dev(stored)
+        d.symmetry = symm
+        if which == "A":
+            dA = d
+        else:
+            dB = d
     flop = [0]
     lim = [v or None for v in p["limits"]]
     dbcsr_multiply(p["transa"], p["transb"], p["alpha"], dA, dB, p["beta"], dC, first_row=lim[0], last_row=lim[1], first_column=lim[2],
