@@ -2474,7 +2474,20 @@ int dbcsr_amd_mm_symbolic_filtered(void* handle, libsmm_acc_data_t datatype, dou
     E->cls_mode = E->cls_m[0] > 0 && E->cls_n[0] > 0 && E->cls_k[0] > 0;
   }
   // processing order of the numeric phase: column panels sized for the Infinity Cache, rows dealt to XCDs
-  const int64_t b_bytes_est = b->nblks * (int64_t)E->max_k * E->max_n * (int64_t)sizeof(double);
+  // size of B from the mean block sizes when the histograms are at hand (mixed sizes: the maxima overestimate it 2x on
+  // BASELINE config 3, which doubled the number of panels and with it the compulsory re-reads of the A block-rows)
+  double mean_k = E->max_k, mean_n = E->max_n;
+  if (E->use_classes > 0 && E->max_k <= 32 && E->max_n <= 32 && E->min_k >= 1 && E->min_n >= 1) {
+    double sk = 0, ck = 0, sn = 0, cn = 0;
+    for (int sz = 1; sz <= 32; ++sz) {
+      sn += (double)sz * E->cls_host_hist[33 + sz];
+      cn += E->cls_host_hist[33 + sz];
+      sk += (double)sz * E->cls_host_hist[66 + sz];
+      ck += E->cls_host_hist[66 + sz];
+    }
+    if (ck > 0 && cn > 0) mean_k = sk / ck, mean_n = sn / cn;
+  }
+  const int64_t b_bytes_est = (int64_t)((double)b->nblks * mean_k * mean_n * (double)sizeof(double));
   int NP = (int)std::min<int64_t>((b_bytes_est + E->panel_bytes - 1) / E->panel_bytes, (int64_t)W);
   if (NP < 1) NP = 1;
   const int PW = (W + NP - 1) / NP;

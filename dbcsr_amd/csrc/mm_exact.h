@@ -25,8 +25,10 @@
 //                              the block's end are bounds-checked away and copy zeros): no wave-uniform branches in the staging
 //                              code; 0: piece counts follow the product's inner size (one scalar branch per piece)
 //  DBCSR_EXACT_SCHED_BARRIER 1: scheduling barrier after every k step of the multiply (bounds the live fragment registers)
+// Measured on BASELINE config 3 (kernel ms, all launches of a multiply; gpurun_out/s7): ALL_PIECES/SCHED_BARRIER = 0/0 9.68,
+// 0/1 9.57, 1/0 9.18, 1/1 9.11 -> defaults 1 / 1.
 #ifndef DBCSR_EXACT_ALL_PIECES
-#define DBCSR_EXACT_ALL_PIECES 0
+#define DBCSR_EXACT_ALL_PIECES 1
 #endif
 #ifndef DBCSR_EXACT_SCHED_BARRIER
 #define DBCSR_EXACT_SCHED_BARRIER 1
