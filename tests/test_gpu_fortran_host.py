@@ -81,3 +81,40 @@ def test_dump_driver_through_acc_backend(name):
     data = np.frombuffer(base64.b64decode(got["values_b64"]), "<f8") if ref.nblks else np.zeros(0)
     scale = max(np.max(np.abs(ref.data)), 1e-300) if ref.nblks else 1.0
     assert data.size == ref.data.size and np.max(np.abs(data - ref.data), initial=0.0) <= 1e-10 * scale
+
+
+# ---- the call-site change of INTEGRATION.md section 2, compiled into the reference (tools/build_dbcsr_host.py resident):
+# dbcsr_multiply of the otherwise unchanged library hands the whole multiply to the device-resident engine -------------------
+HOST_RES = os.path.join(ROOT, "oracle", "_ref", "host_resident")
+needs_resident = pytest.mark.skipif(not os.path.exists(os.path.join(HOST_RES, "dbcsr_perf")),
+                                    reason="patched reference host not built (tools/build_dbcsr_host.py resident)")
+ENV_RES = dict(ENV, DBCSR_AMD_RESIDENT="1")
+
+
+@needs_resident
+@pytest.mark.parametrize("name", sorted(k for k, v in GOLD.items() if v["check"] == "T" and v["data_type"] == 3))
+def test_reference_perf_driver_through_resident_engine(name, tmp_path):
+    c = GOLD[name]
+    write_perf(c, tmp_path / "case.perf")
+    r = subprocess.run([os.path.join(HOST_RES, "dbcsr_perf"), str(tmp_path / "case.perf")], cwd=tmp_path, env=ENV_RES, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]   # the driver checks its golden checksums itself (1e-11)
+    m = re.search(r"checksum\(C_out\)\s*=\s*([0-9.E+-]+)", r.stdout)
+    assert m and abs(float(m.group(1)) / c["checksum"] - 1.0) <= c["threshold"]
+    # no parameter stack was ever built: the reference's own multiplication statistics stay empty
+    mm = re.search(r"matmuls total\s+(\d+)", r.stdout)
+    assert mm and int(mm.group(1)) == 0, r.stdout[-3000:]
+
+
+@needs_resident
+@pytest.mark.parametrize("name", R.names(lambda p: p["values"] and R.nonsymmetric(p)))
+def test_dump_driver_through_resident_engine(name):
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import base64
+    import make_ref_fixtures as F
+    ref = R.RefResult(name)
+    got = F.run_case(ref.params, exe=os.path.join(HOST_RES, "dbcsr_ref_dump"), env={"OMP_NUM_THREADS": "4", "DBCSR_AMD_RESIDENT": "1"})
+    assert got["nblks"] == ref.nblks and got["flop"] == ref.flop
+    assert np.array_equal(np.asarray(got["row"]) - 1, ref.rows) and np.array_equal(np.asarray(got["col"], np.int32) - 1, ref.col_i)
+    data = np.frombuffer(base64.b64decode(got["values_b64"]), "<f8") if ref.nblks else np.zeros(0)
+    scale = max(np.max(np.abs(ref.data)), 1e-300) if ref.nblks else 1.0
+    assert data.size == ref.data.size and np.max(np.abs(data - ref.data), initial=0.0) <= 1e-10 * scale

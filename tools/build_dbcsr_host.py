@@ -58,7 +58,14 @@ def expand_tree(scratch, patches):
                     fh.write(text)
                 if f.endswith(".F"):  # the .f90 files are #include fragments, not compilation units
                     files.append(dst)
-    for p in patches:  # unified diffs relative to the expanded tree
+    if patches:
+        # the call-site change of INTEGRATION.md section 2: this repository's glue module next to the reference's mm sources,
+        # then the unified diff(s) relative to the expanded tree
+        glue = os.path.join(ROOT, "dbcsr_amd", "fortran", "dbcsr_amd_resident.F")
+        dst = os.path.join(out, "src", "mm", "dbcsr_amd_resident.F90")
+        shutil.copy(glue, dst)
+        files.append(dst)
+    for p in patches:
         subprocess.check_call(["patch", "-p1", "-d", out, "-i", os.path.abspath(p)])
     return out, files
 
@@ -109,7 +116,7 @@ def build_variant(variant, scratch, exp, files, jobs, reuse=False):
     os.makedirs(bdir, exist_ok=True)
     flags = ["-cpp", "-O2", "-fopenmp", "-D__MKL", "-D__NO_STATM_ACCESS", "-J", bdir, "-I", bdir,
              "-I", os.path.join(exp, "src"), "-I", os.path.join(exp, "src", "base")]
-    if variant == "acc":
+    if variant in ("acc", "resident"):
         flags += ["-D__DBCSR_ACC"]
     lib_files = [f for f in files if os.sep + "src" + os.sep in f]
     test_files = [f for f in files if os.sep + "tests" + os.sep in f]
@@ -134,7 +141,7 @@ def build_variant(variant, scratch, exp, files, jobs, reuse=False):
     os.makedirs(outdir, exist_ok=True)
     lib_objs = [objs[f] for f in lib_files]
     link = ["-fopenmp", "-L/opt/conda/lib", "-lmkl_rt", "-Wl,-rpath,/opt/conda/lib"]
-    if variant == "acc":
+    if variant in ("acc", "resident"):
         link += ["-L" + os.path.join(ROOT, "dbcsr_amd"), "-ldbcsr_acc_amd", "-Wl,-rpath,$ORIGIN/../../../dbcsr_amd"]
     for prog, srcs in TEST_PROGRAMS.items():
         pobjs = [objs[f] for f in test_files if os.path.basename(f)[:-4] + ".F" in srcs]
@@ -149,7 +156,8 @@ def build_variant(variant, scratch, exp, files, jobs, reuse=False):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("variant", nargs="?", default="both", choices=["cpu", "acc", "both"])
+    ap.add_argument("variant", nargs="?", default="both", choices=["cpu", "acc", "both", "resident"],
+                    help="resident = acc + the call-site patch (dbcsr_multiply -> device-resident engine), output oracle/_ref/host_resident")
     ap.add_argument("--scratch", default="/tmp/dbcsr_host")
     ap.add_argument("--jobs", type=int, default=16)
     ap.add_argument("--patch", action="append", default=[])
@@ -158,6 +166,8 @@ def main():
     if not os.path.isdir(REF):
         raise SystemExit("the reference is not mounted here: nothing to build (the GPU box uses the prebuilt oracle/_ref)")
     os.makedirs(a.scratch, exist_ok=True)
+    if a.variant == "resident" and not a.patch:
+        a.patch = [os.path.join(ROOT, "dbcsr_amd", "fortran", "dbcsr_mm_call_site.patch")]
     if a.reuse and os.path.isdir(os.path.join(a.scratch, "expanded")):
         exp = os.path.join(a.scratch, "expanded")
         files = [os.path.join(d, f) for d, _, fs in os.walk(exp) for f in fs if f.endswith(".F90")]
