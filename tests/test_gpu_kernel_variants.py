@@ -17,6 +17,8 @@ MIXED = (300, 280, 260, 0.5, 0.5, 0.6, [1, 13, 1, 23, 1, 32, 1, 7], [1, 23, 1, 5
 H2O = (23 * 20 + 16, 23 * 18 + 16, 23 * 22 + 16, 0.6, 0.6, 0.7, [1, 23], [1, 23], [1, 23])
 TINY = (240, 240, 240, 0.7, 0.7, 0.7, [1, 4], [1, 4, 1, 3], [1, 4, 1, 2])
 CONFIG3 = (68 * 9 + 24, 68 * 8 + 24, 68 * 10 + 24, 0.8, 0.8, 0.8, [1, 13, 1, 23, 1, 32], [1, 13, 1, 23, 1, 32], [1, 13, 1, 23, 1, 32])
+# config 3's regime at an oracle-friendly size: {13, 23, 32} blocks + tail 24, 200 block rows, fill 13.6 % -> 3.7 products per C block
+CONFIG3_37 = (68 * 66 + 24, 68 * 66 + 24, 68 * 66 + 24, 0.864, 0.864, 0.864, [1, 13, 1, 23, 1, 32], [1, 13, 1, 23, 1, 32], [1, 13, 1, 23, 1, 32])
 POW2 = (16 * 20 + 9, 32 * 10 + 5, 16 * 18 + 3, 0.6, 0.6, 0.6, [1, 16, 1, 32], [1, 32, 1, 16, 1, 8], [1, 16, 1, 32, 1, 24])  # padded LDS pitches
 BIG = (300, 270, 280, 0.5, 0.5, 0.5, [1, 45, 1, 13], [1, 67, 1, 5], [1, 40, 1, 23])
 
@@ -42,6 +44,8 @@ VARIANTS = [
     ({"DBCSR_AMD_MM_CLASSES": "2"}, H2O, "mm_numeric_f64_class["),
     ({"DBCSR_AMD_MM_CLASSES": "2"}, CONFIG3, "mm_numeric_f64_class["),
     ({"DBCSR_AMD_MM_CLASSES": "2"}, POW2, "mm_numeric_f64_class["),
+    ({"DBCSR_AMD_MM_CLASSES": "2"}, CONFIG3_37, "mm_numeric_f64_class[9 jit + 1 generic"),
+    ({"DBCSR_AMD_MM_CLASSES": "0"}, CONFIG3_37, "mm_numeric_f64_pipe<4>"),   # what the automatic choice runs below the class threshold
 ]
 
 
