@@ -2031,7 +2031,7 @@ __global__ void order_len_cls(const int64_t* __restrict__ base, int64_t total, i
       const int64_t b1 = (cls == kNumClasses - 1 && x == 7) ? total : base[k1];
       mx = b1 - base[k0] > mx ? b1 - base[k0] : mx;
     }
-    const int64_t len = (mx + 3) & ~(int64_t)3;
+    const int64_t len = (mx + 31) & ~(int64_t)31;  // multiple of 4 waves x up to 8 blocks per wave
     lens[cls] = len;
     lens[kNumClasses + cls] = off;
     off += 8 * len;
@@ -2225,6 +2225,7 @@ struct Engine {
   int use_pipe = -1, pipe_g = 8;  // multi-block pipelined kernel: -1 automatic (short product lists only), DBCSR_AMD_MM_KERNEL=pipe|lds1 forces; DBCSR_AMD_MM_PIPE_G = blocks per wave
   // (m, n) classes (mixed block sizes, see order_count_cls): DBCSR_AMD_MM_CLASSES = 0 never, 1 automatic, 2 always when the sizes allow
   int use_classes = 1;
+  int class_g = 1;  // DBCSR_AMD_MM_CLASS_G: C blocks per wave in the class kernels (1, 2, 4, 8)
   bool cls_mode = false;
   int cls_m[3] = {0, 0, 0}, cls_n[3] = {0, 0, 0}, cls_k[3] = {0, 0, 0};
   int64_t cls_len[kNumClasses] = {0}, cls_off[kNumClasses] = {0};
@@ -2278,6 +2279,10 @@ int dbcsr_amd_mm_create(void** handle) {
   }
   if (const char* k = getenv("DBCSR_AMD_MM_PIPE_G")) E->pipe_g = std::max(1, atoi(k));
   if (const char* k = getenv("DBCSR_AMD_MM_CLASSES")) E->use_classes = atoi(k);
+  if (const char* k = getenv("DBCSR_AMD_MM_CLASS_G")) {
+    const int g = atoi(k);
+    E->class_g = (g == 2 || g == 4 || g == 8) ? g : 1;
+  }
   if (hipHostMalloc(reinterpret_cast<void**>(&E->cls_host_hist), 3 * 33 * sizeof(int), hipHostMallocDefault) != hipSuccess ||
       hipHostMalloc(reinterpret_cast<void**>(&E->cls_host_lens), (2 * kNumClasses + 1) * sizeof(int64_t), hipHostMallocDefault) != hipSuccess)
     return -1;
@@ -2625,7 +2630,7 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
         const unsigned nwg_c = (unsigned)(8 * E->cls_len[c] / 4);
         ClassKernel ck;
         const int cm = c < 9 ? E->cls_m[c / 3] : 0, cn = c < 9 ? E->cls_n[c % 3] : 0;
-        if (c < 9 && cm > 0 && cn > 0 && jit_class_kernel(cm, cn, E->cls_k[0], E->cls_k[1], E->cls_k[2], &ck) == 0) {
+        if (c < 9 && cm > 0 && cn > 0 && jit_class_kernel(cm, cn, E->cls_k[0], E->cls_k[1], E->cls_k[2], E->class_g, &ck) == 0) {
           const Desc* p_descs = E->descs.p;
           long p_nblk = (long)nblk;
           const Entry* p_entries = E->entries.p;
@@ -2636,7 +2641,7 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
           double p_alpha = alpha, p_beta = beta;
           int p_skip = skip_empty;
           void* args[] = {&p_descs, &p_nblk, &p_entries, &p_a, &p_b, &p_c, &p_ci, &p_alpha, &p_beta, &p_skip, &ord};
-          ACC_CHECK(hipModuleLaunchKernel(ck.fn, nwg_c, 1, 1, 256, 1, 1, (unsigned)(4 * ck.wave_lds), st, args, nullptr));
+          ACC_CHECK(hipModuleLaunchKernel(ck.fn, nwg_c / (unsigned)E->class_g, 1, 1, 256, 1, 1, (unsigned)(4 * ck.wave_lds), st, args, nullptr));
           ++njit;
         } else {
           const size_t lb = (size_t)4 * g_lds_wave * sizeof(double);

@@ -305,6 +305,252 @@ __device__ __forceinline__ void mm_class_kernel_body(const Desc* __restrict__ de
                                        smem + (size_t)wid * ClassShape<M, N, K0, K1, K2>::WAVE_LDS);
 }
 
+
+// ---- G consecutive C blocks of the class per wave, the product pipeline running ACROSS block boundaries --------------------
+// With few products per C block (BASELINE config 3: 3.7) a wave's life is dominated by the dependent chain
+// order[] -> descriptor -> product list -> first operands (about 4 of its 9 us).  Here a wave owns G consecutive positions of
+// its class segment: the G block ids and descriptors are fetched with two vector loads (lane l holds block l) and handed out
+// with v_readlane, the product list of block b + 1 is requested while block b is multiplied, and the operands of the first
+// product of block b + 1 are already in flight while the last product of block b is multiplied.  Same arithmetic per block
+// as cblock_f64_classes (products of a block in list order, then the products of other inner sizes), so results are identical.
+template <int M, int N, int K0, int K1, int K2, int G>
+__device__ __forceinline__ void mm_class_stream_body(const Desc* __restrict__ descs, int64_t nblk, const Entry* __restrict__ entries,
+                                                     const double* __restrict__ a_data, const double* __restrict__ b_data,
+                                                     double* __restrict__ c_out, const double* __restrict__ c_in, double alpha, double beta,
+                                                     int skip_empty, const int* __restrict__ order, char* smem) {
+  static_assert(G >= 1 && G <= 64, "one lane per block of the group");
+  typedef ClassShape<M, N, K0, K1, K2> CS;
+  constexpr int MA = CS::MA, NC = CS::NC;
+  constexpr int AP = Pitch<M>::P;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int64_t pos0 = ((int64_t)wg * 4 + wid) * G;
+  char* lds = smem + (size_t)wid * CS::WAVE_LDS;
+  char* lds_a = lds;
+  char* lds_b = lds + CS::A_LDS;
+  const LaneMap L(lane);
+  const int voff = lane * 16;
+
+  // block ids and descriptors of the group: lane l < G holds block l
+  const int my_cb = lane < G ? order[pos0 + lane] : -1;
+  const bool my_ok = my_cb >= 0 && my_cb < nblk;
+  const Desc my_d = descs[my_ok ? my_cb : 0];
+  const int my_cnt = my_ok ? my_d.prod_cnt : -1;  // -1: no block at this position
+  auto lane_i32 = [&](int v, int l) { return __builtin_amdgcn_readlane(v, l); };
+  auto lane_i64 = [&](int64_t v, int l) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), l);
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+  };
+
+  const double* pa[MA];
+  int colc[NC];
+#pragma unroll
+  for (int a = 0; a < MA; ++a) {
+    int row = 8 * a + L.rowl;
+    row = row < M ? row : M - 1;
+    pa[a] = reinterpret_cast<const double*>(lds_a) + row + AP * L.kq;
+  }
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    int col = 8 * c + L.coll;
+    colc[c] = col < N ? col : N - 1;
+  }
+  u32x4 ra[CS::CAMAX], rb[CS::CBMAX];
+  double acc[MA][NC];
+
+  // product-list windows (first 64 entries of a block's list), two of them: the block being multiplied and the next one
+  uint32_t w0[2] = {0, 0}, w1[2] = {0, 0}, w2[2] = {1, 1};
+  auto load_window = [&](int buf, int b) {  // b wave-uniform
+    const int cnt = lane_i32(my_cnt, b);
+    if (cnt <= 0) return;
+    const Entry* e = entries + lane_i64(my_d.prod_start, b);
+    const int i = lane < cnt ? lane : cnt - 1;
+    const uint32_t x0 = e[i].a_lo, x1 = e[i].b_lo, x2 = e[i].w;
+    if (buf) {  // (no run-time index into the register arrays: that would put them into scratch)
+      w0[1] = x0, w1[1] = x1, w2[1] = x2;
+    } else {
+      w0[0] = x0, w1[0] = x1, w2[0] = x2;
+    }
+  };
+  auto entry_at = [&](int buf, int b, int i) {  // entry i of block b; beyond the window: straight from memory
+    Entry en;
+    if (i < 64) {
+      en.a_lo = (uint32_t)__builtin_amdgcn_readlane((int)(buf ? w0[1] : w0[0]), i);
+      en.b_lo = (uint32_t)__builtin_amdgcn_readlane((int)(buf ? w1[1] : w1[0]), i);
+      en.w = (uint32_t)__builtin_amdgcn_readlane((int)(buf ? w2[1] : w2[0]), i);
+    } else {
+      en = entries[lane_i64(my_d.prod_start, b) + i];
+    }
+    return en;
+  };
+  auto in_set = [](int ks) { return ks == K0 || (K1 != 0 && ks == K1) || (K2 != 0 && ks == K2); };
+
+  auto issue = [&](const Entry& en) {
+    const int ks = en.ks();
+    const int abytes = __builtin_amdgcn_readfirstlane(M * ks * 8), bbytes = __builtin_amdgcn_readfirstlane(ks * N * 8);
+    const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)(a_data + en.a_off()), 0, abytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)(b_data + en.b_off()), 0, bbytes, 0x00020000);
+#pragma unroll
+    for (int c = 0; c < CS::CAMAX; ++c) ra[c] = __builtin_amdgcn_raw_buffer_load_b128(rsa, voff, c * 1024, 0);
+#pragma unroll
+    for (int c = 0; c < CS::CBMAX; ++c) rb[c] = __builtin_amdgcn_raw_buffer_load_b128(rsb, voff, c * 1024, 0);
+  };
+  auto store = [&](int ks) {
+#pragma unroll
+    for (int c = 0; c < CS::CAMAX; ++c) *reinterpret_cast<u32x4*>(lds_a + staged_offset<M>(c, lane)) = ra[c];
+    const int sh = __builtin_amdgcn_readfirstlane((ks & 15) == 0 ? (ks == 16 ? 4 : 5) : 31);
+#pragma unroll
+    for (int c = 0; c < CS::CBMAX; ++c) *reinterpret_cast<u32x4*>(lds_b + c * 1024 + lane * 16 + 16 * ((c * 128 + lane * 2) >> sh)) = rb[c];
+  };
+  auto compute_k = [&](auto kc) {
+    constexpr int K = decltype(kc)::value;
+    typedef KShape<M, N, K> KSH;
+    constexpr int KS = KSH::KS, BP = KSH::BP;
+    const double* pb[NC];
+    const double* pbt[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      pb[c] = reinterpret_cast<const double*>(lds_b) + L.kq + BP * colc[c];
+      const int kt = 4 * (KS - 1) + L.kq;
+      pbt[c] = reinterpret_cast<const double*>(lds_b) + (kt < K ? kt : 0) + BP * colc[c];
+    }
+    double av[2][MA], bv[2][NC];
+    auto fetch = [&](int s, int buf) {
+#pragma unroll
+      for (int a = 0; a < MA; ++a) av[buf][a] = pa[a][s * 4 * AP];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) bv[buf][c] = (s == KS - 1 && (K & 3)) ? pbt[c][0] : pb[c][4 * s];
+    };
+    fetch(0, 0);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      if (s + 1 < KS) fetch(s + 1, (s + 1) & 1);
+#pragma unroll
+      for (int a = 0; a < MA; ++a)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[a][c] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[s & 1][a], bv[s & 1][c], acc[a][c], 0, 0, 0);
+      if (DBCSR_EXACT_SCHED_BARRIER) __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  // cursor over the in-set products of the group: (block, index); "active" blocks only (a block skipped by skip_empty or an
+  // empty position has no products and no epilogue)
+  auto block_cnt = [&](int b) { return b < G ? lane_i32(my_cnt, b) : -1; };
+  auto first_in_set = [&](int buf, int b, int from) {
+    const int cnt = block_cnt(b);
+    int i = from;
+    while (i < cnt && !in_set(entry_at(buf, b, i).ks())) ++i;
+    return i < cnt ? i : -1;
+  };
+
+  load_window(0, 0);
+  // next product to issue: search forward from block 0
+  int nb = 0, ni = first_in_set(0, 0, 0);  // (nb, ni) = the product whose operands are in flight; ni = -1: block nb has none (left)
+  bool in_flight = false;
+  Entry ne = Entry::make(0, 0, K0);
+  if (ni >= 0) {
+    ne = entry_at(0, 0, ni);
+    issue(ne);
+    in_flight = true;
+  }
+  for (int b = 0; b < G; ++b) {
+    const int buf = b & 1;
+    const int cnt = block_cnt(b);
+    if (b + 1 < G) load_window(buf ^ 1, b + 1);  // the next block's list travels while this block is multiplied
+    if (cnt < 0 || (skip_empty && cnt == 0)) {
+      // nothing to do for this position; if no product is in flight, look into the next block for one
+      if (!in_flight && b + 1 < G) {
+        ni = first_in_set(buf ^ 1, b + 1, 0);
+        nb = b + 1;
+        if (ni >= 0) {
+          ne = entry_at(buf ^ 1, b + 1, ni);
+          issue(ne);
+          in_flight = true;
+        }
+      }
+      continue;
+    }
+#pragma unroll
+    for (int a = 0; a < MA; ++a)
+#pragma unroll
+      for (int c = 0; c < NC; ++c) acc[a][c] = 0.0;
+    // the product in flight, if any, belongs to this block (the search never runs past a block that still has an epilogue to do)
+    while (in_flight && nb == b) {
+      const int kcur = ne.ks();
+      store(kcur);
+      // next in-set product: in this block, else the first one of the next block
+      int i1 = first_in_set(buf, b, ni + 1);
+      in_flight = false;
+      if (i1 >= 0) {
+        ni = i1;
+        ne = entry_at(buf, b, i1);
+        issue(ne);
+        in_flight = true;
+      } else if (b + 1 < G) {
+        i1 = first_in_set(buf ^ 1, b + 1, 0);
+        nb = b + 1;
+        ni = i1;
+        if (i1 >= 0) {
+          ne = entry_at(buf ^ 1, b + 1, i1);
+          issue(ne);
+          in_flight = true;
+        }
+      }
+      if (kcur == K0) compute_k(IntC<K0>());
+      if constexpr (K1 != 0)
+        if (kcur == K1) compute_k(IntC<K1>());
+      if constexpr (K2 != 0)
+        if (kcur == K2) compute_k(IntC<K2>());
+    }
+    if (!in_flight && nb <= b && b + 1 < G) {  // this block had no in-set product at all: start the next block's first one now
+      ni = first_in_set(buf ^ 1, b + 1, 0);
+      nb = b + 1;
+      if (ni >= 0) {
+        ne = entry_at(buf ^ 1, b + 1, ni);
+        issue(ne);
+        in_flight = true;
+      }
+    }
+    const int64_t d_c_off = lane_i64(my_d.c_off, b), d_cin_off = lane_i64(my_d.cin_off, b), d_ps = lane_i64(my_d.prod_start, b);
+    for (int p = 0; p < cnt; ++p) {  // products of another inner size: straight from global memory
+      const Entry ep = entries[d_ps + p];
+      if (!in_set(ep.ks())) block_product_f64<MA, NC, false>(acc, a_data + ep.a_off(), b_data + ep.b_off(), M, N, ep.ks(), L);
+    }
+    // C epilogue through LDS (the operands of the next product are still in registers, not in LDS)
+    constexpr int CC = (M * N * 8 + 1023) / 1024;
+    double* lds_c = reinterpret_cast<double*>(lds);
+#pragma unroll
+    for (int a = 0; a < MA; ++a)
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const int row = 8 * a + L.rowd, col = 8 * c + L.coll;
+        if (row < M && col < N) lds_c[row + M * col] = alpha * acc[a][c];
+      }
+    const bool has_in = d_cin_off >= 0;
+    const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc((void*)(c_out + d_c_off), 0, M * N * 8, 0x00020000);
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    if (has_in) {
+      const __amdgpu_buffer_rsrc_t rsi = __builtin_amdgcn_make_buffer_rsrc((void*)(c_in + d_cin_off), 0, M * N * 8, 0x00020000);
+#pragma unroll
+      for (int c = 0; c < CC; ++c) {
+        f64x2 v = *reinterpret_cast<const f64x2*>(lds + c * 1024 + voff);
+        const f64x2 w = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(rsi, voff, c * 1024, 0));
+        v[0] += beta * w[0];
+        v[1] += beta * w[1];
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsc, voff, c * 1024, 2);
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < CC; ++c) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(lds + c * 1024 + voff);
+        __builtin_amdgcn_raw_buffer_store_b128(v, rsc, voff, c * 1024, 2);
+      }
+    }
+  }
+}
+
 }  // namespace dbcsr_amd
 
 #ifdef DBCSR_AMD_JIT_M  // translation unit handed to hiprtc (mm_jit.hip): one kernel, its shape comes from the macros
@@ -316,8 +562,13 @@ extern "C" __global__ void __launch_bounds__(256, DBCSR_AMD_JIT_MINW)  // second
                          const double* __restrict__ a_data, const double* __restrict__ b_data, double* __restrict__ c_out,
                          const double* __restrict__ c_in, double alpha, double beta, int skip_empty, const int* __restrict__ order) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+#if defined(DBCSR_AMD_JIT_G) && DBCSR_AMD_JIT_G > 1
+  dbcsr_amd::mm_class_stream_body<DBCSR_AMD_JIT_M, DBCSR_AMD_JIT_N, DBCSR_AMD_JIT_K0, DBCSR_AMD_JIT_K1, DBCSR_AMD_JIT_K2, DBCSR_AMD_JIT_G>(
+      descs, nblk, entries, a_data, b_data, c_out, c_in, alpha, beta, skip_empty, order, smem);
+#else
   dbcsr_amd::mm_class_kernel_body<DBCSR_AMD_JIT_M, DBCSR_AMD_JIT_N, DBCSR_AMD_JIT_K0, DBCSR_AMD_JIT_K1, DBCSR_AMD_JIT_K2>(
       descs, nblk, entries, a_data, b_data, c_out, c_in, alpha, beta, skip_empty, order, smem);
+#endif
 }
 #endif
 #endif

@@ -14,7 +14,8 @@ struct ClassKernel {
 // 0 on success; the kernel for C blocks of m x n whose products have inner sizes k0, k1, k2 (0 = absent, k0 > 0).
 // Thread-safe; compiles on first use (~1 s), then served from the cache.  Non-zero when hiprtc is unavailable or fails
 // (the caller then runs the generic kernel on that class).
-int jit_class_kernel(int m, int n, int k0, int k1, int k2, ClassKernel* out);
+// g > 1: the variant in which a wave walks g consecutive C blocks of the class (mm_class_stream_body)
+int jit_class_kernel(int m, int n, int k0, int k1, int k2, int g, ClassKernel* out);
 
 }  // namespace dbcsr_amd
 #endif

@@ -67,16 +67,17 @@ struct Cached {
   bool failed = false;
 };
 std::mutex g_mu;
-std::map<std::tuple<int, int, int, int, int, int>, Cached> g_cache;  // (device, m, n, k0, k1, k2)
+std::map<std::tuple<int, int, int, int, int, int, int>, Cached> g_cache;  // (device, m, n, k0, k1, k2, g)
 
 }  // namespace
 
-int jit_class_kernel(int m, int n, int k0, int k1, int k2, ClassKernel* out) {
+int jit_class_kernel(int m, int n, int k0, int k1, int k2, int g, ClassKernel* out) {
+  if (g < 1 || g > 64) return -1;
   if (!out || m < 1 || n < 1 || k0 < 1 || m > 32 || n > 32 || k0 > 32 || k1 > 32 || k2 > 32) return -1;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return -1;
   std::lock_guard<std::mutex> lock(g_mu);
-  auto key = std::make_tuple(dev, m, n, k0, k1, k2);
+  auto key = std::make_tuple(dev, m, n, k0, k1, k2, g);
   auto it = g_cache.find(key);
   if (it != g_cache.end()) {
     if (it->second.failed) return -1;
@@ -93,11 +94,12 @@ int jit_class_kernel(int m, int n, int k0, int k1, int k2, ClassKernel* out) {
   // waves per SIMD the LDS allows (4 waves per workgroup, 160 KiB per CU): the register allocation is asked to allow as many
   int wgs = (160 * 1024) / (4 * wave_lds);
   int minw = wgs > 4 ? 4 : (wgs < 1 ? 1 : wgs);
+  if (g > 1 && minw > 1) --minw;  // the multi-block body keeps descriptors and two list windows in registers
   char defs[512];
   snprintf(defs, sizeof defs,
            "#define DBCSR_AMD_JIT_M %d\n#define DBCSR_AMD_JIT_N %d\n#define DBCSR_AMD_JIT_K0 %d\n#define DBCSR_AMD_JIT_K1 %d\n"
-           "#define DBCSR_AMD_JIT_K2 %d\n#define DBCSR_AMD_JIT_MINW %d\n#include \"mm_exact.h\"\n",
-           m, n, k0, k1, k2, minw);
+           "#define DBCSR_AMD_JIT_K2 %d\n#define DBCSR_AMD_JIT_MINW %d\n#define DBCSR_AMD_JIT_G %d\n#include \"mm_exact.h\"\n",
+           m, n, k0, k1, k2, minw, g);
   const char* hsrc[] = {kJitSrc_mm_types, kJitSrc_smm_core, kJitSrc_mm_exact};
   const char* hname[] = {"mm_types.h", "smm_core.h", "mm_exact.h"};
   rtc_program prog = nullptr;

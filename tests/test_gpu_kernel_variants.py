@@ -45,12 +45,17 @@ VARIANTS = [
     ({"DBCSR_AMD_MM_CLASSES": "2"}, CONFIG3, "mm_numeric_f64_class["),
     ({"DBCSR_AMD_MM_CLASSES": "2"}, POW2, "mm_numeric_f64_class["),
     ({"DBCSR_AMD_MM_CLASSES": "2"}, CONFIG3_37, "mm_numeric_f64_class[9 jit + 1 generic"),
-    ({"DBCSR_AMD_MM_CLASSES": "0"}, CONFIG3_37, "mm_numeric_f64_pipe<4>"),   # what the automatic choice runs below the class threshold
+    ({"DBCSR_AMD_MM_CLASSES": "0"}, CONFIG3_37, "mm_numeric_f64_pipe<4>"),
+    # the class kernels with a wave walking 8 / 4 consecutive C blocks of its class (product pipeline across block boundaries)
+    ({"DBCSR_AMD_MM_CLASSES": "2", "DBCSR_AMD_MM_CLASS_G": "8"}, CONFIG3_37, "mm_numeric_f64_class[9 jit + 1 generic"),
+    ({"DBCSR_AMD_MM_CLASSES": "2", "DBCSR_AMD_MM_CLASS_G": "8"}, MIXED, "mm_numeric_f64_class["),
+    ({"DBCSR_AMD_MM_CLASSES": "2", "DBCSR_AMD_MM_CLASS_G": "4"}, POW2, "mm_numeric_f64_class["),
+    ({"DBCSR_AMD_MM_CLASSES": "2", "DBCSR_AMD_MM_CLASS_G": "8"}, H2O, "mm_numeric_f64_class["),   # what the automatic choice runs below the class threshold
 ]
 
 
 def run_case(monkeypatch, env, case, dtype, tol, expect, alpha=0.7, beta=1.3, retain=False, in_place_twice=False):
-    for k in ("DBCSR_AMD_MM_KERNEL", "DBCSR_AMD_MM_HOT", "DBCSR_AMD_MM_TINY", "DBCSR_AMD_MM_PIPE_G", "DBCSR_AMD_MM_SYMBOLIC", "DBCSR_AMD_MM_CLASSES"):
+    for k in ("DBCSR_AMD_MM_KERNEL", "DBCSR_AMD_MM_HOT", "DBCSR_AMD_MM_TINY", "DBCSR_AMD_MM_PIPE_G", "DBCSR_AMD_MM_SYMBOLIC", "DBCSR_AMD_MM_CLASSES", "DBCSR_AMD_MM_CLASS_G"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
