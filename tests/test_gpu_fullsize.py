@@ -24,6 +24,8 @@ CONFIGS = {
     "config4_131072_23x23_fill1": (131072, 0.01, [1, 23], torch.float64),
     # config 5's shape (32 x 32, 20 %, fp32) at a quarter of its edge: the full 131072^2 needs 143 GB and 2.7 s per multiply
     "config5_shape_32768_32x32_fill20_fp32": (32768, 0.20, [1, 32], torch.float32),
+    # ... and at its full size on one GPU (180 TFLOP per multiply, 69 GB of C, 33 GB of product lists; four passes over k)
+    "config5_131072_32x32_fill20_fp32": (131072, 0.20, [1, 32], torch.float32),
 }
 
 
