@@ -494,6 +494,123 @@ fill_products_grid(const int* __restrict__ a_row_p, const int* __restrict__ a_co
 }
 
 
+// ---- product-driven variants for a sparse C (BASELINE config 4: C 43 % full, 1.3 products per C block) --------------------------
+// The grid kernels test every (row, column) candidate against every block of A's row: nbr x nbc x |A row| bitmap tests
+// (config 4: 1.9 G for 18.6 M products; count 2.0 ms + fill 2.7 ms = 15 % of the multiply).  Here ONE WAVE owns a block row i of A
+// (hence of C) and walks its blocks A(i, k) in ascending k; the lanes take the blocks B(k, j) of row k, look up the C block by
+// bitmap rank and bump its counter.  Work is proportional to the number of products.  Inside a step all lanes hit different C
+// blocks, steps are sequential and no other wave touches row i, so the list slots handed out by the atomic in the fill pass
+// follow ascending k: same lists as the other kernels.
+__global__ void __launch_bounds__(256) count_products_rows(const int* __restrict__ a_row_p, const int* __restrict__ a_col_i,
+                                                           const int* __restrict__ rs, const int* __restrict__ ks, const int* __restrict__ cs,
+                                                           const int* __restrict__ b_row_p, const int* __restrict__ b_col_i,
+                                                           const uint32_t* __restrict__ c_bm, const int* __restrict__ c_pre,
+                                                           const int* __restrict__ c_row_p, int nbr, int W, int* __restrict__ prod_cnt,
+                                                           unsigned long long* __restrict__ flop_out) {
+  const int lane = threadIdx.x & 63;
+  const int i = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  unsigned long long flop = 0;
+  if (i < nbr) {
+    const unsigned long long m = (unsigned long long)rs[i];
+    for (int ab = a_row_p[i]; ab < a_row_p[i + 1]; ++ab) {
+      const int k = a_col_i[ab];
+      const unsigned long long kk = (unsigned long long)ks[k];
+      for (int bb = b_row_p[k] + lane; bb < b_row_p[k + 1]; bb += 64) {
+        const int j = b_col_i[bb], w = j >> 5, bit = j & 31;
+        const uint32_t cw = c_bm[(size_t)i * W + w];
+        if (!((cw >> bit) & 1u)) continue;  // retain_sparsity: no such C block
+        const int cb = c_row_p[i] + c_pre[(size_t)i * W + w] + __popc(cw & ((1u << bit) - 1u));
+        atomicAdd(&prod_cnt[cb], 1);
+        flop += 2ull * m * (unsigned long long)cs[j] * kk;
+      }
+    }
+  }
+  __shared__ unsigned long long red[4];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) flop += __shfl_down(flop, off, 64);
+  if (lane == 0) red[threadIdx.x >> 6] = flop;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long t = red[0] + red[1] + red[2] + red[3];
+    if (t) atomicAdd(flop_out, t);
+  }
+}
+
+__global__ void __launch_bounds__(256) fill_products_rows(const int* __restrict__ a_row_p, const int* __restrict__ a_col_i,
+                                                          const int64_t* __restrict__ a_blk_p, const int* __restrict__ ks,
+                                                          const int* __restrict__ b_row_p, const int* __restrict__ b_col_i,
+                                                          const int64_t* __restrict__ b_blk_p, const uint32_t* __restrict__ c_bm,
+                                                          const int* __restrict__ c_pre, const int* __restrict__ c_row_p,
+                                                          const int64_t* __restrict__ prod_start, int nbr, int W, int* __restrict__ fill_cnt,
+                                                          Entry* __restrict__ entries) {
+  const int lane = threadIdx.x & 63;
+  const int i = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  if (i >= nbr) return;
+  for (int ab = a_row_p[i]; ab < a_row_p[i + 1]; ++ab) {
+    const int k = a_col_i[ab];
+    const int kk = ks[k];
+    const int64_t a_off = a_blk_p[ab];
+    for (int bb = b_row_p[k] + lane; bb < b_row_p[k + 1]; bb += 64) {
+      const int j = b_col_i[bb], w = j >> 5, bit = j & 31;
+      const uint32_t cw = c_bm[(size_t)i * W + w];
+      if (!((cw >> bit) & 1u)) continue;
+      const int cb = c_row_p[i] + c_pre[(size_t)i * W + w] + __popc(cw & ((1u << bit) - 1u));
+      const int slot = atomicAdd(&fill_cnt[cb], 1);
+      entries[prod_start[cb] + slot] = Entry::make(a_off, b_blk_p[bb], kk);
+    }
+  }
+}
+
+// thread per (row, bitmap word): element counts of the C blocks in index order (count pass of the rows variant) ...
+__global__ void __launch_bounds__(256) block_sizes_rows(const uint32_t* __restrict__ c_bm, const int* __restrict__ c_pre,
+                                                        const int* __restrict__ c_row_p, const int* __restrict__ rs, const int* __restrict__ cs,
+                                                        int nbr, int W, int* __restrict__ blk_nze) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (int64_t)nbr * W) return;
+  const int i = (int)(t / W), w = (int)(t % W);
+  uint32_t v = c_bm[t];
+  int cb = c_row_p[i] + c_pre[t];
+  while (v) {
+    const int bit = __ffs(v) - 1;
+    v &= v - 1;
+    blk_nze[cb++] = rs[i] * cs[32 * w + bit];
+  }
+}
+
+// ... and their descriptors / index entries (fill pass)
+__global__ void __launch_bounds__(256)
+finish_descs_rows(const int* __restrict__ cin_row_p, const int64_t* __restrict__ cin_blk_p, const int* __restrict__ rs,
+                  const int* __restrict__ cs, const uint32_t* __restrict__ cin_bm, const int* __restrict__ cin_pre,
+                  const uint32_t* __restrict__ c_bm, const int* __restrict__ c_pre, const int* __restrict__ c_row_p,
+                  const int64_t* __restrict__ c_blk_p_ws, const int64_t* __restrict__ prod_start, const int* __restrict__ prod_cnt, int nbr,
+                  int W, int* __restrict__ c_col_i, int64_t* __restrict__ c_blk_p, Desc* __restrict__ descs) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (int64_t)nbr * W) return;
+  const int i = (int)(t / W), w = (int)(t % W);
+  uint32_t v = c_bm[t];
+  if (!v) return;
+  int cb = c_row_p[i] + c_pre[t];
+  const uint32_t cinw = cin_bm ? cin_bm[t] : 0u;
+  while (v) {
+    const int bit = __ffs(v) - 1;
+    v &= v - 1;
+    const uint32_t below = (1u << bit) - 1u;
+    const int j = 32 * w + bit;
+    Desc d;
+    d.c_off = c_blk_p_ws[cb];
+    d.cin_off = -1;
+    if ((cinw >> bit) & 1u) d.cin_off = cin_blk_p[cin_row_p[i] + cin_pre[t] + __popc(cinw & below)];
+    d.prod_start = prod_start[cb];
+    d.prod_cnt = prod_cnt[cb];
+    d.m = (int16_t)rs[i];
+    d.n = (int16_t)cs[j];
+    descs[cb] = d;
+    c_col_i[cb] = j;
+    c_blk_p[cb] = d.c_off;
+    ++cb;
+  }
+}
+
 // ---- C structure only (multi-tick / Cannon use): emit the sorted index of the pattern
 // computed by the symbolic phase and describe where each block's initial value comes from.
 __global__ void __launch_bounds__(256)
@@ -2220,6 +2337,8 @@ struct Engine {
   int64_t c_nblks = 0, nproducts = 0;
   bool have_cin = false, retain = false, valid = false;
   int max_m = 0, max_k = 0, max_n = 0, min_m = 0, min_k = 0, min_n = 0;
+  bool rows_kernels = false;  // product-driven symbolic kernels (sparse C); DBCSR_AMD_MM_SYMBOLIC=rows forces, =grid / =word exclude
+  int force_symbolic = 0;     // 0 automatic, 1 word, 2 grid, 3 rows
   bool grid_kernels = false, force_word_kernels = false;  // DBCSR_AMD_MM_SYMBOLIC=word forces the per-word symbolic kernels
   int dbg = 0;      // DBCSR_AMD_MM_DBG: ablation switches of the LDS kernel (profiling only)
   int use_pipe = -1, pipe_g = 8;  // multi-block pipelined kernel: -1 automatic (short product lists only), DBCSR_AMD_MM_KERNEL=pipe|lds1 forces; DBCSR_AMD_MM_PIPE_G = blocks per wave
@@ -2290,7 +2409,10 @@ int dbcsr_amd_mm_create(void** handle) {
   if (const char* k = getenv("DBCSR_AMD_MM_HOT")) E->use_hot = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_TINY")) E->use_tiny = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_LDS_PAD")) E->lds_pad = atoi(k);
-  if (const char* k = getenv("DBCSR_AMD_MM_SYMBOLIC")) E->force_word_kernels = strcmp(k, "word") == 0;
+  if (const char* k = getenv("DBCSR_AMD_MM_SYMBOLIC")) {
+    E->force_word_kernels = strcmp(k, "word") == 0;
+    E->force_symbolic = strcmp(k, "word") == 0 ? 1 : (strcmp(k, "grid") == 0 ? 2 : (strcmp(k, "rows") == 0 ? 3 : 0));
+  }
   if (const char* k = getenv("DBCSR_AMD_MM_PANEL_MB")) E->panel_bytes = (int64_t)atoll(k) << 20;
   if (const char* k = getenv("DBCSR_AMD_MM_ROW_GROUP")) E->row_group = atoi(k);
   for (int i = 0; i < 3; ++i) {
@@ -2529,7 +2651,16 @@ int dbcsr_amd_mm_symbolic_filtered(void* handle, libsmm_acc_data_t datatype, dou
   // one lane per (row, column) candidate unless C is extremely sparse (then one thread per bitmap word)
   const int nJ = (nbc + 63) / 64;
   E->grid_kernels = filtering || (((int64_t)nbr * nJ * 64 <= 256 * std::max<int64_t>(c_nblks, 1)) && !E->force_word_kernels);
-  if (E->grid_kernels)
+  // sparse C (less than 60 % of the candidates are blocks) with enough block rows to fill the chip: product-driven kernels
+  E->rows_kernels = !filtering && (E->force_symbolic == 3 || (E->force_symbolic == 0 && nbr >= 2048 && 10 * c_nblks < 6 * (int64_t)nbr * nbc));
+  if (E->rows_kernels) {
+    E->grid_kernels = false;
+    ACC_CHECK(hipMemsetAsync(E->prod_cnt.p, 0, sizeof(int) * (size_t)c_nblks, st));
+    hipLaunchKernelGGL(block_sizes_rows, grid_for((int64_t)nbr * W), dim3(256), 0, st, E->c_bm.p, E->c_pre.p, c_out_row_p, a->row_blk_size,
+                       b->col_blk_size, nbr, W, E->blk_nze.p);
+    hipLaunchKernelGGL(count_products_rows, grid_for((int64_t)nbr * 64), dim3(256), 0, st, a->row_p, a->col_i, a->row_blk_size, a->col_blk_size,
+                       b->col_blk_size, b->row_p, b->col_i, E->c_bm.p, E->c_pre.p, c_out_row_p, nbr, W, E->prod_cnt.p, E->dev_scalars.p + 3);
+  } else if (E->grid_kernels)
     hipLaunchKernelGGL(count_products_grid, grid_for((int64_t)nbr * nJ * 64), dim3(256), 0, st, a->row_p, a->col_i, a->row_blk_size,
                        a->col_blk_size, b->col_blk_size, E->b_bm.p, E->c_bm.p, E->c_pre.p, c_out_row_p, nbr, nbc, W, nJ,
                        E->prod_cnt.p, E->blk_nze.p, E->dev_scalars.p + 3, b->row_p, E->b_pre.p, E->filter);
@@ -2587,7 +2718,16 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
   if (nblk == 0) return 0;
   if (E->entries.ensure((size_t)E->nproducts + 1) || E->descs.ensure((size_t)nblk + 1)) return -1;
   ACC_CHECK(hipEventRecord(E->ev[0], st));
-  if (E->grid_kernels) {
+  if (E->rows_kernels) {
+    if (E->tmp_i32.ensure((size_t)nblk + 1)) return -1;
+    ACC_CHECK(hipMemsetAsync(E->tmp_i32.p, 0, sizeof(int) * (size_t)nblk, st));
+    hipLaunchKernelGGL(fill_products_rows, grid_for((int64_t)nbr * 64), dim3(256), 0, st, a->row_p, a->col_i, a->blk_p, a->col_blk_size, b->row_p,
+                       b->col_i, b->blk_p, E->c_bm.p, E->c_pre.p, c_out->row_p, E->prod_start.p, nbr, W, E->tmp_i32.p, E->entries.p);
+    hipLaunchKernelGGL(finish_descs_rows, grid_for((int64_t)nbr * W), dim3(256), 0, st, c_in->row_p, c_in->blk_p, c_out->row_blk_size,
+                       c_out->col_blk_size, E->have_cin ? E->cin_bm.p : (const uint32_t*)nullptr,
+                       E->have_cin ? E->cin_pre.p : (const int*)nullptr, E->c_bm.p, E->c_pre.p, c_out->row_p, E->c_blk_p_ws.p, E->prod_start.p,
+                       E->prod_cnt.p, nbr, W, c_out->col_i, c_out->blk_p, E->descs.p);
+  } else if (E->grid_kernels) {
     const int nbc = b->nblkcols, nJ = (nbc + 63) / 64;
     hipLaunchKernelGGL(fill_products_grid, grid_for((int64_t)nbr * nJ * 64), dim3(256), 0, st, a->row_p, a->col_i, a->blk_p, b->row_p,
                        b->blk_p, c_in->row_p, c_in->blk_p, a->row_blk_size, a->col_blk_size, b->col_blk_size, E->b_bm.p, E->b_pre.p,

@@ -20,6 +20,7 @@ CONFIG3 = (68 * 9 + 24, 68 * 8 + 24, 68 * 10 + 24, 0.8, 0.8, 0.8, [1, 13, 1, 23,
 # config 3's regime at an oracle-friendly size: {13, 23, 32} blocks + tail 24, 200 block rows, fill 13.6 % -> 3.7 products per C block
 CONFIG3_37 = (68 * 66 + 24, 68 * 66 + 24, 68 * 66 + 24, 0.864, 0.864, 0.864, [1, 13, 1, 23, 1, 32], [1, 13, 1, 23, 1, 32], [1, 13, 1, 23, 1, 32])
 POW2 = (16 * 20 + 9, 32 * 10 + 5, 16 * 18 + 3, 0.6, 0.6, 0.6, [1, 16, 1, 32], [1, 32, 1, 16, 1, 8], [1, 16, 1, 32, 1, 24])  # padded LDS pitches
+SPARSE = (23 * 120 + 16, 23 * 110 + 16, 23 * 130 + 16, 0.97, 0.97, 0.98, [1, 23], [1, 23], [1, 23])  # 0.1 products per candidate
 BIG = (300, 270, 280, 0.5, 0.5, 0.5, [1, 45, 1, 13], [1, 67, 1, 5], [1, 40, 1, 23])
 
 # (environment, case, expected kernel-name prefix)
@@ -39,6 +40,11 @@ VARIANTS = [
     ({"DBCSR_AMD_MM_TINY": "0", "DBCSR_AMD_MM_KERNEL": "pipe"}, TINY, "mm_numeric_f64_pipe<1>"),
     ({}, BIG, "mm_numeric_f64"),
     ({"DBCSR_AMD_MM_SYMBOLIC": "word"}, MIXED, "mm_numeric_f64"),
+    # product-driven symbolic kernels (automatic for a sparse C with many block rows: BASELINE config 4)
+    ({"DBCSR_AMD_MM_SYMBOLIC": "rows"}, MIXED, "mm_numeric_f64"),
+    ({"DBCSR_AMD_MM_SYMBOLIC": "rows"}, H2O, "mm_numeric_f64_hot<23,23,23>"),
+    ({"DBCSR_AMD_MM_SYMBOLIC": "rows", "DBCSR_AMD_MM_CLASSES": "2"}, CONFIG3_37, "mm_numeric_f64_class["),
+    ({"DBCSR_AMD_MM_SYMBOLIC": "rows"}, SPARSE, "mm_numeric_f64"),
     # (m, n) classes with run-time compiled exact-size kernels (forced: the cases are far below the automatic threshold)
     ({"DBCSR_AMD_MM_CLASSES": "2"}, MIXED, "mm_numeric_f64_class["),
     ({"DBCSR_AMD_MM_CLASSES": "2"}, H2O, "mm_numeric_f64_class["),
@@ -85,7 +91,7 @@ def test_fp64_variant_matches_oracle(monkeypatch, env, case, expect):
     run_case(monkeypatch, env, case, np.float64, 1e-10, expect)
 
 
-@pytest.mark.parametrize("env,case,expect", [v for v in VARIANTS if v[1] in (H2O, MIXED)][:9] + [v for v in VARIANTS if "DBCSR_AMD_MM_CLASSES" in v[0]],
+@pytest.mark.parametrize("env,case,expect", [v for v in VARIANTS if v[1] in (H2O, MIXED)][:9] + [v for v in VARIANTS if "DBCSR_AMD_MM_CLASSES" in v[0] or v[0].get("DBCSR_AMD_MM_SYMBOLIC") == "rows"],
                          ids=lambda v: "-".join("%s=%s" % (k[13:], x) for k, x in v.items()) if isinstance(v, dict) else None)
 def test_fp64_variant_retain_and_in_place(monkeypatch, env, case, expect):
     run_case(monkeypatch, env, case, np.float64, 1e-10, expect, alpha=1.0, beta=1.0, retain=True, in_place_twice=True)
