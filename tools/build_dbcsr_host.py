@@ -124,8 +124,9 @@ def build_variant(variant, scratch, exp, files, jobs, reuse=False):
     def compile_one(f):
         o = os.path.join(bdir, os.path.basename(f)[:-4] + ".o")
         short = os.path.basename(f)
-        if reuse and os.path.exists(o):
+        if reuse and os.path.exists(o) and not dirty:
             return o
+        rebuilt.append(o)
         r = subprocess.run([FC] + flags + ['-D__SHORT_FILE__="%s"' % short, "-c", f, "-o", o], capture_output=True, text=True)
         if r.returncode != 0:
             sys.stderr.write("FAILED %s\n%s\n" % (f, r.stderr[-3000:]))
@@ -133,10 +134,13 @@ def build_variant(variant, scratch, exp, files, jobs, reuse=False):
         return o
 
     objs = {}
+    dirty, rebuilt = [], []   # --reuse: once one object had to be rebuilt, every later level is (its .mod files may have changed)
     for lvl in toposort(lib_files + test_files, [os.path.join(exp, "src"), os.path.join(exp, "src", "base")]):
         with cf.ThreadPoolExecutor(jobs) as ex:
             for f, o in zip(lvl, ex.map(compile_one, lvl)):
                 objs[f] = o
+        if rebuilt:
+            dirty.append(True)
     outdir = os.path.join(ROOT, "oracle", "_ref", "host_" + variant)
     os.makedirs(outdir, exist_ok=True)
     lib_objs = [objs[f] for f in lib_files]
@@ -171,6 +175,12 @@ def main():
     if a.reuse and os.path.isdir(os.path.join(a.scratch, "expanded")):
         exp = os.path.join(a.scratch, "expanded")
         files = [os.path.join(d, f) for d, _, fs in os.walk(exp) for f in fs if f.endswith(".F90")]
+        glue_dst = os.path.join(exp, "src", "mm", "dbcsr_amd_resident.F90")
+        if os.path.exists(glue_dst):   # this repository's own module may have changed since: refresh it and what uses it
+            shutil.copy(os.path.join(ROOT, "dbcsr_amd", "fortran", "dbcsr_amd_resident.F"), glue_dst)
+            o = os.path.join(a.scratch, "build_resident", "dbcsr_amd_resident.o")
+            if os.path.exists(o):
+                os.remove(o)
     else:
         exp, files = expand_tree(a.scratch, a.patch)
     for v in (["cpu", "acc"] if a.variant == "both" else [a.variant]):

@@ -9,7 +9,7 @@ toks = [0, "F", "dbcsr_multiply", 16384, 16384, 16384, "0.9d0", "0.9d0", "0.9d0"
 open("gpurun_out/s12/h2o16k.perf", "w").write("\n".join(str(t) for t in toks) + "\n")
 PY
 P=$PWD/$O/h2o16k.perf
-for v in "host_cpu 32 0" "host_acc 8 0" "host_resident 8 1"; do set -- $v
+for v in "host_cpu 32 0" "host_acc 8 0" "host_resident 8 1v"; do set -- $v
   ( cd /tmp && DBCSR_AMD_RESIDENT=$3 OMP_NUM_THREADS=$2 timeout 600 $OLDPWD/oracle/_ref/$1/dbcsr_perf $P > $OLDPWD/$O/$1.txt 2>&1 )
-  echo "== $1 (OMP $2, resident $3)"; grep -E "time  |perf total|flops total|matmuls total|checksum\(C_out\) " $O/$1.txt
+  echo "== $1 (OMP $2, resident $3)"; grep -E "dbcsr_amd_resident:|time  |perf total|flops total|matmuls total|checksum\(C_out\) " $O/$1.txt
 done
