@@ -911,7 +911,7 @@ __device__ __forceinline__ void cblock_f64_lds(const Desc& d, const Entry* __res
 // (the generic path: 103 VALU + 98 SALU instructions per 23^3 product besides the 54 MFMAs).  Products of the
 // block with another inner dimension (the tail block column of A) are multiplied straight from global memory.
 template <int M, int N, int K>
-__device__ __forceinline__ void cblock_f64_exact(const Desc& d, const Entry* __restrict__ entries, const double* __restrict__ a_data,
+__device__ __forceinline__ void cblock_f64_exact(const Desc& d, const Entry& first, const Entry* __restrict__ entries, const double* __restrict__ a_data,
                                                  const double* __restrict__ b_data, double* __restrict__ c_out,
                                                  const double* __restrict__ c_in, double alpha, double beta, const LaneMap& L, int lane,
                                                  char* lds_a, char* lds_b, int dbg) {
@@ -959,7 +959,7 @@ __device__ __forceinline__ void cblock_f64_exact(const Desc& d, const Entry* __r
   // Products with inner dimension K run through the staged pipeline (i0 = the one being multiplied, i1 = the next
   // candidate, whose list entry was requested one trip earlier); the others are summed afterwards.
   int i0 = 0;
-  Entry e0 = e[0];
+  Entry e0 = first;  // == e[0], already here
   while (i0 < cnt && e0.ks() != K) {
     ++i0;
     e0 = e[i0 < cnt ? i0 : cnt - 1];
@@ -1073,21 +1073,32 @@ template <int M, int N, int K>
 __global__ void __launch_bounds__(256) mm_numeric_f64_hot(const Desc* __restrict__ descs, int64_t nblk, const Entry* __restrict__ entries,
                                                           const double* __restrict__ a_data, const double* __restrict__ b_data,
                                                           double* __restrict__ c_out, const double* __restrict__ c_in, double alpha,
-                                                          double beta, int lds_a_doubles, int lds_wave_doubles, int dbg, const int* __restrict__ order) {
+                                                          double beta, int lds_a_doubles, int lds_wave_doubles, int dbg, const int* __restrict__ order,
+                                                          const Work* __restrict__ work) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
   const int64_t pos = (int64_t)wg * 4 + wid;
-  const int64_t cb = order[pos];
-  if (cb < 0 || cb >= nblk) return;
-  if ((dbg & 32) && descs[cb].prod_cnt == 0) return;
+  Desc d;
+  Entry first;
+  if (work) {  // launch-order records: descriptor and first product in one read
+    const Work w = work[pos];
+    if (w.prod_cnt < 0) return;
+    d.c_off = w.c_off, d.cin_off = w.cin_off, d.prod_start = w.prod_start, d.prod_cnt = w.prod_cnt, d.m = w.m, d.n = w.n;
+    first.a_lo = w.a_lo, first.b_lo = w.b_lo, first.w = w.w;
+  } else {
+    const int64_t cb = order[pos];
+    if (cb < 0 || cb >= nblk) return;
+    d = descs[cb];
+    first = entries[d.prod_start];
+  }
+  if ((dbg & 32) && d.prod_cnt == 0) return;
   char* lds_a = smem + (size_t)wid * lds_wave_doubles * 8;
   char* lds_b = lds_a + (size_t)lds_a_doubles * 8;
-  const Desc d = descs[cb];
   const LaneMap L(lane);
   if (d.m == M && d.n == N) {
-    cblock_f64_exact<M, N, K>(d, entries, a_data, b_data, c_out, c_in, alpha, beta, L, lane, lds_a, lds_b, dbg);
+    cblock_f64_exact<M, N, K>(d, first, entries, a_data, b_data, c_out, c_in, alpha, beta, L, lane, lds_a, lds_b, dbg);
     return;
   }
   // the few blocks of another size (tail block row / column): straight from global memory, as one 32 x 32 tile
@@ -2197,6 +2208,25 @@ __global__ void __launch_bounds__(256) order_fill_cls(const uint32_t* __restrict
 
 // ---- per-(m, n, k) statistics (dbcsr_mm_sched.F:392-461): histogram over the product lists, open addressing ------------
 constexpr int kStatSlots = 8192;  // power of two
+// launch-order work records (mm_types.h Work): one thread per position of order[]
+__global__ void __launch_bounds__(256) build_work(const int* __restrict__ order, int64_t npos, const Desc* __restrict__ descs, int64_t nblk,
+                                                  const Entry* __restrict__ entries, Work* __restrict__ work) {
+  const int64_t pos = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pos >= npos) return;
+  const int cb = order[pos];
+  Work w;
+  w.c_off = 0, w.cin_off = -1, w.prod_start = 0, w.prod_cnt = -1, w.m = 0, w.n = 0, w.a_lo = 0, w.b_lo = 0, w.w = 0, w.pad = 0;
+  if (cb >= 0 && cb < nblk) {
+    const Desc d = descs[cb];
+    w.c_off = d.c_off, w.cin_off = d.cin_off, w.prod_start = d.prod_start, w.prod_cnt = d.prod_cnt, w.m = d.m, w.n = d.n;
+    if (d.prod_cnt > 0) {
+      const Entry e = entries[d.prod_start];
+      w.a_lo = e.a_lo, w.b_lo = e.b_lo, w.w = e.w;
+    }
+  }
+  work[pos] = w;
+}
+
 __global__ void __launch_bounds__(256) mnk_histogram(const Desc* __restrict__ descs, int64_t nblk, const Entry* __restrict__ entries,
                                                      unsigned long long* __restrict__ keys, unsigned long long* __restrict__ counts,
                                                      int* __restrict__ overflow) {
@@ -2248,13 +2278,13 @@ namespace dbcsr_amd {
 
 static bool launch_hot_f64(int m, int n, int k, dim3 grid, size_t lds_bytes, hipStream_t st, const Desc* descs, int64_t nblk,
                            const Entry* entries, const double* a_data, const double* b_data, double* c_out, const double* c_in,
-                           double alpha, double beta, int lds_a, int lds_wave, int dbg, const int* order) {
+                           double alpha, double beta, int lds_a, int lds_wave, int dbg, const int* order, const Work* work) {
   if (m != n || m != k) return false;
   switch (m) {
 #define DBCSR_HOT_CASE(S_)                                                                                                      \
   case S_:                                                                                                                      \
     hipLaunchKernelGGL((mm_numeric_f64_hot<S_, S_, S_>), grid, dim3(256), lds_bytes, st, descs, nblk, entries, a_data, b_data, c_out, \
-                       c_in, alpha, beta, lds_a, lds_wave, dbg, order);                                                         \
+                       c_in, alpha, beta, lds_a, lds_wave, dbg, order, work);                                                   \
     return true;
     DBCSR_AMD_HOT_SIZES(DBCSR_HOT_CASE)
 #undef DBCSR_HOT_CASE
@@ -2318,6 +2348,8 @@ struct Engine {
   FilterArgs filter = {nullptr, nullptr, 0.0f};
   int64_t flt_nblks = 0;
   DevBuf<int> order, order_cnt;
+  DevBuf<Work> work;  // launch-order records of the exact-size fp64 kernels (DBCSR_AMD_MM_WORK=0: order[] -> descs[] -> entries[] instead)
+  int use_work = 1;
   DevBuf<int64_t> order_base;
   int64_t order_len = 0;
   Window crop_win = {0, 0, 0, 0};       // window of the last dbcsr_amd_bcsr_crop_count
@@ -2398,6 +2430,7 @@ int dbcsr_amd_mm_create(void** handle) {
   }
   if (const char* k = getenv("DBCSR_AMD_MM_PIPE_G")) E->pipe_g = std::max(1, atoi(k));
   if (const char* k = getenv("DBCSR_AMD_MM_CLASSES")) E->use_classes = atoi(k);
+  if (const char* k = getenv("DBCSR_AMD_MM_WORK")) E->use_work = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_CLASS_G")) {
     const int g = atoi(k);
     E->class_g = (g == 2 || g == 4 || g == 8) ? g : 1;
@@ -2744,6 +2777,20 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
   const unsigned nwg = (unsigned)((nblk + 3) / 4);
   // in-place accumulation (Cannon ticks after the first): C blocks without products in this call are left untouched
   const int skip_empty = (c_out->data == c_in->data && E->retain && beta == 1.0) ? 1 : 0;
+  // launch-order work records for the exact-size fp64 kernels (one wave per C block): descriptor + first product in one read
+  const Work* hot_work = nullptr;
+  {
+    const bool small64 = datatype == dbcsr_type_real_8 && E->use_lds && E->max_m <= 32 && E->max_k <= 32 && E->max_n <= 32 && E->min_m >= 1 &&
+                         E->min_k >= 1 && E->min_n >= 1 && !(E->use_tiny && E->max_m <= 4 && E->max_n <= 4);
+    const bool exact = E->cls_mode ? E->class_g == 1
+                                   : (E->use_hot && E->use_pipe != 1 && E->hot_m > 0 && E->dma_stages == 0 && E->hot_m == E->hot_n && E->hot_m == E->hot_k);
+    const int64_t npos = 8 * E->order_len;
+    if (E->use_work && small64 && exact && npos > 0) {
+      if (E->work.ensure((size_t)npos + 1)) return -1;
+      hipLaunchKernelGGL(build_work, grid_for(npos), dim3(256), 0, st, E->order.p, npos, E->descs.p, nblk, E->entries.p, E->work.p);
+      hot_work = E->work.p;
+    }
+  }
   ACC_CHECK(hipEventRecord(E->ev[1], st));
   if (datatype == dbcsr_type_real_8) {
     // LDS path: blocks of at most 32 x 32 (any smaller size: the staging loads are bounds-checked buffer loads)
@@ -2780,7 +2827,8 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
           const double* p_ci = static_cast<const double*>(c_in->data);
           double p_alpha = alpha, p_beta = beta;
           int p_skip = skip_empty;
-          void* args[] = {&p_descs, &p_nblk, &p_entries, &p_a, &p_b, &p_c, &p_ci, &p_alpha, &p_beta, &p_skip, &ord};
+          const Work* p_work = hot_work ? hot_work + E->cls_off[c] : nullptr;
+          void* args[] = {&p_descs, &p_nblk, &p_entries, &p_a, &p_b, &p_c, &p_ci, &p_alpha, &p_beta, &p_skip, &ord, &p_work};
           ACC_CHECK(hipModuleLaunchKernel(ck.fn, nwg_c / (unsigned)E->class_g, 1, 1, 256, 1, 1, (unsigned)(4 * ck.wave_lds), st, args, nullptr));
           ++njit;
         } else {
@@ -2825,7 +2873,8 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
       } else if (E->use_hot && E->use_pipe != 1 && E->hot_m > 0 &&
           launch_hot_f64(E->hot_m, E->hot_n, E->hot_k, dim3(nwg_o), lds_bytes, st, E->descs.p, nblk, E->entries.p,
                          static_cast<const double*>(a->data), static_cast<const double*>(b->data), static_cast<double*>(c_out->data),
-                         static_cast<const double*>(c_in->data), alpha, beta, lds_a, lds_wave, E->dbg | (skip_empty ? 32 : 0), E->order.p)) {
+                         static_cast<const double*>(c_in->data), alpha, beta, lds_a, lds_wave, E->dbg | (skip_empty ? 32 : 0), E->order.p,
+                         hot_work)) {
         // launched: C blocks of the dominant size take the exact-size path, the others the generic one
         snprintf(E->last_kernel, sizeof E->last_kernel, "mm_numeric_f64_hot<%d,%d,%d>", E->hot_m, E->hot_n, E->hot_k);
       } else {

@@ -106,7 +106,8 @@ __device__ __forceinline__ int staged_offset(int c, int lane) {
 }
 
 template <int M, int N, int K0, int K1, int K2>
-__device__ __forceinline__ void cblock_f64_classes(const Desc& d, const Entry* __restrict__ entries, const double* __restrict__ a_data,
+__device__ __forceinline__ void cblock_f64_classes(const Desc& d, const Entry& first, bool have_first, const Entry* __restrict__ entries,
+                                                   const double* __restrict__ a_data,
                                                    const double* __restrict__ b_data, double* __restrict__ c_out,
                                                    const double* __restrict__ c_in, double alpha, double beta, const LaneMap& L, int lane,
                                                    char* lds) {
@@ -229,9 +230,18 @@ __device__ __forceinline__ void cblock_f64_classes(const Desc& d, const Entry* _
     }
   };
 
-  int i0 = next_in_set(0);
-  Entry e0 = i0 < cnt ? entry_at(i0) : Entry::make(0, 0, K0);
-  if (i0 < cnt) issue(e0);
+  // the first product: known before the list window arrives when the launch-order record carried it
+  int i0;
+  Entry e0;
+  if (have_first && in_set(first.ks())) {
+    i0 = 0;
+    e0 = first;
+    issue(e0);
+  } else {
+    i0 = next_in_set(0);
+    e0 = i0 < cnt ? entry_at(i0) : Entry::make(0, 0, K0);
+    if (i0 < cnt) issue(e0);
+  }
   while (i0 < cnt) {
     const int kcur = e0.ks();
     const int i1 = next_in_set(i0 + 1);
@@ -291,17 +301,28 @@ template <int M, int N, int K0, int K1, int K2>
 __device__ __forceinline__ void mm_class_kernel_body(const Desc* __restrict__ descs, int64_t nblk, const Entry* __restrict__ entries,
                                                      const double* __restrict__ a_data, const double* __restrict__ b_data,
                                                      double* __restrict__ c_out, const double* __restrict__ c_in, double alpha, double beta,
-                                                     int skip_empty, const int* __restrict__ order, char* smem) {
+                                                     int skip_empty, const int* __restrict__ order, const Work* __restrict__ work, char* smem) {
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
   const int64_t pos = (int64_t)wg * 4 + wid;
-  const int64_t cb = order[pos];
-  if (cb < 0 || cb >= nblk) return;
-  const Desc d = descs[cb];
+  Desc d;
+  Entry first = Entry::make(0, 0, 0);
+  bool have_first = false;
+  if (work) {  // launch-order records: descriptor and first product in one read
+    const Work w = work[pos];
+    if (w.prod_cnt < 0) return;
+    d.c_off = w.c_off, d.cin_off = w.cin_off, d.prod_start = w.prod_start, d.prod_cnt = w.prod_cnt, d.m = w.m, d.n = w.n;
+    first.a_lo = w.a_lo, first.b_lo = w.b_lo, first.w = w.w;
+    have_first = w.prod_cnt > 0;
+  } else {
+    const int64_t cb = order[pos];
+    if (cb < 0 || cb >= nblk) return;
+    d = descs[cb];
+  }
   if (skip_empty && d.prod_cnt == 0) return;
   const LaneMap L(lane);
-  cblock_f64_classes<M, N, K0, K1, K2>(d, entries, a_data, b_data, c_out, c_in, alpha, beta, L, lane,
+  cblock_f64_classes<M, N, K0, K1, K2>(d, first, have_first, entries, a_data, b_data, c_out, c_in, alpha, beta, L, lane,
                                        smem + (size_t)wid * ClassShape<M, N, K0, K1, K2>::WAVE_LDS);
 }
 
@@ -560,14 +581,15 @@ __device__ __forceinline__ void mm_class_stream_body(const Desc* __restrict__ de
 extern "C" __global__ void __launch_bounds__(256, DBCSR_AMD_JIT_MINW)  // second argument: waves per SIMD the register allocation must allow
     mm_numeric_f64_class(const dbcsr_amd::Desc* __restrict__ descs, long nblk, const dbcsr_amd::Entry* __restrict__ entries,
                          const double* __restrict__ a_data, const double* __restrict__ b_data, double* __restrict__ c_out,
-                         const double* __restrict__ c_in, double alpha, double beta, int skip_empty, const int* __restrict__ order) {
+                         const double* __restrict__ c_in, double alpha, double beta, int skip_empty, const int* __restrict__ order,
+                         const dbcsr_amd::Work* __restrict__ work) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
 #if defined(DBCSR_AMD_JIT_G) && DBCSR_AMD_JIT_G > 1
   dbcsr_amd::mm_class_stream_body<DBCSR_AMD_JIT_M, DBCSR_AMD_JIT_N, DBCSR_AMD_JIT_K0, DBCSR_AMD_JIT_K1, DBCSR_AMD_JIT_K2, DBCSR_AMD_JIT_G>(
       descs, nblk, entries, a_data, b_data, c_out, c_in, alpha, beta, skip_empty, order, smem);
 #else
   dbcsr_amd::mm_class_kernel_body<DBCSR_AMD_JIT_M, DBCSR_AMD_JIT_N, DBCSR_AMD_JIT_K0, DBCSR_AMD_JIT_K1, DBCSR_AMD_JIT_K2>(
-      descs, nblk, entries, a_data, b_data, c_out, c_in, alpha, beta, skip_empty, order, smem);
+      descs, nblk, entries, a_data, b_data, c_out, c_in, alpha, beta, skip_empty, order, work, smem);
 #endif
 }
 #endif

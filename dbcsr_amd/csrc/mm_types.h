@@ -45,6 +45,16 @@ struct Desc {  // one C block
   int16_t m, n;
 };
 
+struct Work {  // one position of the launch order: the C block's descriptor AND its first product, 48 bytes.  A wave reads
+               // work[pos] (neighbouring waves read neighbouring records) and can request its first operands at once:
+               // the dependent chain order[pos] -> descs[cb] -> entries[prod_start] -> operands becomes work[pos] -> operands
+  int64_t c_off, cin_off, prod_start;
+  int32_t prod_cnt;  // -1: padding position (no C block)
+  int16_t m, n;
+  uint32_t a_lo, b_lo, w;  // the first Entry of the block (undefined when prod_cnt == 0)
+  uint32_t pad;
+};
+
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   // Workgroup b is dispatched to XCD b % 8 (MI355X_MICROARCH.md); give each XCD a
   // contiguous range of C blocks so that the A block-row it works on stays in
