@@ -136,60 +136,127 @@ def _sub_index(rows, cols, keep, row_local, col_local, nrows_local, row_sizes, c
 class DistBlocks:
     """The part of a distributed matrix that ONE rank holds before the multiply: any subset of the blocks, in any order,
     addressed by GLOBAL block coordinates (the counterpart of a rank-local dbcsr_type: src/core/dbcsr_types.F:362-461).
-    rows / cols: int32 arrays, data: the blocks concatenated (column-major each) in the same order."""
+    rows / cols: int32 arrays (host), data: the blocks concatenated (column-major each) in the same order -- a numpy array
+    or a torch tensor; a tensor in HBM stays there through the redistribution."""
 
     def __init__(self, rows, cols, data):
         self.rows, self.cols = np.ascontiguousarray(rows, np.int32), np.ascontiguousarray(cols, np.int32)
-        self.data = np.ascontiguousarray(data)
+        self.data = data if isinstance(data, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(data))
 
 
-def redistribute(loc, dest_of, row_sizes, col_sizes, dtype):
+_GATHER_CHUNK = 1 << 26  # elements per gather pass (bounds the int64 index vector to 512 MB)
+
+
+def gather_blocks(src, starts, lens):
+    """out = the blocks src[starts[b] : starts[b] + lens[b]] back to back, on src's device (starts / lens: host int64)."""
+    starts, lens = np.asarray(starts, np.int64), np.asarray(lens, np.int64)
+    total = int(lens.sum())
+    out = torch.empty(total, dtype=src.dtype, device=src.device)
+    if total == 0:
+        return out
+    dst = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    b0 = 0
+    while b0 < len(lens):
+        b1 = int(np.searchsorted(dst, dst[b0] + _GATHER_CHUNK, side="right"))
+        b1 = max(b0 + 1, min(b1 - 1, len(lens)))
+        n = int(dst[b1] - dst[b0])
+        if n:
+            shift = torch.as_tensor(starts[b0:b1] - dst[b0:b1], device=src.device)
+            idx = torch.repeat_interleave(shift, torch.as_tensor(lens[b0:b1], device=src.device), output_size=n)
+            idx += torch.arange(int(dst[b0]), int(dst[b1]), device=src.device)
+            out[int(dst[b0]):int(dst[b1])] = src[idx]
+        b0 = b1
+    return out
+
+
+def _wire_device(like):
+    """Where point-to-point buffers must live: HBM under the nccl (= RCCL) backend, host memory under gloo."""
+    if dist.is_initialized() and dist.get_backend() == "nccl":
+        return like.device if like.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def redistribute(loc, dest_of, row_sizes, col_sizes, dtype, comm=None):
     """make_images for one matrix (reference src/mm/dbcsr_mm_cannon.F:292-750): every block travels from the rank that
     holds it to the rank that owns its target image, as an (index, data) pair -- sizes first (one allgather, :532),
     then int32 block coordinates and the block data (:674-678, :1036).  Collective over the default process group.
-    Returns (rows, cols, offsets, data) of the blocks this rank now owns, sorted by (row, col), and the coordinates
-    of EVERY block of the matrix with its owner (the index metadata the other ranks need to address those images)."""
+    The int32 index is handled on the host (as the reference does); the block data is packed per destination, sent and
+    sorted into (row, col) order ON THE DEVICE IT LIVES ON (gather_blocks) -- device buffers go straight into RCCL under
+    the nccl backend, under gloo they are staged through host memory for the wire only; with ``comm`` (a
+    dbcsr_amd.comm.NativeComm) sizes, index and data travel through the C-ABI exchange of include/dbcsr_amd_comm.h instead.
+    Returns (rows, cols, offsets, data) of the blocks this rank now owns, sorted by (row, col) -- data a tensor on the
+    input's device -- and the coordinates of EVERY block of the matrix with its owner (the index metadata the other
+    ranks need to address those images)."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
-    nze = row_sizes[loc.rows].astype(np.int64) * col_sizes[loc.cols].astype(np.int64) if len(loc.rows) else np.zeros(0, np.int64)
+    src = loc.data.to(dtype)
+    dev = src.device
+    nblk = len(loc.rows)
+    nze = row_sizes[loc.rows].astype(np.int64) * col_sizes[loc.cols].astype(np.int64) if nblk else np.zeros(0, np.int64)
     off = np.concatenate([[0], np.cumsum(nze)]).astype(np.int64)
-    dest = np.asarray(dest_of(loc.rows, loc.cols), np.int64) if len(loc.rows) else np.zeros(0, np.int64)
-    out_idx, out_dat = [], []
-    for d in range(world):
-        sel = np.nonzero(dest == d)[0]
-        out_idx.append(np.stack([loc.rows[sel], loc.cols[sel]]).astype(np.int32) if len(sel) else np.zeros((2, 0), np.int32))
-        out_dat.append(np.concatenate([loc.data[off[b]:off[b + 1]] for b in sel]) if len(sel) else np.zeros(0, loc.data.dtype))
+    dest = np.asarray(dest_of(loc.rows, loc.cols), np.int64) if nblk else np.zeros(0, np.int64)
+    perm = np.argsort(dest, kind="stable")
+    nb_to = np.bincount(dest, minlength=world).astype(np.int64)
+    ne_to = np.bincount(dest, weights=nze, minlength=world).astype(np.int64) if nblk else np.zeros(world, np.int64)
+    b_lo = np.concatenate([[0], np.cumsum(nb_to)]).astype(np.int64)
+    e_lo = np.concatenate([[0], np.cumsum(ne_to)]).astype(np.int64)
+    packed = gather_blocks(src, off[perm], nze[perm])            # grouped by destination rank
+    idx_out = np.stack([loc.rows[perm], loc.cols[perm]]).astype(np.int32) if nblk else np.zeros((2, 0), np.int32)
     if world > 1:
+        wire = src.device if comm is not None else _wire_device(src)
         # sizes: what every rank will send to every rank (blocks, elements)
-        mine = torch.tensor([[out_idx[d].shape[1], out_dat[d].size] for d in range(world)], dtype=torch.int64)
-        allsz = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(allsz, mine)
-        ops, rbuf = [], {}
+        mine = torch.as_tensor(np.stack([nb_to, ne_to], axis=1).astype(np.int64)).to(wire)
+        if comm is not None:   # C-ABI transport (include/dbcsr_amd_comm.h): allgather + ONE grouped exchange of device buffers
+            gathered = torch.empty((world,) + tuple(mine.shape), dtype=torch.int64, device=wire)
+            comm.allgather_bytes(mine, gathered).synchronize()
+            allsz = gathered.cpu().numpy()
+        else:
+            allsz_t = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allsz_t, mine)
+            allsz = np.stack([a.cpu().numpy() for a in allsz_t])
+        nb_from = allsz[:, rank, 0].astype(np.int64)
+        ne_from = allsz[:, rank, 1].astype(np.int64)
+        rb_lo = np.concatenate([[0], np.cumsum(nb_from)]).astype(np.int64)
+        re_lo = np.concatenate([[0], np.cumsum(ne_from)]).astype(np.int64)
+        recv_dat = torch.empty(int(re_lo[-1]), dtype=dtype, device=dev)
+        recv_idx = np.zeros((2, int(rb_lo[-1])), np.int32)
+        sends, recvs, idx_bufs, dat_bufs = [], [], {}, {}
         for d in range(world):
             if d == rank:
                 continue
-            if out_idx[d].shape[1]:
-                ops.append(dist.P2POp(dist.isend, torch.from_numpy(np.ascontiguousarray(out_idx[d])), d))
-                ops.append(dist.P2POp(dist.isend, torch.from_numpy(np.ascontiguousarray(out_dat[d])), d))
-            nb, ne = int(allsz[d][rank][0]), int(allsz[d][rank][1])
-            if nb:
-                rbuf[d] = (torch.empty((2, nb), dtype=torch.int32), torch.empty(ne, dtype=dtype))
-                ops.append(dist.P2POp(dist.irecv, rbuf[d][0], d))
-                ops.append(dist.P2POp(dist.irecv, rbuf[d][1], d))
-        for w in (dist.batch_isend_irecv(ops) if ops else []):
-            w.wait()
-        idx = [out_idx[rank]] + [rbuf[d][0].numpy() for d in sorted(rbuf)]
-        dat = [out_dat[rank]] + [rbuf[d][1].numpy() for d in sorted(rbuf)]
+            if nb_to[d]:
+                ti = torch.from_numpy(np.ascontiguousarray(idx_out[:, b_lo[d]:b_lo[d + 1]])).to(wire)
+                td = packed[int(e_lo[d]):int(e_lo[d + 1])].to(wire)
+                sends += [(ti, d), (td, d)]
+            if nb_from[d]:
+                idx_bufs[d] = torch.empty((2, int(nb_from[d])), dtype=torch.int32, device=wire)
+                seg = recv_dat[int(re_lo[d]):int(re_lo[d + 1])]
+                dat_bufs[d] = seg if seg.device == wire else torch.empty(int(ne_from[d]), dtype=dtype, device=wire)
+                recvs += [(idx_bufs[d], d), (dat_bufs[d], d)]
+        if comm is not None:
+            comm.exchange(sends, recvs).synchronize()
+        else:
+            ops = [dist.P2POp(dist.isend, t, d) for t, d in sends] + [dist.P2POp(dist.irecv, t, d) for t, d in recvs]
+            for w in (dist.batch_isend_irecv(ops) if ops else []):
+                w.wait()
+            if wire.type == "cuda":
+                torch.cuda.synchronize()
+        for d in idx_bufs:
+            recv_idx[:, rb_lo[d]:rb_lo[d + 1]] = idx_bufs[d].cpu().numpy()
+            seg = recv_dat[int(re_lo[d]):int(re_lo[d + 1])]
+            if dat_bufs[d].data_ptr() != seg.data_ptr():
+                seg.copy_(dat_bufs[d])
+        # my own share never touches the wire
+        recv_idx[:, rb_lo[rank]:rb_lo[rank + 1]] = idx_out[:, b_lo[rank]:b_lo[rank + 1]]
+        recv_dat[int(re_lo[rank]):int(re_lo[rank + 1])] = packed[int(e_lo[rank]):int(e_lo[rank + 1])]
+        rows, cols, data = recv_idx[0].copy(), recv_idx[1].copy(), recv_dat
     else:
-        idx, dat = [out_idx[0]], [out_dat[0]]
-    rows = np.concatenate([x[0] for x in idx]).astype(np.int32)
-    cols = np.concatenate([x[1] for x in idx]).astype(np.int32)
-    data = np.concatenate(dat) if dat else np.zeros(0)
+        rows, cols, data = idx_out[0].copy(), idx_out[1].copy(), packed
     n_in = row_sizes[rows].astype(np.int64) * col_sizes[cols].astype(np.int64) if len(rows) else np.zeros(0, np.int64)
     o_in = np.concatenate([[0], np.cumsum(n_in)]).astype(np.int64)
     order = np.lexsort((cols, rows))
     rows, cols = rows[order], cols[order]
-    sdata = np.concatenate([data[o_in[b]:o_in[b + 1]] for b in order]) if len(order) else np.zeros(0, data.dtype)
+    sdata = gather_blocks(data, o_in[order], n_in[order])
     soff = np.concatenate([[0], np.cumsum(n_in[order])]).astype(np.int64)
     # index metadata of the whole matrix: every rank publishes the coordinates of the blocks it now owns
     if world > 1:
@@ -256,13 +323,15 @@ class CannonMultiply:
             (dA, dB, dC), (sm, sk, sn) = distributed
             sm, sk, sn = (np.asarray(x, np.int32) for x in (sm, sk, sn))
             P0 = Partition(sm, sk, sn, g)
-            dests = {"A": lambda rr, cc: np.asarray([g.a_owner(int(P0.row_dist[i]), int(P0.k_dist[k])) for i, k in zip(rr, cc)]),
-                     "B": lambda rr, cc: np.asarray([g.b_owner(int(P0.k_dist[k]), int(P0.col_dist[j])) for k, j in zip(rr, cc)]),
-                     "C": lambda rr, cc: np.asarray([g.rank_of(int(P0.row_dist[i]), int(P0.col_dist[j])) for i, j in zip(rr, cc)])}
-            np_dtype = np.float64 if dtype == torch.float64 else np.float32
+            # owner of a block's target image (Grid.a_owner / b_owner / rank_of, on whole index arrays)
+            dests = {"A": lambda rr, cc: g.a_owner(P0.row_dist[rr].astype(np.int64), P0.k_dist[cc].astype(np.int64)),
+                     "B": lambda rr, cc: g.b_owner(P0.k_dist[rr].astype(np.int64), P0.col_dist[cc].astype(np.int64)),
+                     "C": lambda rr, cc: g.rank_of(P0.row_dist[rr].astype(np.int64), P0.col_dist[cc].astype(np.int64))}
             self._owned, self.pat = {}, {}
             for w, loc, (rsz, csz) in (("C", dC, (sm, sn)), ("A", dA, (sm, sk)), ("B", dB, (sk, sn))):
-                owned, everyone = redistribute(DistBlocks(loc.rows, loc.cols, np.asarray(loc.data, np_dtype)), dests[w], rsz, csz, dtype)
+                src = loc.data if isinstance(loc.data, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(loc.data))
+                # the blocks go to HBM once, before the redistribution: packing, exchange and sorting happen there
+                owned, everyone = redistribute(DistBlocks(loc.rows, loc.cols, src.to(self.device, dtype)), dests[w], rsz, csz, dtype, comm=self.comm)
                 self._owned[w] = owned
                 rows_all = np.concatenate([e[0] for e in everyone]).astype(np.int32)
                 cols_all = np.concatenate([e[1] for e in everyone]).astype(np.int32)
@@ -360,7 +429,7 @@ class CannonMultiply:
                 kkey = rows[keep].astype(np.int64) * ncol_t + cols[keep]
                 pos = np.searchsorted(okey, kkey)
                 assert len(okey) and np.array_equal(okey[pos], kkey), "image block missing after redistribution"
-                M.data.copy_(torch.as_tensor(np.concatenate([odat[ooff[p]:ooff[p + 1]] for p in pos])).to(self.device))
+                M.data.copy_(gather_blocks(odat, ooff[pos], ooff[pos + 1] - ooff[pos]).to(self.device))
             elif self._host is not None:  # cut the kept blocks out of the replicated global matrix
                 h = self._host[which]
                 hb, hd = np.asarray(h.blk_p, np.int64), np.asarray(h.data)

@@ -113,3 +113,70 @@ def test_grid_and_schedule_properties():
                 assert len(set(vs)) == pr
                 assert all(g0.b_owner(v, c) % pc == c for v in vs)
     assert list(cannon.dist_bin([5, 5, 5, 3, 1], 2)) == [0, 1, 0, 1, 1]
+
+
+class _FakeComm:
+    """Same call interface as dbcsr_amd.comm.NativeComm (allgather_bytes / exchange returning something to synchronize on),
+    carried by gloo: checks the call sequence redistribute() makes on the C-ABI transport."""
+
+    class _Done:
+        def synchronize(self):
+            pass
+
+    def exchange(self, sends, recvs):
+        ops = [dist.P2POp(dist.isend, t, d) for t, d in sends] + [dist.P2POp(dist.irecv, t, d) for t, d in recvs]
+        for w in (dist.batch_isend_irecv(ops) if ops else []):
+            w.wait()
+        return self._Done()
+
+    def allgather_bytes(self, t_send, t_recv):
+        dist.all_gather([t_recv[r] for r in range(t_recv.shape[0])], t_send)
+        return self._Done()
+
+
+def _redist_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dbcsr_amd import cannon
+        rng = np.random.default_rng(11)
+        rs = rng.integers(1, 9, size=17).astype(np.int32)
+        cs = rng.integers(1, 9, size=13).astype(np.int32)
+        present = np.argwhere(rng.random((17, 13)) < 0.5)
+        rows_g, cols_g = present[:, 0].astype(np.int32), present[:, 1].astype(np.int32)
+        vals = {(int(r), int(c)): rng.standard_normal(int(rs[r]) * int(cs[c])) for r, c in zip(rows_g, cols_g)}
+        holder = (rows_g * 5 + cols_g * 3) % world           # where a block starts
+        dest_of = lambda rr, cc: (rr.astype(np.int64) + 2 * cc) % world   # where it has to go
+        mine = np.nonzero(holder == rank)[0][::-1]           # in no particular order
+        loc = cannon.DistBlocks(rows_g[mine], cols_g[mine],
+                                np.concatenate([vals[(int(rows_g[b]), int(cols_g[b]))] for b in mine]) if len(mine) else np.zeros(0))
+        res = []
+        for comm in (None, _FakeComm()):
+            (rows, cols, off, data), everyone = cannon.redistribute(loc, dest_of, rs, cs, torch.float64, comm=comm)
+            ok = all(int(dest_of(np.asarray([r]), np.asarray([c]))[0]) == rank for r, c in zip(rows, cols))
+            ok = ok and np.array_equal(np.lexsort((cols, rows)), np.arange(len(rows)))
+            ok = ok and all(np.array_equal(data[off[b]:off[b + 1]].numpy(), vals[(int(rows[b]), int(cols[b]))]) for b in range(len(rows)))
+            total = sum(len(e[0]) for e in everyone)
+            ok = ok and total == len(rows_g) and np.array_equal(everyone[rank][0], rows)
+            res.append(bool(ok))
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_redistribute_torch_and_c_abi_call_sequence():
+    """make_images for one matrix on 3 ranks: every block arrives at the owner of its image, sorted, bit-identical; the same
+    through the call interface of the C-ABI exchange (allgather of sizes + one grouped exchange)."""
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_redist_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(p.exitcode == 0 for p in procs)
+    assert all(res == [True, True] for _, res in got), got

@@ -22,7 +22,24 @@ def main():
     from dbcsr_amd import cannon
     from dbcsr_amd.multiply import MultiplyEngine
     M, N, K, sp = 23 * 60 + 16, 23 * 50 + 16, 23 * 70 + 16, (0.8, 0.8, 0.85)
-    plan = cannon.CannonMultiply(M, N, K, sp, [1, 23], dtype=torch.float64, engine=MultiplyEngine(), mode=mode)
+    if mode.endswith("+dist"):
+        # distributed input: every rank holds an arbitrary share of the blocks of A, B and C, their data in HBM; make_images
+        # (cannon.redistribute) packs, exchanges and sorts them on the device
+        from oracle import oracle as O
+        A, B, Cm = O.perf_case(M, N, K, *sp, [1, 23], [1, 23], [1, 23])
+
+        def part(Mx, salt):
+            rows = Mx.rows()
+            mine = [b for b in range(Mx.nblks) if (b * 7 + salt * 3 + int(rows[b])) % world == rank]
+            ne = [int(Mx.row_sizes[rows[b]]) * int(Mx.col_sizes[Mx.col_i[b]]) for b in mine]
+            data = np.concatenate([Mx.data[Mx.blk_p[b]:Mx.blk_p[b] + n] for b, n in zip(mine, ne)]) if mine else np.zeros(0)
+            z = np.zeros(0, np.int32)
+            return cannon.DistBlocks(rows[mine] if mine else z, Mx.col_i[mine] if mine else z, torch.from_numpy(data).cuda())
+
+        plan = cannon.CannonMultiply(dtype=torch.float64, engine=MultiplyEngine(), mode=mode.split("+")[0],
+                                     distributed=((part(A, 1), part(B, 2), part(Cm, 3)), (A.row_sizes, A.col_sizes, B.col_sizes)))
+    else:
+        plan = cannon.CannonMultiply(M, N, K, sp, [1, 23], dtype=torch.float64, engine=MultiplyEngine(), mode=mode)
     for _ in range(2):
         Cout, counts = plan.multiply(0.5, 2.0)
     torch.cuda.synchronize()
