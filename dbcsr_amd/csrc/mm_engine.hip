@@ -1079,7 +1079,7 @@ __global__ void __launch_bounds__(256) mm_numeric_f64_hot(const Desc* __restrict
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int64_t pos = (int64_t)wg * 4 + wid;
+  const int64_t pos = (int64_t)wg * (int)(blockDim.x >> 6) + wid;  // 1, 2 or 4 waves per workgroup (Engine::wg_waves)
   Desc d;
   Entry first;
   if (work) {  // launch-order records: descriptor and first product in one read
@@ -1116,7 +1116,7 @@ __global__ void __launch_bounds__(256) mm_numeric_f64_lds(const Desc* __restrict
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int64_t pos = (int64_t)wg * 4 + wid;  // gridDim.x * 4 == padded length of order[]
+  const int64_t pos = (int64_t)wg * (int)(blockDim.x >> 6) + wid;  // gridDim.x * waves per workgroup == padded length of order[]
   const int64_t cb = order[pos];
   if (cb < 0 || cb >= nblk) return;
   if ((dbg & 32) && descs[cb].prod_cnt == 0) return;  // in-place accumulation (beta = 1): untouched blocks stay as they are
@@ -2278,12 +2278,12 @@ namespace dbcsr_amd {
 
 static bool launch_hot_f64(int m, int n, int k, dim3 grid, size_t lds_bytes, hipStream_t st, const Desc* descs, int64_t nblk,
                            const Entry* entries, const double* a_data, const double* b_data, double* c_out, const double* c_in,
-                           double alpha, double beta, int lds_a, int lds_wave, int dbg, const int* order, const Work* work) {
+                           double alpha, double beta, int lds_a, int lds_wave, int dbg, const int* order, const Work* work, int wg_waves) {
   if (m != n || m != k) return false;
   switch (m) {
 #define DBCSR_HOT_CASE(S_)                                                                                                      \
   case S_:                                                                                                                      \
-    hipLaunchKernelGGL((mm_numeric_f64_hot<S_, S_, S_>), grid, dim3(256), lds_bytes, st, descs, nblk, entries, a_data, b_data, c_out, \
+    hipLaunchKernelGGL((mm_numeric_f64_hot<S_, S_, S_>), grid, dim3(64 * wg_waves), lds_bytes, st, descs, nblk, entries, a_data, b_data, c_out, \
                        c_in, alpha, beta, lds_a, lds_wave, dbg, order, work);                                                   \
     return true;
     DBCSR_AMD_HOT_SIZES(DBCSR_HOT_CASE)
@@ -2348,6 +2348,10 @@ struct Engine {
   FilterArgs filter = {nullptr, nullptr, 0.0f};
   int64_t flt_nblks = 0;
   DevBuf<int> order, order_cnt;
+  int wg_waves = 1;   // DBCSR_AMD_MM_WG_WAVES = 1 | 2 | 4: waves per workgroup of the exact-size fp64 kernels.  A workgroup's LDS is
+                      // released when its LAST wave ends, so with product lists of uneven length fewer waves per workgroup keep
+                      // more of the CU's wave slots busy (config 3: kernel 8.93 / 8.09 / 7.51 ms for 4 / 2 / 1, config 2: 23.6 / 22.7 /
+                      // 22.6, config 4: 30.1 / 28.8 / 28.4 on the same box, profiles/r02_wg_waves_bench_lines.txt)
   DevBuf<Work> work;  // launch-order records of the exact-size fp64 kernels (DBCSR_AMD_MM_WORK=0: order[] -> descs[] -> entries[] instead)
   int use_work = 1;
   DevBuf<int64_t> order_base;
@@ -2431,6 +2435,10 @@ int dbcsr_amd_mm_create(void** handle) {
   if (const char* k = getenv("DBCSR_AMD_MM_PIPE_G")) E->pipe_g = std::max(1, atoi(k));
   if (const char* k = getenv("DBCSR_AMD_MM_CLASSES")) E->use_classes = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_WORK")) E->use_work = atoi(k);
+  if (const char* k = getenv("DBCSR_AMD_MM_WG_WAVES")) {
+    const int w = atoi(k);
+    if (w == 1 || w == 2 || w == 4) E->wg_waves = w;
+  }
   if (const char* k = getenv("DBCSR_AMD_MM_CLASS_G")) {
     const int g = atoi(k);
     E->class_g = (g == 2 || g == 4 || g == 8) ? g : 1;
@@ -2829,7 +2837,9 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
           int p_skip = skip_empty;
           const Work* p_work = hot_work ? hot_work + E->cls_off[c] : nullptr;
           void* args[] = {&p_descs, &p_nblk, &p_entries, &p_a, &p_b, &p_c, &p_ci, &p_alpha, &p_beta, &p_skip, &ord, &p_work};
-          ACC_CHECK(hipModuleLaunchKernel(ck.fn, nwg_c / (unsigned)E->class_g, 1, 1, 256, 1, 1, (unsigned)(4 * ck.wave_lds), st, args, nullptr));
+          const unsigned ww = E->class_g == 1 ? (unsigned)E->wg_waves : 4u;  // waves per workgroup (the G-block stream body keeps 4)
+          ACC_CHECK(hipModuleLaunchKernel(ck.fn, (unsigned)(8 * E->cls_len[c]) / ww / (unsigned)E->class_g, 1, 1, 64 * ww, 1, 1,
+                                          (unsigned)(ww * ck.wave_lds), st, args, nullptr));
           ++njit;
         } else {
           const size_t lb = (size_t)4 * g_lds_wave * sizeof(double);
@@ -2871,10 +2881,11 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
                          static_cast<const double*>(c_in->data), alpha, beta, skip_empty, E->order.p)) {
         snprintf(E->last_kernel, sizeof E->last_kernel, "mm_numeric_f64_dma<%d,%d,%d,%d>", E->hot_m, E->hot_n, E->hot_k, E->dma_stages);
       } else if (E->use_hot && E->use_pipe != 1 && E->hot_m > 0 &&
-          launch_hot_f64(E->hot_m, E->hot_n, E->hot_k, dim3(nwg_o), lds_bytes, st, E->descs.p, nblk, E->entries.p,
+          launch_hot_f64(E->hot_m, E->hot_n, E->hot_k, dim3((unsigned)(8 * E->order_len / E->wg_waves)),
+                         (size_t)E->wg_waves * lds_wave * sizeof(double) + (size_t)E->lds_pad, st, E->descs.p, nblk, E->entries.p,
                          static_cast<const double*>(a->data), static_cast<const double*>(b->data), static_cast<double*>(c_out->data),
                          static_cast<const double*>(c_in->data), alpha, beta, lds_a, lds_wave, E->dbg | (skip_empty ? 32 : 0), E->order.p,
-                         hot_work)) {
+                         hot_work, E->wg_waves)) {
         // launched: C blocks of the dominant size take the exact-size path, the others the generic one
         snprintf(E->last_kernel, sizeof E->last_kernel, "mm_numeric_f64_hot<%d,%d,%d>", E->hot_m, E->hot_n, E->hot_k);
       } else {

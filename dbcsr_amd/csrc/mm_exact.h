@@ -305,7 +305,7 @@ __device__ __forceinline__ void mm_class_kernel_body(const Desc* __restrict__ de
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int64_t pos = (int64_t)wg * 4 + wid;
+  const int64_t pos = (int64_t)wg * (int)(blockDim.x >> 6) + wid;  // 1, 2 or 4 waves per workgroup
   Desc d;
   Entry first = Entry::make(0, 0, 0);
   bool have_first = false;

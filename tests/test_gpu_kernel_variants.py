@@ -57,6 +57,11 @@ VARIANTS = [
     ({"DBCSR_AMD_MM_CLASSES": "2", "DBCSR_AMD_MM_CLASS_G": "8"}, MIXED, "mm_numeric_f64_class["),
     ({"DBCSR_AMD_MM_CLASSES": "2", "DBCSR_AMD_MM_CLASS_G": "4"}, POW2, "mm_numeric_f64_class["),
     ({"DBCSR_AMD_MM_CLASSES": "2", "DBCSR_AMD_MM_CLASS_G": "8"}, H2O, "mm_numeric_f64_class["),   # what the automatic choice runs below the class threshold
+    # four / two waves per workgroup (the default is one)
+    ({"DBCSR_AMD_MM_WG_WAVES": "4"}, H2O, "mm_numeric_f64_hot<23,23,23>"),
+    ({"DBCSR_AMD_MM_WG_WAVES": "2"}, H2O, "mm_numeric_f64_hot<23,23,23>"),
+    ({"DBCSR_AMD_MM_WG_WAVES": "4", "DBCSR_AMD_MM_CLASSES": "2"}, CONFIG3_37, "mm_numeric_f64_class[9 jit + 1 generic"),
+    ({"DBCSR_AMD_MM_WG_WAVES": "2", "DBCSR_AMD_MM_CLASSES": "2"}, MIXED, "mm_numeric_f64_class["),
     # without the launch-order work records (the default has them): order[] -> descs[] -> entries[]
     ({"DBCSR_AMD_MM_WORK": "0"}, H2O, "mm_numeric_f64_hot<23,23,23>"),
     ({"DBCSR_AMD_MM_WORK": "0", "DBCSR_AMD_MM_CLASSES": "2"}, CONFIG3_37, "mm_numeric_f64_class[9 jit + 1 generic"),
@@ -65,7 +70,7 @@ VARIANTS = [
 
 
 def run_case(monkeypatch, env, case, dtype, tol, expect, alpha=0.7, beta=1.3, retain=False, in_place_twice=False):
-    for k in ("DBCSR_AMD_MM_KERNEL", "DBCSR_AMD_MM_HOT", "DBCSR_AMD_MM_TINY", "DBCSR_AMD_MM_PIPE_G", "DBCSR_AMD_MM_SYMBOLIC", "DBCSR_AMD_MM_CLASSES", "DBCSR_AMD_MM_CLASS_G", "DBCSR_AMD_MM_WORK"):
+    for k in ("DBCSR_AMD_MM_KERNEL", "DBCSR_AMD_MM_HOT", "DBCSR_AMD_MM_TINY", "DBCSR_AMD_MM_PIPE_G", "DBCSR_AMD_MM_SYMBOLIC", "DBCSR_AMD_MM_CLASSES", "DBCSR_AMD_MM_CLASS_G", "DBCSR_AMD_MM_WORK", "DBCSR_AMD_MM_WG_WAVES"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
