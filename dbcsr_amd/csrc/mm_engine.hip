@@ -1614,12 +1614,14 @@ __device__ __forceinline__ void cblock_f32_exact(const Desc& d, const Entry* __r
   }
 }
 
+static inline size_t f32_lds_bytes(int wg_waves) { return ((size_t)wg_waves * F32_WAVE_FLOATS + 4) * sizeof(float); }
 #define DBCSR_F32_KERNEL_HEAD                                                                          \
-  __shared__ __attribute__((aligned(16))) float smem[4 * F32_WAVE_FLOATS + 4];                          \
+  extern __shared__ __attribute__((aligned(16))) char smem_raw_[]; /* f32_lds_bytes(waves per workgroup) */ \
+  float* smem = reinterpret_cast<float*>(smem_raw_);                                                   \
   const int lane = threadIdx.x & 63;                                                                   \
   const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));                             \
   const int wg = xcd_remap(blockIdx.x, gridDim.x);                                                     \
-  const int64_t pos = (int64_t)wg * 4 + wid;                                                           \
+  const int64_t pos = (int64_t)wg * (int)(blockDim.x >> 6) + wid;                                      \
   const int64_t cb = order[pos];                                                                       \
   if (cb < 0 || cb >= nblk) return;                                                                    \
   const Desc d = descs[cb];                                                                            \
@@ -2320,14 +2322,14 @@ static bool launch_dma_f64(int S, int m, int n, int k, unsigned npos, hipStream_
   }
 }
 
-static bool launch_hot_f32(int m, int n, int k, dim3 grid, hipStream_t st, const Desc* descs, int64_t nblk, const Entry* entries,
+static bool launch_hot_f32(int m, int n, int k, dim3 grid, int wg_waves, hipStream_t st, const Desc* descs, int64_t nblk, const Entry* entries,
                            const float* a_data, const float* b_data, float* c_out, const float* c_in, float alpha, float beta,
                            int skip_empty, const int* order) {
   if (m != n || m != k) return false;
   switch (m) {
 #define DBCSR_HOT_CASE(S_)                                                                                                     \
   case S_:                                                                                                                     \
-    hipLaunchKernelGGL((mm_numeric_f32_hot<S_, S_, S_>), grid, dim3(256), 0, st, descs, nblk, entries, a_data, b_data, c_out, c_in, \
+    hipLaunchKernelGGL((mm_numeric_f32_hot<S_, S_, S_>), grid, dim3(64 * wg_waves), f32_lds_bytes(wg_waves), st, descs, nblk, entries, a_data, b_data, c_out, c_in, \
                        alpha, beta, skip_empty, order);                                                                        \
     return true;
     DBCSR_AMD_HOT_SIZES(DBCSR_HOT_CASE)
@@ -2348,7 +2350,7 @@ struct Engine {
   FilterArgs filter = {nullptr, nullptr, 0.0f};
   int64_t flt_nblks = 0;
   DevBuf<int> order, order_cnt;
-  int wg_waves = 1;   // DBCSR_AMD_MM_WG_WAVES = 1 | 2 | 4: waves per workgroup of the exact-size fp64 kernels.  A workgroup's LDS is
+  int wg_waves = 0;   // DBCSR_AMD_MM_WG_WAVES = 1 | 2 | 4: waves per workgroup of the one-wave-per-C-block kernels (0: by list length).  A workgroup's LDS is
                       // released when its LAST wave ends, so with product lists of uneven length fewer waves per workgroup keep
                       // more of the CU's wave slots busy (config 3: kernel 8.93 / 8.09 / 7.51 ms for 4 / 2 / 1, config 2: 23.6 / 22.7 /
                       // 22.6, config 4: 30.1 / 28.8 / 28.4 on the same box, profiles/r02_wg_waves_bench_lines.txt)
@@ -2783,6 +2785,11 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
                        E->descs.p, E->entries.p);
   }
   const unsigned nwg = (unsigned)((nblk + 3) / 4);
+  // waves per workgroup of the one-wave-per-C-block kernels.  A workgroup's LDS is released when its LAST wave ends: with short,
+  // uneven product lists one wave per workgroup keeps more wave slots busy (config 3: kernel 8.93 -> 7.51 ms, generic LDS kernel
+  // 12.3 -> 9.2, config 2: -5 %, config 4: -6 %); with long lists four waves per workgroup are faster (config 5, 164 products per
+  // block: 2.03 s against 2.27 s)
+  const int ww = E->wg_waves > 0 ? E->wg_waves : (E->nproducts <= 32 * nblk ? 1 : 4);
   // in-place accumulation (Cannon ticks after the first): C blocks without products in this call are left untouched
   const int skip_empty = (c_out->data == c_in->data && E->retain && beta == 1.0) ? 1 : 0;
   // launch-order work records for the exact-size fp64 kernels (one wave per C block): descriptor + first product in one read
@@ -2837,14 +2844,14 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
           int p_skip = skip_empty;
           const Work* p_work = hot_work ? hot_work + E->cls_off[c] : nullptr;
           void* args[] = {&p_descs, &p_nblk, &p_entries, &p_a, &p_b, &p_c, &p_ci, &p_alpha, &p_beta, &p_skip, &ord, &p_work};
-          const unsigned ww = E->class_g == 1 ? (unsigned)E->wg_waves : 4u;  // waves per workgroup (the G-block stream body keeps 4)
-          ACC_CHECK(hipModuleLaunchKernel(ck.fn, (unsigned)(8 * E->cls_len[c]) / ww / (unsigned)E->class_g, 1, 1, 64 * ww, 1, 1,
-                                          (unsigned)(ww * ck.wave_lds), st, args, nullptr));
+          const unsigned cw = E->class_g == 1 ? (unsigned)ww : 4u;  // waves per workgroup (the G-block stream body keeps 4)
+          ACC_CHECK(hipModuleLaunchKernel(ck.fn, (unsigned)(8 * E->cls_len[c]) / cw / (unsigned)E->class_g, 1, 1, 64 * cw, 1, 1,
+                                          (unsigned)(cw * ck.wave_lds), st, args, nullptr));
           ++njit;
         } else {
-          const size_t lb = (size_t)4 * g_lds_wave * sizeof(double);
+          const size_t lb = (size_t)ww * g_lds_wave * sizeof(double);
 #define DBCSR_LAUNCH_G(T_)                                                                                                         \
-  hipLaunchKernelGGL(mm_numeric_f64_lds<T_>, dim3(nwg_c), dim3(256), lb, st, E->descs.p, nblk, E->entries.p,                         \
+  hipLaunchKernelGGL(mm_numeric_f64_lds<T_>, dim3(nwg_c * 4u / (unsigned)ww), dim3(64 * ww), lb, st, E->descs.p, nblk, E->entries.p, \
                      static_cast<const double*>(a->data), static_cast<const double*>(b->data), static_cast<double*>(c_out->data),   \
                      static_cast<const double*>(c_in->data), alpha, beta, g_lds_a, g_lds_wave, dbgv, ord)
           switch (g_maxt) {
@@ -2870,7 +2877,8 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
       const size_t lds_bytes = (size_t)4 * lds_wave * sizeof(double) + (size_t)E->lds_pad;
       const unsigned nwg_o = (unsigned)(8 * E->order_len / 4);
 #define DBCSR_LAUNCH(T_)                                                                                                        \
-  hipLaunchKernelGGL(mm_numeric_f64_lds<T_>, dim3(nwg_o), dim3(256), lds_bytes, st, E->descs.p, nblk, E->entries.p,               \
+  hipLaunchKernelGGL(mm_numeric_f64_lds<T_>, dim3(nwg_o * 4u / (unsigned)ww), dim3(64 * ww),                     \
+                     (size_t)ww * lds_wave * sizeof(double) + (size_t)E->lds_pad, st, E->descs.p, nblk, E->entries.p,     \
                      static_cast<const double*>(a->data), static_cast<const double*>(b->data), static_cast<double*>(c_out->data), \
                      static_cast<const double*>(c_in->data), alpha, beta, lds_a, lds_wave, E->dbg | (skip_empty ? 32 : 0), E->order.p)
       // measured: the pipelined kernel wins when C blocks have few products (config 3: 3.7 per block, 10.4 vs 11.8 ms) and
@@ -2881,11 +2889,11 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
                          static_cast<const double*>(c_in->data), alpha, beta, skip_empty, E->order.p)) {
         snprintf(E->last_kernel, sizeof E->last_kernel, "mm_numeric_f64_dma<%d,%d,%d,%d>", E->hot_m, E->hot_n, E->hot_k, E->dma_stages);
       } else if (E->use_hot && E->use_pipe != 1 && E->hot_m > 0 &&
-          launch_hot_f64(E->hot_m, E->hot_n, E->hot_k, dim3((unsigned)(8 * E->order_len / E->wg_waves)),
-                         (size_t)E->wg_waves * lds_wave * sizeof(double) + (size_t)E->lds_pad, st, E->descs.p, nblk, E->entries.p,
+          launch_hot_f64(E->hot_m, E->hot_n, E->hot_k, dim3((unsigned)(8 * E->order_len / ww)),
+                         (size_t)ww * lds_wave * sizeof(double) + (size_t)E->lds_pad, st, E->descs.p, nblk, E->entries.p,
                          static_cast<const double*>(a->data), static_cast<const double*>(b->data), static_cast<double*>(c_out->data),
                          static_cast<const double*>(c_in->data), alpha, beta, lds_a, lds_wave, E->dbg | (skip_empty ? 32 : 0), E->order.p,
-                         hot_work, E->wg_waves)) {
+                         hot_work, ww)) {
         // launched: C blocks of the dominant size take the exact-size path, the others the generic one
         snprintf(E->last_kernel, sizeof E->last_kernel, "mm_numeric_f64_hot<%d,%d,%d>", E->hot_m, E->hot_n, E->hot_k);
       } else {
@@ -2928,21 +2936,21 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
     if (small32 && E->use_lds && E->cls_mode) {
       for (int c = 0; c < kNumClasses; ++c) {
         if (E->cls_len[c] == 0) continue;
-        hipLaunchKernelGGL(mm_numeric_f32_lds, dim3((unsigned)(8 * E->cls_len[c] / 4)), dim3(256), 0, st, E->descs.p, nblk, E->entries.p,
+        hipLaunchKernelGGL(mm_numeric_f32_lds, dim3((unsigned)(8 * E->cls_len[c] / ww)), dim3(64 * ww), f32_lds_bytes(ww), st, E->descs.p, nblk, E->entries.p,
                            static_cast<const float*>(a->data), static_cast<const float*>(b->data), static_cast<float*>(c_out->data),
                            static_cast<const float*>(c_in->data), (float)alpha, (float)beta, skip_empty, E->order.p + E->cls_off[c]);
       }
       snprintf(E->last_kernel, sizeof E->last_kernel, "mm_numeric_f32_lds[per class segment]");
     } else if (small32 && E->use_lds) {
-      const unsigned nwg_o = (unsigned)(8 * E->order_len / 4);
+      const unsigned nwg_o = (unsigned)(8 * E->order_len / ww);
       if (E->use_hot && E->hot_m > 0 &&
-          launch_hot_f32(E->hot_m, E->hot_n, E->hot_k, dim3(nwg_o), st, E->descs.p, nblk, E->entries.p, static_cast<const float*>(a->data),
+          launch_hot_f32(E->hot_m, E->hot_n, E->hot_k, dim3(nwg_o), ww, st, E->descs.p, nblk, E->entries.p, static_cast<const float*>(a->data),
                          static_cast<const float*>(b->data), static_cast<float*>(c_out->data), static_cast<const float*>(c_in->data),
                          (float)alpha, (float)beta, skip_empty, E->order.p)) {
         snprintf(E->last_kernel, sizeof E->last_kernel, "mm_numeric_f32_hot<%d,%d,%d>", E->hot_m, E->hot_n, E->hot_k);
       } else {
       snprintf(E->last_kernel, sizeof E->last_kernel, "mm_numeric_f32_lds");
-      hipLaunchKernelGGL(mm_numeric_f32_lds, dim3(nwg_o), dim3(256), 0, st, E->descs.p, nblk, E->entries.p,
+      hipLaunchKernelGGL(mm_numeric_f32_lds, dim3(nwg_o), dim3(64 * ww), f32_lds_bytes(ww), st, E->descs.p, nblk, E->entries.p,
                          static_cast<const float*>(a->data), static_cast<const float*>(b->data), static_cast<float*>(c_out->data),
                          static_cast<const float*>(c_in->data), (float)alpha, (float)beta, skip_empty, E->order.p);
       }

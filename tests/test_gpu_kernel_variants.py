@@ -57,9 +57,12 @@ VARIANTS = [
     ({"DBCSR_AMD_MM_CLASSES": "2", "DBCSR_AMD_MM_CLASS_G": "8"}, MIXED, "mm_numeric_f64_class["),
     ({"DBCSR_AMD_MM_CLASSES": "2", "DBCSR_AMD_MM_CLASS_G": "4"}, POW2, "mm_numeric_f64_class["),
     ({"DBCSR_AMD_MM_CLASSES": "2", "DBCSR_AMD_MM_CLASS_G": "8"}, H2O, "mm_numeric_f64_class["),   # what the automatic choice runs below the class threshold
-    # four / two waves per workgroup (the default is one)
+    # four / two / one waves per workgroup (the default goes by the mean product-list length)
     ({"DBCSR_AMD_MM_WG_WAVES": "4"}, H2O, "mm_numeric_f64_hot<23,23,23>"),
     ({"DBCSR_AMD_MM_WG_WAVES": "2"}, H2O, "mm_numeric_f64_hot<23,23,23>"),
+    ({"DBCSR_AMD_MM_WG_WAVES": "1"}, H2O, "mm_numeric_f64_hot<23,23,23>"),
+    ({"DBCSR_AMD_MM_WG_WAVES": "1", "DBCSR_AMD_MM_KERNEL": "lds1", "DBCSR_AMD_MM_HOT": "0"}, MIXED, "mm_numeric_f64_lds"),
+    ({"DBCSR_AMD_MM_WG_WAVES": "4", "DBCSR_AMD_MM_KERNEL": "lds1", "DBCSR_AMD_MM_HOT": "0"}, MIXED, "mm_numeric_f64_lds"),
     ({"DBCSR_AMD_MM_WG_WAVES": "4", "DBCSR_AMD_MM_CLASSES": "2"}, CONFIG3_37, "mm_numeric_f64_class[9 jit + 1 generic"),
     ({"DBCSR_AMD_MM_WG_WAVES": "2", "DBCSR_AMD_MM_CLASSES": "2"}, MIXED, "mm_numeric_f64_class["),
     # without the launch-order work records (the default has them): order[] -> descs[] -> entries[]
@@ -118,6 +121,10 @@ F32_MIXED = (300, 280, 260, 0.5, 0.5, 0.6, [1, 13, 1, 32, 1, 7], [1, 23, 1, 32],
     ({"DBCSR_AMD_MM_KERNEL": "direct"}, F32_MIXED, "mm_numeric_f32"),
     ({}, BIG, "mm_numeric_f32"),
     ({"DBCSR_AMD_MM_CLASSES": "2"}, F32_MIXED, "mm_numeric_f32_lds[per class"),
+    ({"DBCSR_AMD_MM_WG_WAVES": "4"}, F32, "mm_numeric_f32_hot<32,32,32>"),
+    ({"DBCSR_AMD_MM_WG_WAVES": "1"}, F32, "mm_numeric_f32_hot<32,32,32>"),
+    ({"DBCSR_AMD_MM_WG_WAVES": "2"}, F32_MIXED, "mm_numeric_f32_lds"),
+    ({"DBCSR_AMD_MM_WG_WAVES": "4", "DBCSR_AMD_MM_CLASSES": "2"}, F32_MIXED, "mm_numeric_f32_lds[per class"),
 ], ids=lambda v: "-".join("%s=%s" % (k[13:], x) for k, x in v.items()) if isinstance(v, dict) else None)
 def test_fp32_variant_matches_oracle(monkeypatch, env, case, expect):
     run_case(monkeypatch, env, case, np.float32, 2e-5, expect, alpha=1.0, beta=1.0)
