@@ -911,7 +911,7 @@ __device__ __forceinline__ void cblock_f64_lds(const Desc& d, const Entry* __res
 // (the generic path: 103 VALU + 98 SALU instructions per 23^3 product besides the 54 MFMAs).  Products of the
 // block with another inner dimension (the tail block column of A) are multiplied straight from global memory.
 template <int M, int N, int K>
-__device__ __forceinline__ void cblock_f64_exact(const Desc& d, const Entry& first, const Entry* __restrict__ entries, const double* __restrict__ a_data,
+__device__ __forceinline__ void cblock_f64_exact(const Desc& d, const Entry first, const Entry* __restrict__ entries, const double* __restrict__ a_data,
                                                  const double* __restrict__ b_data, double* __restrict__ c_out,
                                                  const double* __restrict__ c_in, double alpha, double beta, const LaneMap& L, int lane,
                                                  char* lds_a, char* lds_b, int dbg) {
@@ -1080,19 +1080,12 @@ __global__ void __launch_bounds__(256) mm_numeric_f64_hot(const Desc* __restrict
   const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
   const int64_t pos = (int64_t)wg * (int)(blockDim.x >> 6) + wid;  // 1, 2 or 4 waves per workgroup (Engine::wg_waves)
-  Desc d;
+  // launch-order records (build_work): descriptor and first product in one read -- no order[] -> descs[] -> entries[] chain
+  const Work w = work[pos];
+  if (w.prod_cnt < 0) return;  // padding position
+  const Desc d = {w.c_off, w.cin_off, w.prod_start, w.prod_cnt, w.m, w.n};
   Entry first;
-  if (work) {  // launch-order records: descriptor and first product in one read
-    const Work w = work[pos];
-    if (w.prod_cnt < 0) return;
-    d.c_off = w.c_off, d.cin_off = w.cin_off, d.prod_start = w.prod_start, d.prod_cnt = w.prod_cnt, d.m = w.m, d.n = w.n;
-    first.a_lo = w.a_lo, first.b_lo = w.b_lo, first.w = w.w;
-  } else {
-    const int64_t cb = order[pos];
-    if (cb < 0 || cb >= nblk) return;
-    d = descs[cb];
-    first = entries[d.prod_start];
-  }
+  first.a_lo = w.a_lo, first.b_lo = w.b_lo, first.w = w.w;
   if ((dbg & 32) && d.prod_cnt == 0) return;
   char* lds_a = smem + (size_t)wid * lds_wave_doubles * 8;
   char* lds_b = lds_a + (size_t)lds_a_doubles * 8;
@@ -2350,11 +2343,16 @@ struct Engine {
   FilterArgs filter = {nullptr, nullptr, 0.0f};
   int64_t flt_nblks = 0;
   DevBuf<int> order, order_cnt;
+  // class launches of one multiply write disjoint C blocks: with DBCSR_AMD_MM_CLASS_STREAMS = n > 1 they are dealt to n streams
+  // forked from / joined to the caller's stream, so that the tail of one launch overlaps the start of the next
+  int class_streams = 1;
+  hipStream_t cls_stream[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t cls_fork = nullptr, cls_join[4] = {nullptr, nullptr, nullptr, nullptr};
   int wg_waves = 0;   // DBCSR_AMD_MM_WG_WAVES = 1 | 2 | 4: waves per workgroup of the one-wave-per-C-block kernels (0: by list length).  A workgroup's LDS is
                       // released when its LAST wave ends, so with product lists of uneven length fewer waves per workgroup keep
                       // more of the CU's wave slots busy (config 3: kernel 8.93 / 8.09 / 7.51 ms for 4 / 2 / 1, config 2: 23.6 / 22.7 /
                       // 22.6, config 4: 30.1 / 28.8 / 28.4 on the same box, profiles/r02_wg_waves_bench_lines.txt)
-  DevBuf<Work> work;  // launch-order records of the exact-size fp64 kernels (DBCSR_AMD_MM_WORK=0: order[] -> descs[] -> entries[] instead)
+  DevBuf<Work> work;  // launch-order records of the exact-size fp64 kernels (DBCSR_AMD_MM_WORK=0: the class kernels read order[] -> descs[] -> entries[] instead)
   int use_work = 1;
   DevBuf<int64_t> order_base;
   int64_t order_len = 0;
@@ -2462,6 +2460,14 @@ int dbcsr_amd_mm_create(void** handle) {
     e = hipEventCreate(&E->ev[i]);
     if (e != hipSuccess) return check(e, "hipEventCreate", __FILE__, __LINE__);
   }
+  if (const char* k = getenv("DBCSR_AMD_MM_CLASS_STREAMS")) E->class_streams = std::max(1, std::min(4, atoi(k)));
+  if (E->class_streams > 1) {
+    if (hipEventCreateWithFlags(&E->cls_fork, hipEventDisableTiming) != hipSuccess) E->class_streams = 1;
+    for (int i = 0; i < E->class_streams && E->class_streams > 1; ++i)
+      if (hipStreamCreateWithFlags(&E->cls_stream[i], hipStreamNonBlocking) != hipSuccess ||
+          hipEventCreateWithFlags(&E->cls_join[i], hipEventDisableTiming) != hipSuccess)
+        E->class_streams = 1;
+  }
   *handle = E;
   return 0;
 }
@@ -2495,6 +2501,11 @@ int dbcsr_amd_mm_destroy(void* handle) {
   E->cls_hist.release(); E->cls_row.release(); E->cls_col.release(); E->cls_col_bm.release(); E->cls_lens.release();
   for (int i = 0; i < 3; ++i)
     if (E->ev[i]) (void)hipEventDestroy(E->ev[i]);
+  for (int i = 0; i < 4; ++i) {
+    if (E->cls_stream[i]) (void)hipStreamDestroy(E->cls_stream[i]);
+    if (E->cls_join[i]) (void)hipEventDestroy(E->cls_join[i]);
+  }
+  if (E->cls_fork) (void)hipEventDestroy(E->cls_fork);
   delete E;
   return 0;
 }
@@ -2797,10 +2808,11 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
   {
     const bool small64 = datatype == dbcsr_type_real_8 && E->use_lds && E->max_m <= 32 && E->max_k <= 32 && E->max_n <= 32 && E->min_m >= 1 &&
                          E->min_k >= 1 && E->min_n >= 1 && !(E->use_tiny && E->max_m <= 4 && E->max_n <= 4);
-    const bool exact = E->cls_mode ? E->class_g == 1
+    // (the ahead-of-time exact-size kernel reads nothing else; the class kernels keep the order[] -> descs[] path for DBCSR_AMD_MM_WORK=0)
+    const bool exact = E->cls_mode ? (E->class_g == 1 && E->use_work)
                                    : (E->use_hot && E->use_pipe != 1 && E->hot_m > 0 && E->dma_stages == 0 && E->hot_m == E->hot_n && E->hot_m == E->hot_k);
     const int64_t npos = 8 * E->order_len;
-    if (E->use_work && small64 && exact && npos > 0) {
+    if (small64 && exact && npos > 0) {
       if (E->work.ensure((size_t)npos + 1)) return -1;
       hipLaunchKernelGGL(build_work, grid_for(npos), dim3(256), 0, st, E->order.p, npos, E->descs.p, nblk, E->entries.p, E->work.p);
       hot_work = E->work.p;
@@ -2825,9 +2837,16 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
       const int g_lds_wave = g_lds_a + g_lds_b;
       const int g_maxt = (std::max(E->max_m, E->max_n) + 7) / 8;
       const int dbgv = E->dbg | (skip_empty ? 32 : 0);
-      int njit = 0, ngen = 0;
+      int njit = 0, ngen = 0, nlaunch = 0;
+      const int NS = E->class_streams;
+      hipStream_t st_main = st;
+      if (NS > 1) {
+        ACC_CHECK(hipEventRecord(E->cls_fork, st_main));
+        for (int i = 0; i < NS; ++i) ACC_CHECK(hipStreamWaitEvent(E->cls_stream[i], E->cls_fork, 0));
+      }
       for (int c = 0; c < kNumClasses; ++c) {
         if (E->cls_len[c] == 0) continue;
+        if (NS > 1) st = E->cls_stream[nlaunch++ % NS];
         const int* ord = E->order.p + E->cls_off[c];
         const unsigned nwg_c = (unsigned)(8 * E->cls_len[c] / 4);
         ClassKernel ck;
@@ -2862,6 +2881,13 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
           }
 #undef DBCSR_LAUNCH_G
           ++ngen;
+        }
+      }
+      if (NS > 1) {
+        st = st_main;
+        for (int i = 0; i < NS; ++i) {
+          ACC_CHECK(hipEventRecord(E->cls_join[i], E->cls_stream[i]));
+          ACC_CHECK(hipStreamWaitEvent(st_main, E->cls_join[i], 0));
         }
       }
       snprintf(E->last_kernel, sizeof E->last_kernel, "mm_numeric_f64_class[%d jit + %d generic launches; m {%d,%d,%d} n {%d,%d,%d} k {%d,%d,%d}]", njit,

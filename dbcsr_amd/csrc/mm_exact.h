@@ -106,7 +106,7 @@ __device__ __forceinline__ int staged_offset(int c, int lane) {
 }
 
 template <int M, int N, int K0, int K1, int K2>
-__device__ __forceinline__ void cblock_f64_classes(const Desc& d, const Entry& first, bool have_first, const Entry* __restrict__ entries,
+__device__ __forceinline__ void cblock_f64_classes(const Desc& d, const Entry first, bool have_first, const Entry* __restrict__ entries,
                                                    const double* __restrict__ a_data,
                                                    const double* __restrict__ b_data, double* __restrict__ c_out,
                                                    const double* __restrict__ c_in, double alpha, double beta, const LaneMap& L, int lane,

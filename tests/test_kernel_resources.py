@@ -1,0 +1,71 @@
+"""Register / scratch budget of the compiled gfx950 kernels, read from the code objects inside the built library (no GPU needed).
+A refactoring of the exact-size kernel's prologue once cost config 2 fifteen per cent without failing any parity test: a struct
+passed by reference landed in scratch memory and the register count crossed an occupancy step.  This pins what the measured
+numbers rely on: no kernel uses scratch, and the exact-size kernels keep the occupancy their LDS slice allows."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "dbcsr_amd", "libdbcsr_acc_amd.so")
+LLVM = "/opt/rocm/lib/llvm/bin"
+MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
+
+
+def kernels_of_library(tmp_path):
+    objcopy, bundler, readelf = (os.path.join(LLVM, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf"))
+    if not (os.path.exists(LIB) and all(os.path.exists(t) for t in (objcopy, bundler, readelf))):
+        pytest.skip("library or LLVM binutils not available")
+    fat = tmp_path / "fat.bin"
+    subprocess.check_call([objcopy, "--dump-section", ".hip_fatbin=%s" % fat, LIB, str(tmp_path / "unused.so")])
+    blob = fat.read_bytes()
+    starts = [m.start() for m in re.finditer(re.escape(MAGIC), blob)]
+    out = {}
+    for i, s in enumerate(starts):   # one bundle per translation unit
+        part = tmp_path / ("bundle%d.bin" % i)
+        part.write_bytes(blob[s:starts[i + 1] if i + 1 < len(starts) else len(blob)])
+        co = tmp_path / ("gfx950_%d.co" % i)
+        r = subprocess.run([bundler, "--type=o", "--unbundle", "--input=%s" % part, "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                            "--output=%s" % co], capture_output=True, text=True)
+        if r.returncode != 0 or not co.exists() or co.stat().st_size == 0:
+            continue
+        notes = subprocess.run([readelf, "--notes", str(co)], capture_output=True, text=True).stdout
+        cur = {}
+        for line in notes.splitlines():
+            m = re.match(r"\s*-?\s*\.(name|private_segment_fixed_size|vgpr_count|sgpr_count|group_segment_fixed_size):\s*(\S+)", line)
+            if not m:
+                if line.strip().startswith("- .") and cur.get("name"):
+                    cur = {}
+                continue
+            k, v = m.groups()
+            cur[k] = v if k == "name" else int(v)
+            if "name" in cur and "private_segment_fixed_size" in cur and "vgpr_count" in cur:
+                out[cur["name"]] = dict(cur)
+    return out
+
+
+def demangle(names):
+    filt = shutil.which("c++filt") or os.path.join(LLVM, "llvm-cxxfilt")
+    r = subprocess.run([filt], input="\n".join(names), capture_output=True, text=True)
+    return dict(zip(names, r.stdout.splitlines()))
+
+
+def test_no_scratch_and_exact_kernels_keep_their_occupancy(tmp_path):
+    ks = kernels_of_library(tmp_path)
+    assert len(ks) > 100, "expected the whole kernel set of the library, got %d" % len(ks)
+    pretty = demangle(sorted(ks))
+    spilled = {pretty[n]: k["private_segment_fixed_size"] for n, k in ks.items() if k["private_segment_fixed_size"] > 0}
+    assert not spilled, "kernels using scratch memory: %s" % spilled
+    hot64 = {pretty[n]: k["vgpr_count"] for n, k in ks.items() if "mm_numeric_f64_hot<" in pretty[n]}
+    hot32 = {pretty[n]: k["vgpr_count"] for n, k in ks.items() if "mm_numeric_f32_hot<" in pretty[n]}
+    assert len(hot64) >= 20 and len(hot32) >= 20
+    # 512 registers per SIMD lane.  Blocks up to 24 x 24: 4 waves per SIMD (16 per CU, what a 9.5 KB LDS slice allows for 23 x 23)
+    # need <= 128 (vgpr_count of the code object = arch + accumulation registers, allocation granule included); blocks of 25 ... 32
+    # hold 16 accumulators and their 13-16 KB LDS slice allows 10-12 waves per CU anyway: 152-180 today (2-3 waves per SIMD)
+    size_of = lambda n: int(re.search(r"hot<(\d+),", n).group(1))
+    too_big = {n: v for n, v in hot64.items() if v > (128 if size_of(n) <= 24 else 184)}
+    assert not too_big, too_big
+    assert all(v <= 96 for v in hot32.values()), hot32
