@@ -9,12 +9,134 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <unordered_map>
 
 #include "../../include/dbcsr_acc.h"
 #include "common.h"
 
 namespace {
 std::atomic<int> g_initialized{0};
+
+// ---- caching allocator behind c_dbcsr_acc_{dev,host}_mem_{allocate,deallocate} ------------------------------------------
+// The host grows its C buffer (pinned host + device copy) geometrically during every multiply and releases it afterwards
+// (dbcsr_mm_accdrv.F:475-476, dbcsr_data_ensure_size / dbcsr_data_release): with plain hipHostMalloc / hipHostFree /
+// hipMalloc / hipFree that is a third of the reference driver's wall time on this path (pinning 2 GB takes longer than the
+// multiply).  Released blocks are kept, by size class (1/8-octave steps), and handed out again; an allocation is served by
+// a cached block of at most 25 % more than its class.  Semantics kept: deallocate synchronises the device as hipFree /
+// hipHostFree do (a block is never recycled while work that uses it may be in flight); blocks above the pool's cap are
+// really freed, oldest first; c_dbcsr_acc_finalize and an out-of-memory allocation empty the pool.
+// DBCSR_AMD_ACC_POOL_MB / DBCSR_AMD_ACC_HOST_POOL_MB: caps (0 = no caching); default a quarter of the device memory / 16 GiB.
+struct Pool {
+  bool host;
+  std::mutex mu;
+  std::multimap<std::pair<int, size_t>, std::pair<void*, unsigned long>> free_;  // (device, bytes) -> (block, age stamp)
+  std::unordered_map<void*, std::pair<int, size_t>> live;                         // block -> (device, bytes)
+  size_t cached = 0;
+  long long cap = -1;  // bytes; -1 = not yet read
+  unsigned long stamp = 0;
+
+  static size_t size_class(size_t n) {
+    if (n <= 4096) return 4096;
+    size_t p = 1;
+    while ((p << 1) <= n) p <<= 1;
+    const size_t g = p >> 3 > 4096 ? p >> 3 : 4096;
+    return (n + g - 1) / g * g;
+  }
+  long long capacity() {
+    if (cap >= 0) return cap;
+    const char* env = getenv(host ? "DBCSR_AMD_ACC_HOST_POOL_MB" : "DBCSR_AMD_ACC_POOL_MB");
+    if (env) {
+      cap = atoll(env) << 20;
+    } else if (host) {
+      cap = 16ll << 30;
+    } else {
+      size_t f = 0, t = 0;
+      cap = hipMemGetInfo(&f, &t) == hipSuccess ? (long long)(t / 4) : 0;
+      (void)hipGetLastError();
+    }
+    if (cap < 0) cap = 0;
+    return cap;
+  }
+  hipError_t raw_alloc(void** p, size_t n) { return host ? hipHostMalloc(p, n, hipHostMallocDefault) : hipMalloc(p, n); }
+  hipError_t raw_free(void* p) { return host ? hipHostFree(p) : hipFree(p); }
+  void trim_locked(size_t keep) {
+    while (cached > keep && !free_.empty()) {
+      auto oldest = free_.begin();
+      for (auto it = free_.begin(); it != free_.end(); ++it)
+        if (it->second.second < oldest->second.second) oldest = it;
+      cached -= oldest->first.second;
+      (void)raw_free(oldest->second.first);
+      free_.erase(oldest);
+    }
+  }
+  hipError_t allocate(void** out, size_t nbytes) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const size_t want = size_class(nbytes);
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      if (capacity() > 0) {
+        auto it = free_.lower_bound({dev, want});
+        if (it != free_.end() && it->first.first == dev && it->first.second <= want + want / 4) {
+          *out = it->second.first;
+          cached -= it->first.second;
+          live[*out] = it->first;
+          free_.erase(it);
+          return hipSuccess;
+        }
+      }
+    }
+    hipError_t e = raw_alloc(out, want);
+    if (e != hipSuccess) {  // give the cached blocks back and try once more
+      (void)hipGetLastError();
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        trim_locked(0);
+      }
+      e = raw_alloc(out, want);
+    }
+    if (e == hipSuccess) {
+      std::lock_guard<std::mutex> lk(mu);
+      live[*out] = {dev, want};
+    }
+    return e;
+  }
+  hipError_t deallocate(void* p) {
+    std::pair<int, size_t> info{0, 0};
+    bool known = false;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      auto it = live.find(p);
+      if (it != live.end()) {
+        info = it->second;
+        known = true;
+        live.erase(it);
+      }
+    }
+    if (!known || capacity() <= 0 || (long long)info.second > capacity()) return raw_free(p);
+    const hipError_t e = hipDeviceSynchronize();  // what hipFree / hipHostFree imply: nothing in flight may still use the block
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lk(mu);
+    free_.insert({info, {p, ++stamp}});
+    cached += info.second;
+    trim_locked((size_t)capacity());
+    return hipSuccess;
+  }
+  size_t cached_on(int dev) {
+    std::lock_guard<std::mutex> lk(mu);
+    size_t s = 0;
+    for (auto& kv : free_)
+      if (kv.first.first == dev) s += kv.first.second;
+    return s;
+  }
+  void clear() {
+    std::lock_guard<std::mutex> lk(mu);
+    trim_locked(0);
+  }
+};
+Pool g_dev_pool{false}, g_host_pool{true};
 }
 
 namespace dbcsr_amd {
@@ -54,6 +176,8 @@ int c_dbcsr_acc_init(void) {
 }
 
 int c_dbcsr_acc_finalize(void) {
+  g_dev_pool.clear();
+  g_host_pool.clear();
   g_initialized.store(0);
   return 0;
 }
@@ -198,13 +322,13 @@ int c_dbcsr_acc_dev_mem_allocate(void** dev_mem, size_t nbytes) {
   if (!dev_mem) return -1;
   *dev_mem = nullptr;
   if (nbytes == 0) return 0;
-  ACC_CHECK(hipMalloc(dev_mem, nbytes));
+  ACC_CHECK(g_dev_pool.allocate(dev_mem, nbytes));
   return 0;
 }
 
 int c_dbcsr_acc_dev_mem_deallocate(void* dev_mem) {
   if (!dev_mem) return 0;  // called with NULL when no device exists (dbcsr_acc_test.c:189)
-  ACC_CHECK(hipFree(dev_mem));
+  ACC_CHECK(g_dev_pool.deallocate(dev_mem));
   return 0;
 }
 
@@ -219,14 +343,14 @@ int c_dbcsr_acc_host_mem_allocate(void** host_mem, size_t nbytes, void* stream) 
   if (!host_mem) return -1;
   *host_mem = nullptr;
   if (nbytes == 0) return 0;
-  ACC_CHECK(hipHostMalloc(host_mem, nbytes, hipHostMallocDefault));
+  ACC_CHECK(g_host_pool.allocate(host_mem, nbytes));
   return 0;
 }
 
 int c_dbcsr_acc_host_mem_deallocate(void* host_mem, void* stream) {
   (void)stream;
   if (!host_mem) return 0;
-  ACC_CHECK(hipHostFree(host_mem));
+  ACC_CHECK(g_host_pool.deallocate(host_mem));
   return 0;
 }
 
@@ -257,6 +381,9 @@ int c_dbcsr_acc_memset_zero(void* dev_mem, size_t offset, size_t nbytes, void* s
 int c_dbcsr_acc_dev_mem_info(size_t* mem_free, size_t* mem_total) {
   size_t f = 0, t = 0;
   ACC_CHECK(hipMemGetInfo(&f, &t));
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  f += g_dev_pool.cached_on(dev);  // released blocks the library keeps for reuse are available to the host
   if (mem_free) *mem_free = f;
   if (mem_total) *mem_total = t;
   return 0;
