@@ -13,7 +13,7 @@ PROGRAM dbcsr_ref_dump
    USE dbcsr_dist_util, ONLY: dbcsr_checksum
    USE dbcsr_iterator_operations, ONLY: dbcsr_iterator_blocks_left, dbcsr_iterator_next_block, &
                                         dbcsr_iterator_start, dbcsr_iterator_stop
-   USE dbcsr_kinds, ONLY: int_8, real_8
+   USE dbcsr_kinds, ONLY: int_8, real_4, real_8
    USE dbcsr_lib, ONLY: dbcsr_finalize_lib, dbcsr_init_lib
    USE dbcsr_methods, ONLY: dbcsr_get_num_blocks, dbcsr_nblkcols_total, dbcsr_nblkrows_total, dbcsr_release
    USE dbcsr_mp_methods, ONLY: dbcsr_mp_new, dbcsr_mp_release
@@ -21,16 +21,16 @@ PROGRAM dbcsr_ref_dump
                             mp_world_finalize, mp_world_init
    USE dbcsr_multiply_api, ONLY: dbcsr_multiply
    USE dbcsr_test_methods, ONLY: dbcsr_make_random_block_sizes, dbcsr_make_random_matrix, dbcsr_reset_randmat_seed
-   USE dbcsr_types, ONLY: dbcsr_distribution_obj, dbcsr_iterator, dbcsr_mp_obj, dbcsr_type, dbcsr_type_real_8
+   USE dbcsr_types, ONLY: dbcsr_distribution_obj, dbcsr_iterator, dbcsr_mp_obj, dbcsr_type, dbcsr_type_real_4, dbcsr_type_real_8
    IMPLICIT NONE
 
    INTEGER, PARAMETER :: maxbs = 16
-   INTEGER :: m, n, k, limits(6), nbs_m, nbs_n, nbs_k, bs_m(2*maxbs), bs_n(2*maxbs), bs_k(2*maxbs), dump_values
+   INTEGER :: m, n, k, limits(6), nbs_m, nbs_n, nbs_k, bs_m(2*maxbs), bs_n(2*maxbs), bs_k(2*maxbs), dump_values, data_type
    REAL(real_8) :: sp_a, sp_b, sp_c, alpha, beta, filter_eps
    CHARACTER :: transa, transb, symm_a, symm_b, symm_c
    LOGICAL :: retain
    NAMELIST /spec/ m, n, k, sp_a, sp_b, sp_c, transa, transb, symm_a, symm_b, symm_c, alpha, beta, limits, retain, &
-      filter_eps, nbs_m, nbs_n, nbs_k, bs_m, bs_n, bs_k, dump_values
+      filter_eps, nbs_m, nbs_n, nbs_k, bs_m, bs_n, bs_k, dump_values, data_type
 
    CHARACTER(len=1000) :: fin, fout
    INTEGER :: numnodes, mynode, npdims(2), myploc(2), u, row, col, nblk
@@ -42,6 +42,8 @@ PROGRAM dbcsr_ref_dump
    TYPE(dbcsr_type) :: ma, mb, mc
    TYPE(dbcsr_iterator) :: iter
    REAL(real_8), DIMENSION(:, :), POINTER :: blk
+   REAL(real_4), DIMENSION(:, :), POINTER :: blk4
+   REAL(real_4) :: alpha4, beta4
    LOGICAL :: tr
    INTEGER(int_8) :: flop
    REAL(real_8) :: cs, cs_pos
@@ -50,7 +52,7 @@ PROGRAM dbcsr_ref_dump
    CALL get_command_argument(2, fout)
    transa = 'N'; transb = 'N'; symm_a = 'N'; symm_b = 'N'; symm_c = 'N'
    alpha = 1.0_real_8; beta = 1.0_real_8; limits = 0; retain = .FALSE.; filter_eps = -1.0_real_8
-   bs_m = 0; bs_n = 0; bs_k = 0; dump_values = 0
+   bs_m = 0; bs_n = 0; bs_k = 0; dump_values = 0; data_type = 3   ! 1 = real(4), 3 = real(8), as in the .perf files
    OPEN (newunit=u, file=TRIM(fin), status='old', action='read')
    READ (u, nml=spec)
    CLOSE (u)
@@ -88,7 +90,10 @@ PROGRAM dbcsr_ref_dump
    END IF
 
    flop = 0
-   IF (ANY(limits .NE. 0)) THEN
+   alpha4 = REAL(alpha, real_4); beta4 = REAL(beta, real_4)
+   IF (data_type == 1) THEN
+      CALL multiply_real4()
+   ELSE IF (ANY(limits .NE. 0)) THEN
       IF (filter_eps .GE. 0.0_real_8) THEN
          CALL dbcsr_multiply(transa, transb, alpha, ma, mb, beta, mc, first_row=lim(1), last_row=lim(2), first_column=lim(3), &
                              last_column=lim(4), first_k=lim(5), last_k=lim(6), retain_sparsity=retain, filter_eps=filter_eps, flop=flop)
@@ -115,6 +120,12 @@ PROGRAM dbcsr_ref_dump
    WRITE (u, '(A,2(1X,ES24.16E3))') 'checksum_b', dbcsr_checksum(mb), dbcsr_checksum(mb, pos=.TRUE.)
    CALL dbcsr_iterator_start(iter, mc)
    DO WHILE (dbcsr_iterator_blocks_left(iter))
+      IF (data_type == 1) THEN   ! single precision values are written as doubles (exactly representable)
+         CALL dbcsr_iterator_next_block(iter, row, col, blk4, tr)
+         WRITE (u, '(A,2(1X,I0),1X,L1,2(1X,I0))') 'block', row, col, tr, SIZE(blk4, 1), SIZE(blk4, 2)
+         IF (dump_values .NE. 0) WRITE (u, '(4(1X,ES24.16E3))') REAL(blk4, real_8)
+         CYCLE
+      END IF
       CALL dbcsr_iterator_next_block(iter, row, col, blk, tr)
       IF (dump_values .NE. 0) THEN
          ! a block stored transposed (symmetric storage) is written as stored, with its flag
@@ -143,6 +154,24 @@ CONTAINS
       lim = limits(i)
    END FUNCTION lim
 
+   SUBROUTINE multiply_real4()
+      IF (ANY(limits .NE. 0)) THEN
+         IF (filter_eps .GE. 0.0_real_8) THEN
+            CALL dbcsr_multiply(transa, transb, alpha4, ma, mb, beta4, mc, first_row=lim(1), last_row=lim(2), first_column=lim(3), &
+                                last_column=lim(4), first_k=lim(5), last_k=lim(6), retain_sparsity=retain, filter_eps=filter_eps, flop=flop)
+         ELSE
+            CALL dbcsr_multiply(transa, transb, alpha4, ma, mb, beta4, mc, first_row=lim(1), last_row=lim(2), first_column=lim(3), &
+                                last_column=lim(4), first_k=lim(5), last_k=lim(6), retain_sparsity=retain, flop=flop)
+         END IF
+      ELSE
+         IF (filter_eps .GE. 0.0_real_8) THEN
+            CALL dbcsr_multiply(transa, transb, alpha4, ma, mb, beta4, mc, retain_sparsity=retain, filter_eps=filter_eps, flop=flop)
+         ELSE
+            CALL dbcsr_multiply(transa, transb, alpha4, ma, mb, beta4, mc, retain_sparsity=retain, flop=flop)
+         END IF
+      END IF
+   END SUBROUTINE multiply_real4
+
    SUBROUTINE make(mat, rs, cs_, name, sparsity, symm)
       TYPE(dbcsr_type), INTENT(OUT) :: mat
       INTEGER, DIMENSION(:), POINTER, CONTIGUOUS :: rs, cs_
@@ -152,7 +181,8 @@ CONTAINS
       CALL dbcsr_dist_bin(rd, SIZE(rs), npdims(1), rs)
       CALL dbcsr_dist_bin(cd, SIZE(cs_), npdims(2), cs_)
       CALL dbcsr_distribution_new(dist, mp_env, rd, cd)
-      CALL dbcsr_make_random_matrix(mat, rs, cs_, name, sparsity, group, data_type=dbcsr_type_real_8, symmetry=symm, dist=dist)
+      CALL dbcsr_make_random_matrix(mat, rs, cs_, name, sparsity, group, &
+                                    data_type=MERGE(dbcsr_type_real_4, dbcsr_type_real_8, data_type == 1), symmetry=symm, dist=dist)
       CALL dbcsr_distribution_release(dist)
       DEALLOCATE (rd, cd)
    END SUBROUTINE make

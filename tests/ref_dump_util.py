@@ -19,6 +19,11 @@ def names(pred=lambda p: True):
     return sorted(k for k, v in cases().items() if pred(v["params"]))
 
 
+def np_dtype(p):
+    """data_type of the case as in the .perf format: 1 = real(4), 3 = real(8)"""
+    return np.float32 if p.get("data_type", 3) == 1 else np.float64
+
+
 def nonsymmetric(p):
     return p["symm_a"] == "N" and p["symm_b"] == "N" and p["symm_c"] == "N"
 
@@ -46,7 +51,9 @@ def oracle_inputs(p):
     a symmetric / antisymmetric operand is returned as the FULL matrix (desymmetrized), its stored triangle as 4th / 5th item."""
     from oracle import oracle as O
     if nonsymmetric(p):
-        return O.perf_case(p["M"], p["N"], p["K"], p["sp"][0], p["sp"][1], p["sp"][2], p["bs_m"], p["bs_n"], p["bs_k"], p["transa"], p["transb"])
+        return O.perf_case(p["M"], p["N"], p["K"], p["sp"][0], p["sp"][1], p["sp"][2], p["bs_m"], p["bs_n"], p["bs_k"], p["transa"], p["transb"],
+                           dtype=np_dtype(p))
+    assert np_dtype(p) == np.float64
     assert p["symm_c"] == "N"
     sm, sn, sk = O.make_block_sizes(p["M"], p["bs_m"]), O.make_block_sizes(p["N"], p["bs_n"]), O.make_block_sizes(p["K"], p["bs_k"])
     c0 = O.RANDMAT_SEED_INIT
@@ -79,6 +86,9 @@ def stored_operands(p):
 def oracle_run(p):
     from oracle import oracle as O
     A, B, Cm = oracle_inputs(p)
+    if np_dtype(p) == np.float32:   # the oracle's multiply is double precision: single-precision inputs are widened (exactly)
+        wide = lambda M: O.Bcsr(M.row_sizes, M.col_sizes, M.row_p, M.col_i, M.blk_p, M.data.astype(np.float64))
+        A, B, Cm = wide(A), wide(B), wide(Cm)
     eps = p["filter_eps"] if p["filter_eps"] >= 0 else 0.0
     if any(p["limits"]):
         return O.multiply_limits(p["transa"], p["transb"], p["alpha"], A, B, p["beta"], Cm, p["limits"], retain_sparsity=p["retain"], filter_eps=eps)

@@ -80,7 +80,7 @@ def test_dump_driver_through_acc_backend(name):
     import base64
     data = np.frombuffer(base64.b64decode(got["values_b64"]), "<f8") if ref.nblks else np.zeros(0)
     scale = max(np.max(np.abs(ref.data)), 1e-300) if ref.nblks else 1.0
-    assert data.size == ref.data.size and np.max(np.abs(data - ref.data), initial=0.0) <= 1e-10 * scale
+    assert data.size == ref.data.size and np.max(np.abs(data - ref.data), initial=0.0) <= (5e-6 if R.np_dtype(ref.params) == np.float32 else 1e-10) * scale
 
 
 # ---- the call-site change of INTEGRATION.md section 2, compiled into the reference (tools/build_dbcsr_host.py resident):
@@ -117,4 +117,4 @@ def test_dump_driver_through_resident_engine(name):
     assert np.array_equal(np.asarray(got["row"]) - 1, ref.rows) and np.array_equal(np.asarray(got["col"], np.int32) - 1, ref.col_i)
     data = np.frombuffer(base64.b64decode(got["values_b64"]), "<f8") if ref.nblks else np.zeros(0)
     scale = max(np.max(np.abs(ref.data)), 1e-300) if ref.nblks else 1.0
-    assert data.size == ref.data.size and np.max(np.abs(data - ref.data), initial=0.0) <= 1e-10 * scale
+    assert data.size == ref.data.size and np.max(np.abs(data - ref.data), initial=0.0) <= (5e-6 if R.np_dtype(ref.params) == np.float32 else 1e-10) * scale

@@ -1,6 +1,6 @@
 """GPU paths against outputs of the REAL reference library (tests/golden/ref_dump.json: true dbcsr_multiply on the
 BLAS path, built unchanged with tools/build_dbcsr_host.py): the dbcsr_multiply mirror (symmetric / antisymmetric operands
-included: they are passed as stored, one triangle, and desymmetrized on the device) and the one-call native dbcsr_amd_multiply.  Block index identical, flop identical, values within 1e-10 relative (north star)."""
+included: they are passed as stored, one triangle, and desymmetrized on the device) and the one-call native dbcsr_amd_multiply.  Block index identical, flop identical, values within 1e-10 relative (north star); single-precision cases (config 5's data type) within 5e-6 of the largest element."""
 import numpy as np
 import pytest
 import torch
@@ -19,7 +19,9 @@ def compare(out, flop, ref):
     if ref.data is not None and ref.nblks:
         scale = max(np.max(np.abs(ref.data)), 1e-300)
         assert out.data.size == ref.data.size
-        assert np.max(np.abs(out.data - ref.data)) <= 1e-10 * scale
+        # single precision: reference and device both sum in float, in different orders
+        tol = 5e-6 if R.np_dtype(ref.params) == np.float32 else 1e-10
+        assert np.max(np.abs(out.data.astype(np.float64) - ref.data)) <= tol * scale
 
 
 @pytest.mark.parametrize("name", R.names())
@@ -51,5 +53,5 @@ def test_native_call_matches_reference_dump(name):
     p = ref.params
     A, B, Cm = R.oracle_inputs(p)
     got, flop = native_multiply(p["transa"], p["transb"], p["alpha"], A, B, p["beta"], Cm, limits=p["limits"] if any(p["limits"]) else None,
-                                retain=p["retain"], eps=max(p["filter_eps"], 0.0))
+                                retain=p["retain"], eps=max(p["filter_eps"], 0.0), dtype=R.np_dtype(p))
     compare(got, flop, ref)

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DUMP = os.path.join(ROOT, "oracle", "_ref", "host_cpu", "dbcsr_ref_dump")
 
 D = dict(transa="N", transb="N", symm_a="N", symm_b="N", symm_c="N", alpha=1.0, beta=1.0, limits=[0] * 6, retain=False,
-         filter_eps=-1.0, values=True)
+         filter_eps=-1.0, values=True, data_type=3)
 
 
 def case(name, M, N, K, sp, bs_m, bs_n=None, bs_k=None, **kw):
@@ -58,6 +58,11 @@ CASES = [
     case("symm_a_A", 60, 60, 60, (0.5, 0.5, 0.5), [1, 4], symm_a="A"),
     case("symm_a_S_T", 60, 60, 60, (0.5, 0.5, 0.5), [1, 4], symm_a="S", transa="T"),
     case("symm_b_A_T", 60, 60, 60, (0.5, 0.5, 0.5), [1, 4], symm_b="A", transb="T"),
+    # single precision (data_type 1 of the .perf format; BASELINE config 5's shape: 32 x 32 blocks, and a mixed one)
+    case("fp32_32", 32 * 6, 32 * 5, 32 * 7, (0.6, 0.6, 0.7), [1, 32], data_type=1),
+    case("fp32_32_beta0_T", 32 * 5, 32 * 5, 32 * 6, (0.5, 0.5, 0.5), [1, 32], data_type=1, beta=0.0, transa="T"),
+    case("fp32_mixed", 120, 110, 130, (0.5, 0.6, 0.7), [1, 13, 1, 32, 1, 7], [1, 23, 1, 32], [1, 13, 1, 32, 1, 9], data_type=1, alpha=0.5, beta=2.0),
+    case("fp32_filter_retain", 100, 100, 100, (0.7, 0.7, 0.5), [1, 5], data_type=1, filter_eps=12.0, retain=True),
 ]
 
 
@@ -74,7 +79,7 @@ def write_nml(c, path):
         for d in ("m", "n", "k"):
             bs = c["bs_" + d]
             f.write(" nbs_%s=%d, bs_%s=%s,\n" % (d, len(bs) // 2, d, ",".join(map(str, bs))))
-        f.write(" dump_values=%d\n/\n" % (1 if c["values"] else 0))
+        f.write(" dump_values=%d, data_type=%d\n/\n" % (1 if c["values"] else 0, c.get("data_type", 3)))
 
 
 def parse_dump(path):
