@@ -2351,11 +2351,6 @@ struct Engine {
   FilterArgs filter = {nullptr, nullptr, 0.0f};
   int64_t flt_nblks = 0;
   DevBuf<int> order, order_cnt;
-  // class launches of one multiply write disjoint C blocks: with DBCSR_AMD_MM_CLASS_STREAMS = n > 1 they are dealt to n streams
-  // forked from / joined to the caller's stream, so that the tail of one launch overlaps the start of the next
-  int class_streams = 1;
-  hipStream_t cls_stream[4] = {nullptr, nullptr, nullptr, nullptr};
-  hipEvent_t cls_fork = nullptr, cls_join[4] = {nullptr, nullptr, nullptr, nullptr};
   int wg_waves = 0;   // DBCSR_AMD_MM_WG_WAVES = 1 | 2 | 4: waves per workgroup of the one-wave-per-C-block kernels (0: by list length).  A workgroup's LDS is
                       // released when its LAST wave ends, so with product lists of uneven length fewer waves per workgroup keep
                       // more of the CU's wave slots busy (config 3: kernel 8.93 / 8.09 / 7.51 ms for 4 / 2 / 1, config 2: 23.6 / 22.7 /
@@ -2468,14 +2463,6 @@ int dbcsr_amd_mm_create(void** handle) {
     e = hipEventCreate(&E->ev[i]);
     if (e != hipSuccess) return check(e, "hipEventCreate", __FILE__, __LINE__);
   }
-  if (const char* k = getenv("DBCSR_AMD_MM_CLASS_STREAMS")) E->class_streams = std::max(1, std::min(4, atoi(k)));
-  if (E->class_streams > 1) {
-    if (hipEventCreateWithFlags(&E->cls_fork, hipEventDisableTiming) != hipSuccess) E->class_streams = 1;
-    for (int i = 0; i < E->class_streams && E->class_streams > 1; ++i)
-      if (hipStreamCreateWithFlags(&E->cls_stream[i], hipStreamNonBlocking) != hipSuccess ||
-          hipEventCreateWithFlags(&E->cls_join[i], hipEventDisableTiming) != hipSuccess)
-        E->class_streams = 1;
-  }
   *handle = E;
   return 0;
 }
@@ -2509,11 +2496,6 @@ int dbcsr_amd_mm_destroy(void* handle) {
   E->cls_hist.release(); E->cls_row.release(); E->cls_col.release(); E->cls_col_bm.release(); E->cls_lens.release();
   for (int i = 0; i < 3; ++i)
     if (E->ev[i]) (void)hipEventDestroy(E->ev[i]);
-  for (int i = 0; i < 4; ++i) {
-    if (E->cls_stream[i]) (void)hipStreamDestroy(E->cls_stream[i]);
-    if (E->cls_join[i]) (void)hipEventDestroy(E->cls_join[i]);
-  }
-  if (E->cls_fork) (void)hipEventDestroy(E->cls_fork);
   delete E;
   return 0;
 }
@@ -2845,16 +2827,9 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
       const int g_lds_wave = g_lds_a + g_lds_b;
       const int g_maxt = (std::max(E->max_m, E->max_n) + 7) / 8;
       const int dbgv = E->dbg | (skip_empty ? 32 : 0);
-      int njit = 0, ngen = 0, nlaunch = 0;
-      const int NS = E->class_streams;
-      hipStream_t st_main = st;
-      if (NS > 1) {
-        ACC_CHECK(hipEventRecord(E->cls_fork, st_main));
-        for (int i = 0; i < NS; ++i) ACC_CHECK(hipStreamWaitEvent(E->cls_stream[i], E->cls_fork, 0));
-      }
+      int njit = 0, ngen = 0;
       for (int c = 0; c < kNumClasses; ++c) {
         if (E->cls_len[c] == 0) continue;
-        if (NS > 1) st = E->cls_stream[nlaunch++ % NS];
         const int* ord = E->order.p + E->cls_off[c];
         const unsigned nwg_c = (unsigned)(8 * E->cls_len[c] / 4);
         ClassKernel ck;
@@ -2889,13 +2864,6 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
           }
 #undef DBCSR_LAUNCH_G
           ++ngen;
-        }
-      }
-      if (NS > 1) {
-        st = st_main;
-        for (int i = 0; i < NS; ++i) {
-          ACC_CHECK(hipEventRecord(E->cls_join[i], E->cls_stream[i]));
-          ACC_CHECK(hipStreamWaitEvent(st_main, E->cls_join[i], 0));
         }
       }
       snprintf(E->last_kernel, sizeof E->last_kernel, "mm_numeric_f64_class[%d jit + %d generic launches; m {%d,%d,%d} n {%d,%d,%d} k {%d,%d,%d}]", njit,
