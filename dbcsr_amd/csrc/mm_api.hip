@@ -93,6 +93,16 @@ int transposed(void* h, libsmm_acc_data_t dt, const dbcsr_amd_bcsr* src, Owned& 
 }
 
 
+// block (r, c) <-> its twin (c, r): mode 1 stored triangle -> canonical form, mode 2 canonical form -> stored triangle (dbcsr_amd_bcsr_twin_*)
+int twin(void* h, libsmm_acc_data_t dt, const dbcsr_amd_bcsr* src, int mode, int antisymmetric, Owned& dst, void* stream) {
+  if (alloc_row_p(dst, src->nblkrows)) return -1;
+  int64_t nb = 0, nz = 0;
+  int rc = dbcsr_amd_bcsr_twin_count(h, src, mode, dst.m.row_p, &nb, &nz, stream);
+  if (rc) return rc;
+  if (alloc_arrays(dst, src->nblkrows, src->nblkcols, src->row_blk_size, src->col_blk_size, nb, nz, elem_size(dt), false)) return -1;
+  return dbcsr_amd_bcsr_twin_apply(h, dt, src, mode, antisymmetric, &dst.m, stream);
+}
+
 // sum of the block sizes of one dimension (device array of n int32): dbcsr_nfullrows_total / dbcsr_nfullcols_total
 int full_extent(const int32_t* sizes, int n, int64_t* out, hipStream_t st) {
   *out = 0;
@@ -330,6 +340,35 @@ int dbcsr_amd_multiply(void* handle, char transa, char transb, libsmm_acc_data_t
   c_out->row_blk_size = matrix_c->row_blk_size;
   c_out->col_blk_size = matrix_c->col_blk_size;
   result->live = false;  // ownership passes to the caller (dbcsr_amd_bcsr_release)
+  return 0;
+}
+
+int dbcsr_amd_multiply_symmetric_c(void* handle, char transa, char transb, libsmm_acc_data_t datatype, double alpha,
+                                   const dbcsr_amd_bcsr* matrix_a, const dbcsr_amd_bcsr* matrix_b, double beta, const dbcsr_amd_bcsr* matrix_c,
+                                   int antisymmetric, int retain_sparsity, double filter_eps, dbcsr_amd_bcsr* c_out, int64_t* flop, void* stream) {
+  if (!handle || !matrix_c || !c_out || matrix_c->nblkrows != matrix_c->nblkcols) return -1;
+  if (datatype != dbcsr_type_real_8 && datatype != dbcsr_type_real_4) return -10;
+  // dbcsr_mm.F:711-719: the index of a product matrix with symmetry is put into canonical form before the multiplication ...
+  Owned canon;
+  int rc = twin(handle, datatype, matrix_c, 1, antisymmetric, canon, stream);
+  if (rc) return rc;
+  // ... the local multiply computes only the blocks stored in that form (dbcsr_mm_csr.F:280-292) ...
+  dbcsr_amd_bcsr prod;
+  if ((rc = dbcsr_amd_mm_set_canonical_product(handle, 1))) return rc;
+  rc = dbcsr_amd_multiply(handle, transa, transb, datatype, alpha, matrix_a, matrix_b, beta, &canon.m, nullptr, retain_sparsity, filter_eps, &prod,
+                          flop, stream);
+  (void)dbcsr_amd_mm_set_canonical_product(handle, 0);
+  if (rc) return rc;
+  // ... and the result goes back to the stored triangle (row <= column)
+  Owned upper;
+  rc = twin(handle, datatype, &prod, 2, antisymmetric, upper, stream);
+  if (rc == 0 && hipStreamSynchronize(stream_of(stream)) != hipSuccess) rc = -1;
+  (void)dbcsr_amd_bcsr_release(&prod);
+  if (rc) return rc;
+  *c_out = upper.m;
+  c_out->row_blk_size = matrix_c->row_blk_size;
+  c_out->col_blk_size = matrix_c->col_blk_size;
+  upper.live = false;
   return 0;
 }
 

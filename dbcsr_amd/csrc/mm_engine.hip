@@ -160,18 +160,29 @@ __global__ void __launch_bounds__(256) bitmap_from_index(const int* __restrict__
   }
 }
 
+// Product matrix with symmetry, index in canonical (checkerboard) form: the local multiply computes block (i, j) only when it
+// is the stored one of the pair (i, j) / (j, i) (dbcsr_mm_csr.F:280-292, checker_tr of dbcsr_dist_operations.F:65-75): the
+// diagonal, (i + j) even above it, (i + j) odd below it.  Bits of word w of row i that may receive products:
+__device__ __forceinline__ uint32_t canonical_bits(int i, int w) {
+  const uint32_t even = (i & 1) ? 0xAAAAAAAAu : 0x55555555u;      // columns j of this word with (i + j) even (32 w is even)
+  const int d = i - 32 * w;                                       // position of the diagonal relative to the word
+  const uint32_t upper = d <= 0 ? 0xFFFFFFFFu : (d >= 32 ? 0u : ~((1u << d) - 1u));  // columns j >= i
+  return (even & upper) | (~even & ~upper);
+}
+
 // thread per (row i, word w)
 __global__ void __launch_bounds__(256) c_bitmap(const int* __restrict__ a_row_p, const int* __restrict__ a_col_i,
                                                 const uint32_t* __restrict__ b_bm, const uint32_t* __restrict__ cin_bm, int nbr, int W,
-                                                int retain, uint32_t* __restrict__ c_bm) {
+                                                int retain, int canonical, uint32_t* __restrict__ c_bm) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (int64_t)nbr * W) return;
   const int i = (int)(t / W), w = (int)(t % W);
-  uint32_t v = cin_bm ? cin_bm[t] : 0u;
+  uint32_t v = 0u;
   if (!retain) {
     for (int ab = a_row_p[i]; ab < a_row_p[i + 1]; ++ab) v |= b_bm[(size_t)a_col_i[ab] * W + w];
+    if (canonical) v &= canonical_bits(i, w);
   }
-  c_bm[t] = v;
+  c_bm[t] = v | (cin_bm ? cin_bm[t] : 0u);
 }
 
 // one wavefront per row: exclusive prefix of popcounts inside the row + row total
@@ -342,14 +353,15 @@ __global__ void __launch_bounds__(256) bcsr_block_norms(const int* __restrict__ 
 __global__ void __launch_bounds__(256) c_bitmap_filtered(const int* __restrict__ a_row_p, const int* __restrict__ a_col_i,
                                                          const int* __restrict__ b_row_p, const uint32_t* __restrict__ b_bm,
                                                          const int* __restrict__ b_pre, const uint32_t* __restrict__ cin_bm, int nbr,
-                                                         int nbc, int W, int nJ, int retain, FilterArgs F, uint32_t* __restrict__ c_bm) {
+                                                         int nbc, int W, int nJ, int retain, int canonical, FilterArgs F,
+                                                         uint32_t* __restrict__ c_bm) {
   const int lane = threadIdx.x & 63;
   const int64_t wv = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (wv >= (int64_t)nbr * nJ) return;
   const int i = (int)(wv / nJ), jb = (int)(wv % nJ);
   const int j = jb * 64 + lane, w = j >> 5, bit = j & 31;
   bool any = false;
-  if (!retain && j < nbc) {
+  if (!retain && j < nbc && !(canonical && !((canonical_bits(i, w) >> bit) & 1u))) {
     const int a0 = a_row_p[i], a1 = a_row_p[i + 1];
     const float reps = row_filter_eps(F, a1 - a0);
     const uint32_t below = (1u << bit) - 1u;
@@ -1898,15 +1910,24 @@ __global__ void __launch_bounds__(256) transpose_sizes(const uint32_t* __restric
 
 // ---- desymmetrize (dbcsr_desymmetrize_deep, what make_images does to a symmetric operand: src/mm/dbcsr_mm_cannon.F:284,
 // 351-379): a symmetric / antisymmetric matrix stores one triangle; the full matrix has block (c, r) = +-block (r, c)^T too
-__global__ void __launch_bounds__(256) desym_mark(const int* __restrict__ s_row_p, const int* __restrict__ s_col_i, int nbr, int W,
+// mode 0: desymmetrize (a block and its twin); mode 1: stored triangle -> canonical (checkerboard) form of a matrix with symmetry
+// (dbcsr_make_index_canonical: block (r, c), r != c, moves to (c, r) when checker_tr says its twin is the stored one,
+// src/dist/dbcsr_dist_operations.F:65-75 on the 1-based coordinates); mode 2: canonical form -> stored triangle (row <= col)
+__device__ __forceinline__ bool twin_moves(int mode, int r, int c) {
+  if (mode == 1) return r != c && ((((r + c) & 1) == 1) == (c >= r));
+  return r > c;  // mode 2
+}
+
+__global__ void __launch_bounds__(256) desym_mark(const int* __restrict__ s_row_p, const int* __restrict__ s_col_i, int nbr, int W, int mode,
                                                   uint32_t* __restrict__ bm) {
   const int lane = threadIdx.x & 63;
   const int r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (r >= nbr) return;
   for (int b = s_row_p[r] + lane; b < s_row_p[r + 1]; b += 64) {
     const int c = s_col_i[b];
-    atomicOr(&bm[(size_t)r * W + (c >> 5)], 1u << (c & 31));
-    atomicOr(&bm[(size_t)c * W + (r >> 5)], 1u << (r & 31));
+    const bool stay = mode == 0 || !twin_moves(mode, r, c), go = mode == 0 || twin_moves(mode, r, c);
+    if (stay) atomicOr(&bm[(size_t)r * W + (c >> 5)], 1u << (c & 31));
+    if (go) atomicOr(&bm[(size_t)c * W + (r >> 5)], 1u << (r & 31));
   }
 }
 
@@ -1914,7 +1935,7 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 desym_fill(const int* __restrict__ s_row_p, const int* __restrict__ s_col_i, const int64_t* __restrict__ s_blk_p, const T* __restrict__ s_data,
            const int* __restrict__ sizes, const uint32_t* __restrict__ bm, const int* __restrict__ pre, const int* __restrict__ d_row_p,
-           const int64_t* __restrict__ d_blk_p_ws, int nbr, int W, T sign, int* __restrict__ d_col_i, int64_t* __restrict__ d_blk_p,
+           const int64_t* __restrict__ d_blk_p_ws, int nbr, int W, T sign, int mode, int* __restrict__ d_col_i, int64_t* __restrict__ d_blk_p,
            T* __restrict__ d_data) {
   const int lane = threadIdx.x & 63;
   const int r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -1928,14 +1949,17 @@ desym_fill(const int* __restrict__ s_row_p, const int* __restrict__ s_col_i, con
     const int c = s_col_i[b];
     const int n = sizes[c];
     const T* src = s_data + s_blk_p[b];
-    const int t0 = slot(r, c);
-    if (lane == 0) {
-      d_col_i[t0] = c;
-      d_blk_p[t0] = d_blk_p_ws[t0];
+    const bool stay = mode == 0 || !twin_moves(mode, r, c), go = mode == 0 ? c != r : twin_moves(mode, r, c);
+    if (stay) {
+      const int t0 = slot(r, c);
+      if (lane == 0) {
+        d_col_i[t0] = c;
+        d_blk_p[t0] = d_blk_p_ws[t0];
+      }
+      T* d0 = d_data + d_blk_p_ws[t0];
+      for (int e = lane; e < m * n; e += 64) d0[e] = src[e];
     }
-    T* d0 = d_data + d_blk_p_ws[t0];
-    for (int e = lane; e < m * n; e += 64) d0[e] = src[e];
-    if (c != r) {
+    if (go) {
       const int t1 = slot(c, r);
       if (lane == 0) {
         d_col_i[t1] = r;
@@ -2351,6 +2375,7 @@ struct Engine {
   FilterArgs filter = {nullptr, nullptr, 0.0f};
   int64_t flt_nblks = 0;
   DevBuf<int> order, order_cnt;
+  int canonical_c = 0;  // dbcsr_amd_mm_set_canonical_product: the product matrix has symmetry, its index is in canonical form
   int wg_waves = 0;   // DBCSR_AMD_MM_WG_WAVES = 1 | 2 | 4: waves per workgroup of the one-wave-per-C-block kernels (0: by list length).  A workgroup's LDS is
                       // released when its LAST wave ends, so with product lists of uneven length fewer waves per workgroup keep
                       // more of the CU's wave slots busy (config 3: kernel 8.93 / 8.09 / 7.51 ms for 4 / 2 / 1, config 2: 23.6 / 22.7 /
@@ -2575,10 +2600,10 @@ int dbcsr_amd_mm_symbolic_filtered(void* handle, libsmm_acc_data_t datatype, dou
   if (filtering)
     hipLaunchKernelGGL(c_bitmap_filtered, grid_for((int64_t)nbr * ((nbc + 63) / 64) * 64), dim3(256), 0, st, a->row_p, a->col_i, b->row_p,
                        E->b_bm.p, E->b_pre.p, E->have_cin ? E->cin_bm.p : (const uint32_t*)nullptr, nbr, nbc, W, (nbc + 63) / 64,
-                       retain_sparsity ? 1 : 0, E->filter, E->c_bm.p);
+                       retain_sparsity ? 1 : 0, E->canonical_c, E->filter, E->c_bm.p);
   else
     hipLaunchKernelGGL(c_bitmap, grid_for((int64_t)nbr * W), dim3(256), 0, st, a->row_p, a->col_i, E->b_bm.p,
-                       E->have_cin ? E->cin_bm.p : (const uint32_t*)nullptr, nbr, W, retain_sparsity ? 1 : 0, E->c_bm.p);
+                       E->have_cin ? E->cin_bm.p : (const uint32_t*)nullptr, nbr, W, retain_sparsity ? 1 : 0, E->canonical_c, E->c_bm.p);
   hipLaunchKernelGGL(row_prefix, grid_for((int64_t)nbr * 64), dim3(256), 0, st, E->c_bm.p, nbr, W, E->c_pre.p, E->row_nnz.p);
   int64_t* dsc = reinterpret_cast<int64_t*>(E->dev_scalars.p);
   if (exclusive_scan<int32_t>(E, E->row_nnz.p, nbr, c_out_row_p, dsc + 0, true, st)) return -1;
@@ -3227,8 +3252,24 @@ int dbcsr_amd_bcsr_transpose(void* handle, libsmm_acc_data_t datatype, const dbc
 }
 
 int dbcsr_amd_bcsr_desymmetrize_count(void* handle, const dbcsr_amd_bcsr* src, int32_t* dst_row_p, int64_t* nblks, int64_t* nze, void* stream) {
+  return dbcsr_amd_bcsr_twin_count(handle, src, 0, dst_row_p, nblks, nze, stream);
+}
+
+int dbcsr_amd_bcsr_desymmetrize_apply(void* handle, libsmm_acc_data_t datatype, const dbcsr_amd_bcsr* src, int antisymmetric, dbcsr_amd_bcsr* dst,
+                                      void* stream) {
+  return dbcsr_amd_bcsr_twin_apply(handle, datatype, src, 0, antisymmetric, dst, stream);
+}
+
+int dbcsr_amd_mm_set_canonical_product(void* handle, int on) {
   Engine* E = static_cast<Engine*>(handle);
-  if (!E || !src || !dst_row_p || !nblks || !nze || src->nblkrows != src->nblkcols) return -1;
+  if (!E) return -1;
+  E->canonical_c = on ? 1 : 0;
+  return 0;
+}
+
+int dbcsr_amd_bcsr_twin_count(void* handle, const dbcsr_amd_bcsr* src, int mode, int32_t* dst_row_p, int64_t* nblks, int64_t* nze, void* stream) {
+  Engine* E = static_cast<Engine*>(handle);
+  if (!E || !src || !dst_row_p || !nblks || !nze || src->nblkrows != src->nblkcols || mode < 0 || mode > 2) return -1;
   hipStream_t st = stream_of(stream);
   const int nbr = src->nblkrows, W = (nbr + 31) / 32;
   E->valid = false;  // shares workspace with the symbolic phase
@@ -3239,7 +3280,7 @@ int dbcsr_amd_bcsr_desymmetrize_count(void* handle, const dbcsr_amd_bcsr* src, i
     return -1;
   int64_t* dsc = reinterpret_cast<int64_t*>(E->dev_scalars.p);
   ACC_CHECK(hipMemsetAsync(E->c_bm.p, 0, sizeof(uint32_t) * (size_t)nbr * W, st));
-  hipLaunchKernelGGL(desym_mark, grid_for((int64_t)nbr * 64), dim3(256), 0, st, src->row_p, src->col_i, nbr, W, E->c_bm.p);
+  hipLaunchKernelGGL(desym_mark, grid_for((int64_t)nbr * 64), dim3(256), 0, st, src->row_p, src->col_i, nbr, W, mode, E->c_bm.p);
   hipLaunchKernelGGL(row_prefix, grid_for((int64_t)nbr * 64), dim3(256), 0, st, E->c_bm.p, nbr, W, E->c_pre.p, E->row_nnz.p);
   if (exclusive_scan<int32_t>(E, E->row_nnz.p, nbr, dst_row_p, dsc + 0, true, st)) return -1;
   // block sizes in index order (square matrix: the transposed-matrix helper with rows = columns = the same sizes)
@@ -3252,13 +3293,13 @@ int dbcsr_amd_bcsr_desymmetrize_count(void* handle, const dbcsr_amd_bcsr* src, i
   ACC_CHECK(hipMemcpyAsync(E->host_scalars, dsc, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
   ACC_CHECK(hipStreamSynchronize(st));
   *nze = E->host_scalars[1];
-  return check(hipGetLastError(), "dbcsr_amd_bcsr_desymmetrize_count", __FILE__, __LINE__);
+  return check(hipGetLastError(), "dbcsr_amd_bcsr_twin_count", __FILE__, __LINE__);
 }
 
-int dbcsr_amd_bcsr_desymmetrize_apply(void* handle, libsmm_acc_data_t datatype, const dbcsr_amd_bcsr* src, int antisymmetric, dbcsr_amd_bcsr* dst,
-                                      void* stream) {
+int dbcsr_amd_bcsr_twin_apply(void* handle, libsmm_acc_data_t datatype, const dbcsr_amd_bcsr* src, int mode, int antisymmetric, dbcsr_amd_bcsr* dst,
+                              void* stream) {
   Engine* E = static_cast<Engine*>(handle);
-  if (!E || !src || !dst || src->nblkrows != src->nblkcols) return -1;
+  if (!E || !src || !dst || src->nblkrows != src->nblkcols || mode < 0 || mode > 2) return -1;
   if (datatype != dbcsr_type_real_8 && datatype != dbcsr_type_real_4) return -10;
   hipStream_t st = stream_of(stream);
   const int nbr = src->nblkrows, W = (nbr + 31) / 32;
@@ -3266,12 +3307,12 @@ int dbcsr_amd_bcsr_desymmetrize_apply(void* handle, libsmm_acc_data_t datatype, 
   if (datatype == dbcsr_type_real_8)
     hipLaunchKernelGGL((desym_fill<double>), grid_for((int64_t)nbr * 64), dim3(256), 0, st, src->row_p, src->col_i, src->blk_p,
                        static_cast<const double*>(src->data), src->row_blk_size, E->c_bm.p, E->c_pre.p, dst->row_p, E->c_blk_p_ws.p, nbr, W,
-                       antisymmetric ? -1.0 : 1.0, dst->col_i, dst->blk_p, static_cast<double*>(dst->data));
+                       antisymmetric ? -1.0 : 1.0, mode, dst->col_i, dst->blk_p, static_cast<double*>(dst->data));
   else
     hipLaunchKernelGGL((desym_fill<float>), grid_for((int64_t)nbr * 64), dim3(256), 0, st, src->row_p, src->col_i, src->blk_p,
                        static_cast<const float*>(src->data), src->row_blk_size, E->c_bm.p, E->c_pre.p, dst->row_p, E->c_blk_p_ws.p, nbr, W,
-                       antisymmetric ? -1.0f : 1.0f, dst->col_i, dst->blk_p, static_cast<float*>(dst->data));
-  return check(hipGetLastError(), "dbcsr_amd_bcsr_desymmetrize_apply", __FILE__, __LINE__);
+                       antisymmetric ? -1.0f : 1.0f, mode, dst->col_i, dst->blk_p, static_cast<float*>(dst->data));
+  return check(hipGetLastError(), "dbcsr_amd_bcsr_twin_apply", __FILE__, __LINE__);
 }
 
 int dbcsr_amd_mm_stats(void* handle, dbcsr_amd_mnk_stat* out, int max_entries, int* n_entries, void* stream) {

@@ -32,6 +32,7 @@ MM_SYMBOLS = [
     "dbcsr_amd_mm_symbolic_filtered", "dbcsr_amd_bcsr_filter_count", "dbcsr_amd_bcsr_filter_apply",
     "dbcsr_amd_bcsr_crop_count", "dbcsr_amd_bcsr_crop_apply", "dbcsr_amd_bcsr_scale_window",
     "dbcsr_amd_multiply", "dbcsr_amd_bcsr_release", "dbcsr_amd_bcsr_desymmetrize_count", "dbcsr_amd_bcsr_desymmetrize_apply",
+    "dbcsr_amd_bcsr_twin_count", "dbcsr_amd_bcsr_twin_apply", "dbcsr_amd_mm_set_canonical_product", "dbcsr_amd_multiply_symmetric_c",
 ]
 
 
@@ -133,6 +134,11 @@ def load_library():
     L.dbcsr_amd_mm_kernel_name.restype = C.c_char_p
     L.dbcsr_amd_bcsr_desymmetrize_count.argtypes = [vp, BP, vp, C.POINTER(i64), C.POINTER(i64), vp]
     L.dbcsr_amd_bcsr_desymmetrize_apply.argtypes = [vp, i32, BP, i32, BP, vp]
+    L.dbcsr_amd_bcsr_twin_count.argtypes = [vp, BP, i32, vp, C.POINTER(i64), C.POINTER(i64), vp]
+    L.dbcsr_amd_bcsr_twin_apply.argtypes = [vp, i32, BP, i32, i32, BP, vp]
+    L.dbcsr_amd_mm_set_canonical_product.argtypes = [vp, i32]
+    L.dbcsr_amd_multiply_symmetric_c.argtypes = [vp, C.c_char, C.c_char, i32, C.c_double, BP, BP, C.c_double, BP, i32, i32, C.c_double, BP,
+                                                 C.POINTER(i64), vp]
     L.dbcsr_amd_mm_stats.argtypes = [vp, C.POINTER(MnkStat), i32, C.POINTER(i32), vp]
     L.dbcsr_amd_comm_unique_id.argtypes = [C.c_char_p]
     L.dbcsr_amd_comm_create.argtypes = [C.POINTER(vp), C.c_char_p, i32, i32]

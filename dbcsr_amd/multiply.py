@@ -225,6 +225,30 @@ class MultiplyEngine:
             raise RuntimeError("dbcsr_amd_bcsr_desymmetrize_apply failed (%d)" % rc)
         return out
 
+    def twin_moved(self, M, mode, symmetry, stream=None):
+        """Blocks of a matrix with symmetry moved to their twins (r, c) -> (c, r), transposed (negated when antisymmetric):
+        mode 1 = stored triangle -> canonical (checkerboard) form (dbcsr_make_index_canonical), mode 2 = canonical form -> stored
+        triangle (row <= column).  include/dbcsr_amd_mm.h: dbcsr_amd_bcsr_twin_count / _apply."""
+        st = StreamHandle(stream)
+        src = M.desc()
+        dev = M.row_p.device
+        row_p = torch.empty(M.nblkrows + 1, dtype=torch.int32, device=dev)
+        nb, nz = C.c_int64(0), C.c_int64(0)
+        rc = self.L.dbcsr_amd_bcsr_twin_count(self.h, C.byref(src), mode, row_p.data_ptr(), C.byref(nb), C.byref(nz), st.ptr)
+        if rc != 0:
+            raise RuntimeError("dbcsr_amd_bcsr_twin_count failed (%d)" % rc)
+        out = DbcsrMatrix(M.row_blk_size, M.col_blk_size, row_p, torch.empty(nb.value, dtype=torch.int32, device=dev),
+                          torch.empty(nb.value, dtype=torch.int64, device=dev), torch.empty(nz.value, dtype=M.dtype, device=dev), M.name)
+        d = out.desc()
+        rc = self.L.dbcsr_amd_bcsr_twin_apply(self.h, M.dtype_code, C.byref(src), mode, 1 if symmetry == "A" else 0, C.byref(d), st.ptr)
+        if rc != 0:
+            raise RuntimeError("dbcsr_amd_bcsr_twin_apply failed (%d)" % rc)
+        return out
+
+    def set_canonical_product(self, on):
+        if self.L.dbcsr_amd_mm_set_canonical_product(self.h, 1 if on else 0) != 0:
+            raise RuntimeError("dbcsr_amd_mm_set_canonical_product failed")
+
     @staticmethod
     def empty_like(M):
         """C without any block, same block sizes (the product matrix after the reference has discarded it, dbcsr_mm.F:865-870)."""
@@ -350,8 +374,24 @@ def dbcsr_multiply(transa, transb, alpha, matrix_a, matrix_b, beta, matrix_c, fi
     if matrix_a.dtype != matrix_b.dtype or matrix_a.dtype != matrix_c.dtype:
         raise TypeError("dbcsr_multiply: data types of A, B and C differ")
     E = engine or default_engine()
-    if getattr(matrix_c, "symmetry", "N") != "N":
-        raise NotImplementedError("dbcsr_multiply: a symmetric product matrix is not supported (operands may be symmetric)")
+    c_symm = getattr(matrix_c, "symmetry", "N")
+    if c_symm != "N":
+        # Product matrix with symmetry (src/mm/dbcsr_mm.F:711-719): its index goes into canonical (checkerboard) form, only the blocks
+        # stored in that form are computed (dbcsr_mm_csr.F:280-292), the result goes back to the stored triangle (row <= column).
+        if c_symm not in ("S", "A"):
+            raise ValueError("unsupported matrix symmetry %r (real data: 'N', 'S', 'A')" % (c_symm,))
+        if any(v is not None and v != 0 for v in (first_row, last_row, first_column, last_column, first_k, last_k)):
+            raise NotImplementedError("dbcsr_multiply: limits with a symmetric product matrix (the reference's tests run full limits only)")
+        canon = E.twin_moved(matrix_c, 1, c_symm)
+        E.set_canonical_product(True)
+        try:
+            counts = dbcsr_multiply(transa, transb, alpha, matrix_a, matrix_b, beta, canon, retain_sparsity=retain_sparsity,
+                                    filter_eps=filter_eps, flop=flop, engine=E)
+        finally:
+            E.set_canonical_product(False)
+        up = E.twin_moved(canon, 2, c_symm)
+        matrix_c.row_p, matrix_c.col_i, matrix_c.blk_p, matrix_c.data = up.row_p, up.col_i, up.blk_p, up.data
+        return counts
     matrix_a, matrix_b = E.desymmetrized(matrix_a), E.desymmetrized(matrix_b)
     A = E.transposed(matrix_a) if transa != "N" else matrix_a
     B = E.transposed(matrix_b) if transb != "N" else matrix_b

@@ -169,6 +169,25 @@ int dbcsr_amd_bcsr_desymmetrize_count(void* handle, const dbcsr_amd_bcsr* src, i
 int dbcsr_amd_bcsr_desymmetrize_apply(void* handle, libsmm_acc_data_t datatype, const dbcsr_amd_bcsr* src, int antisymmetric,
   dbcsr_amd_bcsr* dst, void* stream);
 
+/* Product matrix WITH symmetry (matrix_type 'S' / 'A' of matrix_c).  The reference puts the index of such a product matrix into
+ * canonical (checkerboard) form before the multiplication (src/mm/dbcsr_mm.F:711-719, dbcsr_make_index_canonical), its local
+ * multiply computes block (i, j) only when that is the stored one of the pair (i, j) / (j, i) (src/mm/dbcsr_mm_csr.F:280-292,
+ * checker_tr of src/dist/dbcsr_dist_operations.F:65-75), and the result is returned as the stored triangle.  The pieces:
+ *   dbcsr_amd_bcsr_twin_{count,apply}  mode 0: desymmetrize (= the two calls above); mode 1: stored triangle (row <= column) ->
+ *     canonical form; mode 2: canonical form -> stored triangle.  A block that changes sides is transposed (negated when
+ *     antisymmetric).  Same calling convention as desymmetrize_{count,apply}.
+ *   dbcsr_amd_mm_set_canonical_product(handle, 1): the following symbolic phases of this handle leave out the products of
+ *     blocks that are not stored in canonical form (blocks of C_in are kept wherever they are); 0 switches it off again.
+ *   dbcsr_amd_multiply_symmetric_c: the whole sequence in one call; matrix_c and c_out hold the stored triangle (row <= column),
+ *     no limits (the reference's own tests run symmetric products with full limits only, tests/dbcsr_test_multiply.F:196-200). */
+int dbcsr_amd_bcsr_twin_count(void* handle, const dbcsr_amd_bcsr* src, int mode, int32_t* dst_row_p, int64_t* nblks, int64_t* nze, void* stream);
+int dbcsr_amd_bcsr_twin_apply(void* handle, libsmm_acc_data_t datatype, const dbcsr_amd_bcsr* src, int mode, int antisymmetric,
+  dbcsr_amd_bcsr* dst, void* stream);
+int dbcsr_amd_mm_set_canonical_product(void* handle, int on);
+int dbcsr_amd_multiply_symmetric_c(void* handle, char transa, char transb, libsmm_acc_data_t datatype, double alpha,
+  const dbcsr_amd_bcsr* matrix_a, const dbcsr_amd_bcsr* matrix_b, double beta, const dbcsr_amd_bcsr* matrix_c, int antisymmetric,
+  int retain_sparsity, double filter_eps, dbcsr_amd_bcsr* c_out, int64_t* flop, void* stream);
+
 /* Statistics of the last dbcsr_amd_mm_numeric of this handle, by (m, n, k): at most max_entries records are written to
  * `out` (host memory), *n_entries receives the number of distinct triples (larger than max_entries = truncated).
  * Counted on the device from the product lists of that call; synchronises `stream`. */

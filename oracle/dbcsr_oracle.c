@@ -493,7 +493,9 @@ orc_result* orc_multiply_d(char transa, char transb, double alpha,
   /* B */ int b_nbr, int b_nbc, const int* b_rs, const int* b_cs, const int* b_row_p, const int* b_col_i, const i64* b_blk_p,
   const double* b_data, double beta,
   /* C */ int c_nbr, int c_nbc, const int* c_rs, const int* c_cs, const int* c_row_p, const int* c_col_i, const i64* c_blk_p,
-  const double* c_data, int retain_sparsity, double filter_eps, const int* limits) {
+  const double* c_data, int retain_sparsity, double filter_eps, const int* limits, int canonical_c) {
+  /* canonical_c: the product matrix has symmetry and its index is in canonical (checkerboard) form, dbcsr_mm.F:711-719: the
+   * local multiply then leaves out the blocks whose twin (j, i) is the stored one (dbcsr_mm_csr.F:280-292) */
   int *ta_row_p = NULL, *ta_col_i = NULL, *tb_row_p = NULL, *tb_col_i = NULL;
   i64 *ta_blk_p = NULL, *tb_blk_p = NULL;
   double *ta_data = NULL, *tb_data = NULL;
@@ -629,6 +631,8 @@ orc_result* orc_multiply_d(char transa, char transb, double alpha,
         const int j = b_col_i[bb];
         if (j < j0 || j > j1) continue;
         if (use_eps && a_norms[ab] * b_norms[bb] < row_eps[i]) continue;
+        /* checker_tr (dbcsr_dist_operations.F:65-75) on the 1-based logical coordinates */
+        if (canonical_c && i != j && ((((i + j) & 1) == 1) == (j >= i))) continue;
         const int n = b_cs[j];
         i64 w = lut[j];
         if (w < 0) {

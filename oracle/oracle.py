@@ -53,7 +53,7 @@ def lib():
         L.orc_check_sum.restype = C.c_double
         mat = [C.c_int, C.c_int, i32p, i32p, i32p, i32p, i64p, f64p]
         L.orc_multiply_d.argtypes = ([C.c_char, C.c_char, C.c_double] + mat + mat + [C.c_double] + mat +
-                                     [C.c_int, C.c_double, C.c_void_p])
+                                     [C.c_int, C.c_double, C.c_void_p, C.c_int])
         L.orc_multiply_d.restype = C.c_void_p
         for nm in ("orc_result_nblks", "orc_result_nze", "orc_result_flop", "orc_result_nproducts"):
             getattr(L, nm).argtypes = [C.c_void_p]
@@ -230,15 +230,52 @@ def checksum(M, pos=False):
     return f(M.nbr, M.nbc, M.row_sizes, M.col_sizes, M.row_p, M.col_i, M.blk_p, M.data, 1 if pos else 0)
 
 
-def multiply(transa, transb, alpha, A, B, beta, Cm, retain_sparsity=False, filter_eps=0.0, limits=None):
-    """C <- beta*C + alpha*op(A)*op(B); returns (C_out Bcsr, info dict)."""
+def checker_tr(row, col):
+    """dbcsr_dist_operations.F:65-75 (1-based logical block coordinates): is the stored twin of block (row, col) the block (col, row)?"""
+    return (((row + col) & 1) == 1) == (col >= row)
+
+
+def move_to_twin(M, move, symmetry):
+    """blocks (r, c) with move(r, c) become blocks (c, r) = +-block^T (0-based r, c); the others stay (square blocking)."""
+    sign = 1.0 if symmetry == "S" else -1.0
+    rows = M.rows()
+    blocks = {}
+    for b in range(M.nblks):
+        r, c = int(rows[b]), int(M.col_i[b])
+        m, n = int(M.row_sizes[r]), int(M.col_sizes[c])
+        v = M.data[M.blk_p[b]:M.blk_p[b] + m * n]
+        if move(r, c):
+            blocks[(c, r)] = sign * v.reshape(n, m).T.reshape(-1)
+        else:
+            blocks[(r, c)] = v
+    keys = sorted(blocks)
+    rr = np.asarray([k[0] for k in keys], np.int32)
+    cc = np.asarray([k[1] for k in keys], np.int32)
+    nze = M.row_sizes[rr].astype(np.int64) * M.col_sizes[cc].astype(np.int64) if keys else np.zeros(0, np.int64)
+    blk_p = np.concatenate([[0], np.cumsum(nze)[:-1]]).astype(np.int64) if keys else np.zeros(0, np.int64)
+    data = np.concatenate([blocks[k] for k in keys]) if keys else np.zeros(0, M.data.dtype)
+    row_p = np.zeros(M.nbr + 1, np.int64)
+    np.add.at(row_p, rr.astype(np.int64) + 1, 1)
+    return Bcsr(M.row_sizes, M.col_sizes, np.cumsum(row_p).astype(np.int32), cc, blk_p, data)
+
+
+def multiply(transa, transb, alpha, A, B, beta, Cm, retain_sparsity=False, filter_eps=0.0, limits=None, c_symmetry=None):
+    """C <- beta*C + alpha*op(A)*op(B); returns (C_out Bcsr, info dict).
+    c_symmetry "S" / "A": Cm holds the stored triangle (row <= col) of a symmetric / antisymmetric product matrix.  The reference
+    puts its index into canonical (checkerboard) form first (dbcsr_mm.F:711-719, dbcsr_make_index_canonical), computes only the
+    blocks that are stored in that form (dbcsr_mm_csr.F:280-292) and goes back to the triangle at the end."""
+    if c_symmetry in ("S", "A"):
+        assert limits is None and np.array_equal(Cm.row_sizes, Cm.col_sizes)
+        canon = move_to_twin(Cm, lambda r, c: r != c and checker_tr(r + 1, c + 1), c_symmetry)
+        out, info = multiply(transa, transb, alpha, A, B, beta, canon, retain_sparsity, filter_eps, None, c_symmetry="canonical")
+        return move_to_twin(out, lambda r, c: r > c, c_symmetry), info
     L = lib()
     lim = None
     if limits is not None:
         lim_arr = np.ascontiguousarray(limits, np.int32)
         lim = lim_arr.ctypes.data
     h = L.orc_multiply_d(transa.encode(), transb.encode(), float(alpha), *A._args(), *B._args(), float(beta),
-                         *Cm._args(), 1 if retain_sparsity else 0, float(filter_eps), lim)
+                         *Cm._args(), 1 if retain_sparsity else 0, float(filter_eps), lim, 1 if c_symmetry == "canonical" else 0)
     if not h:
         raise ValueError("orc_multiply_d failed")
     try:

@@ -54,10 +54,9 @@ def oracle_inputs(p):
         return O.perf_case(p["M"], p["N"], p["K"], p["sp"][0], p["sp"][1], p["sp"][2], p["bs_m"], p["bs_n"], p["bs_k"], p["transa"], p["transb"],
                            dtype=np_dtype(p))
     assert np_dtype(p) == np.float64
-    assert p["symm_c"] == "N"
     sm, sn, sk = O.make_block_sizes(p["M"], p["bs_m"]), O.make_block_sizes(p["N"], p["bs_n"]), O.make_block_sizes(p["K"], p["bs_k"])
     c0 = O.RANDMAT_SEED_INIT
-    Cm = O.make_random_matrix(sm, sn, p["sp"][2], c0 + 1)
+    Cm = O.make_random_matrix(sm, sn, p["sp"][2], c0 + 1) if p["symm_c"] == "N" else O.make_random_matrix_symmetric(sm, p["sp"][2], c0 + 1, p["symm_c"])
 
     def operand(symm, rs, cs, sp, counter):
         if symm == "N":
@@ -90,6 +89,9 @@ def oracle_run(p):
         wide = lambda M: O.Bcsr(M.row_sizes, M.col_sizes, M.row_p, M.col_i, M.blk_p, M.data.astype(np.float64))
         A, B, Cm = wide(A), wide(B), wide(Cm)
     eps = p["filter_eps"] if p["filter_eps"] >= 0 else 0.0
+    if p["symm_c"] != "N":
+        assert not any(p["limits"])
+        return O.multiply(p["transa"], p["transb"], p["alpha"], A, B, p["beta"], Cm, retain_sparsity=p["retain"], filter_eps=eps, c_symmetry=p["symm_c"])
     if any(p["limits"]):
         return O.multiply_limits(p["transa"], p["transb"], p["alpha"], A, B, p["beta"], Cm, p["limits"], retain_sparsity=p["retain"], filter_eps=eps)
     return O.multiply(p["transa"], p["transb"], p["alpha"], A, B, p["beta"], Cm, retain_sparsity=p["retain"], filter_eps=eps)

@@ -58,6 +58,16 @@ CASES = [
     case("symm_a_A", 60, 60, 60, (0.5, 0.5, 0.5), [1, 4], symm_a="A"),
     case("symm_a_S_T", 60, 60, 60, (0.5, 0.5, 0.5), [1, 4], symm_a="S", transa="T"),
     case("symm_b_A_T", 60, 60, 60, (0.5, 0.5, 0.5), [1, 4], symm_b="A", transb="T"),
+    # symmetric / antisymmetric PRODUCT matrix: only the blocks of its stored (canonical) form are computed
+    # (dbcsr_test_multiply.F:187-200 runs these with (N, T) / (T, N) and full limits)
+    case("symm_c_S_NT", 60, 60, 50, (0.5, 0.5, 0.6), [1, 4], [1, 4], [1, 5], symm_c="S", transb="T", alpha=0.5, beta=2.0),
+    case("symm_c_S_TN", 60, 60, 50, (0.5, 0.5, 0.6), [1, 4, 1, 6], [1, 4, 1, 6], [1, 5], symm_c="S", transa="T"),
+    case("symm_c_S_beta0", 60, 60, 50, (0.5, 0.5, 0.3), [1, 4], [1, 4], [1, 5], symm_c="S", transb="T", beta=0.0),
+    case("symm_c_S_retain", 60, 60, 50, (0.5, 0.5, 0.5), [1, 4], [1, 4], [1, 5], symm_c="S", transb="T", retain=True),
+    case("symm_c_S_filter", 100, 100, 100, (0.7, 0.7, 0.9), [1, 5], symm_c="S", transb="T", filter_eps=12.0),
+    case("symm_c_A_NT", 60, 60, 50, (0.5, 0.5, 0.6), [1, 4], [1, 4], [1, 5], symm_c="A", transb="T", alpha=-1.5, beta=0.5),
+    case("symm_abc_S", 60, 60, 60, (0.5, 0.5, 0.5), [1, 3, 1, 5], symm_a="S", symm_b="S", symm_c="S"),
+    case("symm_c_S_NN", 48, 48, 48, (0.5, 0.5, 0.5), [1, 4], symm_c="S"),
     # single precision (data_type 1 of the .perf format; BASELINE config 5's shape: 32 x 32 blocks, and a mixed one)
     case("fp32_32", 32 * 6, 32 * 5, 32 * 7, (0.6, 0.6, 0.7), [1, 32], data_type=1),
     case("fp32_32_beta0_T", 32 * 5, 32 * 5, 32 * 6, (0.5, 0.5, 0.5), [1, 32], data_type=1, beta=0.0, transa="T"),
