@@ -300,3 +300,40 @@ def test_mnk_statistics_match_enumeration():
     buf = io.StringIO()
     eng.print_statistics(buf)
     assert "flops total" in buf.getvalue() and "100.0%" in buf.getvalue()
+
+
+@pytest.mark.parametrize("symm", ["S", "A"])
+def test_symmetric_product_is_the_triangle_of_the_full_product(symm):
+    """A product matrix with symmetry at a size where the exact-size kernel runs (8192^2, 23 x 23 blocks, 10 %): C_sym = A A^T (symmetric)
+    or A B^T - B A^T (antisymmetric) computed on the stored triangle only must equal the triangle of the full product, with about
+    half its products."""
+    from dbcsr_amd.matrix import DbcsrMatrix
+    from dbcsr_amd.randmat import perf_matrices
+    E = MultiplyEngine()
+    A, B, _ = perf_matrices(8192, 8192, 8192, (0.9, 0.9, 0.9), [1, 23], [1, 23], [1, 23], dtype=torch.float64, engine=E)
+    dev = A.data.device
+    empty = lambda: DbcsrMatrix.empty_like_pattern(A.row_blk_size, A.row_blk_size, torch.float64, device=dev)
+    full = empty()
+    if symm == "S":
+        c_full = dbcsr_multiply("N", "T", 1.0, A, A, 0.0, full, engine=E)
+    else:
+        dbcsr_multiply("N", "T", 1.0, A, B, 0.0, full, engine=E)
+        c_full = dbcsr_multiply("N", "T", -1.0, B, A, 1.0, full, engine=E)
+    sym = empty()
+    sym.symmetry = symm
+    if symm == "S":
+        c_sym = dbcsr_multiply("N", "T", 1.0, A, A, 0.0, sym, engine=E)
+    else:
+        dbcsr_multiply("N", "T", 1.0, A, B, 0.0, sym, engine=E)
+        c_sym = dbcsr_multiply("N", "T", -1.0, B, A, 1.0, sym, engine=E)
+    torch.cuda.synchronize()
+    assert "hot<23,23,23>" in E.last_kernel()
+    F, S = dev_to_bcsr(full), dev_to_bcsr(sym)
+    frow = F.rows()
+    keep = np.nonzero(frow <= F.col_i)[0]
+    assert np.array_equal(S.rows(), frow[keep]) and np.array_equal(S.col_i, F.col_i[keep])
+    nze = F.row_sizes[frow[keep]].astype(np.int64) * F.col_sizes[F.col_i[keep]]
+    want = np.concatenate([F.data[F.blk_p[b]:F.blk_p[b] + n] for b, n in zip(keep, nze)])
+    assert S.data.size == want.size and rel_err(S.data, want) <= 1e-10
+    nb = len(F.row_sizes)
+    assert abs(c_sym.flop / c_full.flop - 0.5) < 1.5 / nb + 0.01   # half the products (the diagonal blocks are computed once in both)
