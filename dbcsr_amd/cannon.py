@@ -634,8 +634,23 @@ class CannonMultiply:
             dev.copy_(host)
         return [], v, a_data, b_data
 
-    def multiply(self, alpha=1.0, beta=1.0):
-        """One distributed multiply; returns (local C_out, counts with this rank's flop)."""
+    def multiply(self, alpha=1.0, beta=1.0, retain_sparsity=False, filter_eps=None):
+        """One distributed multiply; returns (local C_out, counts with this rank's flop).
+        retain_sparsity / filter_eps as in dbcsr_multiply.  The on-the-fly filter compares every product with
+        (filter_eps / number of blocks of the WHOLE block row of A)^2 (the reference sums the row counts over the process row first,
+        dbcsr_mm_cannon.F:1040-1113): such a multiply runs over the full row / column panels in one piece -- every rank then takes
+        exactly the decisions a single rank would -- whatever the schedule of the plain products is."""
+        if retain_sparsity or (filter_eps is not None and filter_eps > 0.0):
+            works, staged = self._post_all()
+            for w in works:
+                w.wait()
+            for item in staged:
+                if isinstance(item, tuple):
+                    item[1].copy_(item[0])
+            Cout, counts = self.eng.multiply_local(alpha, self.A_panel, self.B_panel, beta, self.C_in, retain_sparsity=retain_sparsity,
+                                                   filter_eps=filter_eps or 0.0)
+            self.last_tick_flop = getattr(self.eng, "last_launch_flop", counts.flop)
+            return Cout, counts
         if self.mode == "gather":
             return self._multiply_gather(alpha, beta)
         g, eng = self.grid, self.eng

@@ -20,6 +20,16 @@ def _to_oracle(M, data=None):
     return O.Bcsr(rs, cs, row_p, col_i, blk_p, np.ascontiguousarray(d, np.float64))
 
 
+def gathered(M):
+    """panel matrices point into a concatenated buffer: re-pack to the oracle's compact layout"""
+    rs, cs, rp, ci, bp, d = M.to_host()
+    rows = np.repeat(np.arange(len(rs)), np.diff(rp))
+    nze = rs[rows].astype(np.int64) * cs[ci].astype(np.int64)
+    nbp = np.concatenate([[0], np.cumsum(nze)[:-1]]).astype(np.int64) if len(nze) else np.zeros(0, np.int64)
+    nd = np.concatenate([d[bp[b]:bp[b] + nze[b]] for b in range(len(ci))]) if len(ci) else np.zeros(0)
+    return O.Bcsr(rs, cs, rp, ci, nbp, nd)
+
+
 class OracleBackend:
     def fill_random_dist(self, M, counter, row_gid, col_gid, nblkrows_global, stream=None):
         rs, cs, row_p, col_i, blk_p, _ = M.to_host()
@@ -65,18 +75,17 @@ class OracleBackend:
                            torch.from_numpy(data), "C")
 
     def numeric_after_symbolic(self, alpha, A, B, beta, Cm, row_p, counts, dtype, stream=None):
-        def gathered(M):  # panel matrices point into a concatenated buffer: re-pack to the oracle's compact layout
-            rs, cs, rp, ci, bp, d = M.to_host()
-            rows = np.repeat(np.arange(len(rs)), np.diff(rp))
-            nze = rs[rows].astype(np.int64) * cs[ci].astype(np.int64)
-            nbp = np.concatenate([[0], np.cumsum(nze)[:-1]]).astype(np.int64) if len(nze) else np.zeros(0, np.int64)
-            nd = np.concatenate([d[bp[b]:bp[b] + nze[b]] for b in range(len(ci))]) if len(ci) else np.zeros(0)
-            return O.Bcsr(rs, cs, rp, ci, nbp, nd)
         out, _ = O.multiply("N", "N", alpha, gathered(A), gathered(B), beta, _to_oracle(Cm))
         return DbcsrMatrix(Cm.row_blk_size, Cm.col_blk_size, torch.from_numpy(out.row_p.copy()), torch.from_numpy(out.col_i.copy()),
                            torch.from_numpy(out.blk_p.copy()), torch.from_numpy(out.data.copy()), "C")
 
     def multiply_local(self, alpha, A, B, beta, Cm, retain_sparsity=False, stream=None, filter_eps=0.0):
+        if retain_sparsity or filter_eps:
+            out, info = O.multiply("N", "N", alpha, gathered(A), gathered(B), beta, _to_oracle(Cm), retain_sparsity=retain_sparsity,
+                                   filter_eps=filter_eps or 0.0)
+            M = DbcsrMatrix(Cm.row_blk_size, Cm.col_blk_size, torch.from_numpy(out.row_p.copy()), torch.from_numpy(out.col_i.copy()),
+                            torch.from_numpy(out.blk_p.copy()), torch.from_numpy(out.data.copy()), "C")
+            return M, _Counts(out.nblks, len(out.data), info["nproducts"], info["flop"])
         row_p, counts = self.symbolic(A, B, Cm, retain_sparsity)
         info_flop, info_np = counts.flop, counts.nproducts
         out = self.numeric_after_symbolic(alpha, A, B, beta, Cm, row_p, counts, torch.float64)

@@ -26,7 +26,7 @@ def _free_port():
 CASE = dict(M=23 * 9 + 16, N=13 * 14 + 5, K=17 * 8 + 3, sp=(0.6, 0.65, 0.8), mix=[1, 23], mix_n=[1, 13], mix_k=[2, 17, 1, 5])
 
 
-def _worker(rank, world, port, alpha, beta, q, mode):
+def _worker(rank, world, port, alpha, beta, q, mode, retain=False, eps=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -53,7 +53,7 @@ def _worker(rank, world, port, alpha, beta, q, mode):
             plan = cannon.CannonMultiply(CASE["M"], CASE["N"], CASE["K"], CASE["sp"], CASE["mix"], dtype=torch.float64,
                                          engine=OracleBackend(), device=torch.device("cpu"), mix_n=CASE["mix_n"], mix_k=CASE["mix_k"],
                                          mode=mode)
-        Cout, counts = plan.multiply(alpha, beta)
+        Cout, counts = plan.multiply(alpha, beta, retain_sparsity=retain, filter_eps=eps) if (retain or eps) else plan.multiply(alpha, beta)
         parts = plan.gather_global(Cout)
         fl = torch.tensor([counts.flop], dtype=torch.int64)
         dist.all_reduce(fl)
@@ -66,11 +66,23 @@ def _worker(rank, world, port, alpha, beta, q, mode):
 @pytest.mark.parametrize("world,mode", [(2, "gather"), (4, "gather+given"), (6, "gather"), (4, "ticks"), (6, "ticks+given"),
                                         (4, "ticks+dist"), (6, "gather+dist"), (2, "ticks+dist")])
 def test_cannon_matches_global_oracle(world, mode):
+    _run_and_compare(world, mode)
+
+
+@pytest.mark.parametrize("world,mode,retain,eps", [(4, "gather", False, 60.0), (6, "ticks", False, 80.0), (4, "ticks+dist", True, None),
+                                                  (2, "gather", True, 60.0)])
+def test_cannon_filter_and_retain_match_global_oracle(world, mode, retain, eps):
+    """filter_eps / retain_sparsity on several ranks: every rank takes the decisions one rank would (row counts of the WHOLE block
+    row enter the on-the-fly filter, dbcsr_mm_cannon.F:1040-1113), block structure and values equal the single-rank oracle's."""
+    _run_and_compare(world, mode, retain, eps)
+
+
+def _run_and_compare(world, mode, retain=False, eps=None):
     alpha, beta = 0.75, -1.25
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, alpha, beta, q, mode)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, alpha, beta, q, mode, retain, eps)) for r in range(world)]
     for p in procs:
         p.start()
     parts, flop, pr, pc, nvirt = q.get(timeout=240)
@@ -80,7 +92,7 @@ def test_cannon_matches_global_oracle(world, mode):
     assert pr * pc == world and nvirt == pr * pc // np.gcd(pr, pc)
     # global reference: same generator, same seeds, one rank
     A, B, Cm = O.perf_case(CASE["M"], CASE["N"], CASE["K"], *CASE["sp"], CASE["mix"], CASE["mix_n"], CASE["mix_k"])
-    ref, info = O.multiply("N", "N", alpha, A, B, beta, Cm)
+    ref, info = O.multiply("N", "N", alpha, A, B, beta, Cm, retain_sparsity=retain, filter_eps=eps or 0.0)
     assert flop == info["flop"]  # every block product executed exactly once across ranks and ticks
     got = {}
     for grow, gcol, blocks in parts:

@@ -22,6 +22,9 @@ def main():
     from dbcsr_amd import cannon
     from dbcsr_amd.multiply import MultiplyEngine
     M, N, K, sp = 23 * 60 + 16, 23 * 50 + 16, 23 * 70 + 16, (0.8, 0.8, 0.85)
+    eps = None
+    if mode.endswith("+filter"):   # on-the-fly filter + final block filter on several ranks (every rank decides as one rank would)
+        mode, eps = mode[:-len("+filter")], 150.0
     if mode.endswith("+dist"):
         # distributed input: every rank holds an arbitrary share of the blocks of A, B and C, their data in HBM; make_images
         # (cannon.redistribute) packs, exchanges and sorts them on the device
@@ -41,7 +44,7 @@ def main():
     else:
         plan = cannon.CannonMultiply(M, N, K, sp, [1, 23], dtype=torch.float64, engine=MultiplyEngine(), mode=mode)
     for _ in range(2):
-        Cout, counts = plan.multiply(0.5, 2.0)
+        Cout, counts = plan.multiply(0.5, 2.0, filter_eps=eps) if eps else plan.multiply(0.5, 2.0)
     torch.cuda.synchronize()
     parts = plan.gather_global(Cout)
     fl = torch.tensor([counts.flop], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
@@ -50,7 +53,10 @@ def main():
     if rank == 0:
         from oracle import oracle as O
         A, B, Cm = O.perf_case(M, N, K, *sp, [1, 23], [1, 23], [1, 23])
-        ref, info = O.multiply("N", "N", 0.5, A, B, 2.0, Cm)
+        ref, info = O.multiply("N", "N", 0.5, A, B, 2.0, Cm, filter_eps=eps or 0.0)
+        if eps:
+            full, finfo = O.multiply("N", "N", 0.5, A, B, 2.0, Cm)
+            assert ref.nblks < full.nblks, "the filter case does not filter"
         got = {}
         for grow, gcol, blocks in parts:
             for r, c, blk in zip(grow, gcol, blocks):
