@@ -286,15 +286,27 @@ class CannonMultiply:
         self.comm = None
         self.transport = "torch"
         if transport in ("native", "auto") and dist.is_initialized() and dist.get_world_size() > 1 and torch.cuda.is_available():
+            import sys
+            err = None
             try:
                 from .comm import NativeComm
                 self.comm = NativeComm()
-                self.transport = "native"
+                err = self._native_selftest()
             except Exception as e:  # noqa: BLE001
+                err = repr(e)
+            # every rank must end up with the same transport: agree over torch's own communicator
+            flag_dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+            ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=flag_dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 1:
+                self.transport = "native"
+            else:
+                if self.comm is not None and err is None:
+                    self.comm.close()
+                self.comm = None   # (a communicator whose self-test did not complete is abandoned, not destroyed: that could block)
                 if transport == "native":
-                    raise
-                import sys
-                sys.stderr.write("dbcsr_amd.cannon: native RCCL transport unavailable (%r), using torch.distributed\n" % (e,))
+                    raise RuntimeError("dbcsr_amd.cannon: native RCCL transport unavailable on some rank (%s)" % (err,))
+                sys.stderr.write("dbcsr_amd.cannon: native RCCL transport unavailable (%s), using torch.distributed\n" % (err or "another rank",))
         self.mode = mode
         self.local_first = local_first
         self._host = None
@@ -412,6 +424,25 @@ class CannonMultiply:
         bmax = max([m.data_numel for v, m in self.B_img.items() if g.b_owner(v, c) != g.rank] + [0])
         self._abuf = [torch.empty(amax, dtype=dtype, device=self.device) for _ in range(2)]
         self._bbuf = [torch.empty(bmax, dtype=dtype, device=self.device) for _ in range(2)]
+
+    def _native_selftest(self, timeout_s=60.0):
+        """One tiny ring exchange through the native transport before it is trusted with the panels; returns None or what went
+        wrong.  The wait is bounded: a transport that does not complete here falls back to torch.distributed instead of hanging
+        the first multiply."""
+        import time
+        c = self.comm
+        nxt, prv = (c.rank + 1) % c.world, (c.rank - 1) % c.world
+        out = torch.full((16,), float(c.rank), dtype=torch.float64, device="cuda")
+        inp = torch.full((16,), -1.0, dtype=torch.float64, device="cuda")
+        ev = c.exchange([(out, nxt)], [(inp, prv)])
+        t0 = time.perf_counter()
+        while not ev.query():
+            if time.perf_counter() - t0 > timeout_s:
+                return "self-test exchange did not complete within %.0f s" % timeout_s
+            time.sleep(0.001)
+        if not bool(torch.all(inp == float(prv))):
+            return "self-test exchange delivered wrong data"
+        return None
 
     def _make(self, which, rdist, rsel, cdist, csel, rloc, cloc, nrows_local, rs_t, cs_t, rsizes, csizes, rgid, cgid, nrow_global, fill):
         rows, cols = self.pat[which]

@@ -29,3 +29,15 @@ def test_native_comm_self_exchange_and_allgather():
     with pytest.raises(RuntimeError):
         comm.exchange([(src, 5)], [])
     comm.close()
+
+
+def test_cannon_transport_selftest_on_one_rank():
+    """the bounded-wait ring exchange CannonMultiply runs before it trusts the native transport (here: a ring of one)"""
+    from dbcsr_amd.cannon import CannonMultiply
+    from dbcsr_amd.comm import NativeComm
+    plan = CannonMultiply.__new__(CannonMultiply)
+    plan.comm = NativeComm()
+    try:
+        assert plan._native_selftest(timeout_s=30.0) is None
+    finally:
+        plan.comm.close()
