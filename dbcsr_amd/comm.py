@@ -63,6 +63,9 @@ class NativeComm:
         return done
 
     def allgather_bytes(self, t_send, t_recv):
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream())
+        self.stream.wait_event(ready)  # t_send was produced on the compute stream
         rc = self.L.dbcsr_amd_comm_allgather(self.h, t_send.data_ptr(), t_recv.data_ptr(), t_send.numel() * t_send.element_size(),
                                              StreamHandle(self.stream).ptr)
         if rc != 0:
