@@ -330,9 +330,11 @@ int dbcsr_amd_multiply(void* handle, char transa, char transb, libsmm_acc_data_t
     if (alloc_row_p(filtered, prod.m.nblkrows)) return -1;
     int64_t nb = 0, nz = 0;
     if ((rc = dbcsr_amd_bcsr_filter_count(handle, datatype, &prod.m, filter_eps, filtered.m.row_p, &nb, &nz, stream))) return rc;
-    if (alloc_arrays(filtered, prod.m.nblkrows, prod.m.nblkcols, prod.m.row_blk_size, prod.m.col_blk_size, nb, nz, esz, false)) return -1;
-    if ((rc = dbcsr_amd_bcsr_filter_apply(handle, datatype, &prod.m, &filtered.m, stream))) return rc;
-    result = &filtered;
+    if (nb != prod.m.nblks) {  // (nothing below the threshold: the product is the result, no second copy)
+      if (alloc_arrays(filtered, prod.m.nblkrows, prod.m.nblkcols, prod.m.row_blk_size, prod.m.col_blk_size, nb, nz, esz, false)) return -1;
+      if ((rc = dbcsr_amd_bcsr_filter_apply(handle, datatype, &prod.m, &filtered.m, stream))) return rc;
+      result = &filtered;
+    }
   }
   // temporaries are freed when this function returns: everything that reads them must have finished
   if (hipStreamSynchronize(st) != hipSuccess) return -1;

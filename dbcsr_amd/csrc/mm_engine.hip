@@ -325,13 +325,15 @@ __device__ __forceinline__ float row_filter_eps(const FilterArgs& F, int nblks_i
 template <typename T>
 __global__ void __launch_bounds__(256) bcsr_block_norms(const int* __restrict__ row_p, const int* __restrict__ col_i,
                                                         const int64_t* __restrict__ blk_p, const T* __restrict__ data,
-                                                        const int* __restrict__ rs, const int* __restrict__ cs, int nbr, double scale,
+                                                        const int* __restrict__ rs, const int* __restrict__ cs, int nbr, int S, double scale,
                                                         float* __restrict__ norms, double* __restrict__ norms64) {
+  // S waves share a block row (wave s takes the blocks b = s mod S): a long row is not one wave's serial stream
   const int lane = threadIdx.x & 63;
-  const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t wv = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int row = (int)(wv / S), sub = (int)(wv % S);
   if (row >= nbr) return;
   const int m = rs[row];
-  for (int b = row_p[row]; b < row_p[row + 1]; ++b) {
+  for (int b = row_p[row] + sub; b < row_p[row + 1]; b += S) {
     const int ne = m * cs[col_i[b]];
     const T* d = data + blk_p[b];
     double s = 0.0;
@@ -506,6 +508,27 @@ fill_products_grid(const int* __restrict__ a_row_p, const int* __restrict__ a_co
 }
 
 
+// C pattern under filtering, product-driven (sparse C): one wave per block row i ORs the bit of every product that passes the
+// on-the-fly filter into row i of c_bm, which starts as C_in's pattern (the candidate-driven c_bitmap_filtered tests
+// nbr x nbc x |A row| combinations)
+__global__ void __launch_bounds__(256) c_bitmap_rows_filtered(const int* __restrict__ a_row_p, const int* __restrict__ a_col_i,
+                                                              const int* __restrict__ b_row_p, const int* __restrict__ b_col_i, int nbr, int W,
+                                                              int canonical, FilterArgs F, uint32_t* __restrict__ c_bm) {
+  const int lane = threadIdx.x & 63;
+  const int i = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  if (i >= nbr) return;
+  const float reps = row_filter_eps(F, a_row_p[i + 1] - a_row_p[i]);
+  for (int ab = a_row_p[i]; ab < a_row_p[i + 1]; ++ab) {
+    const int k = a_col_i[ab];
+    for (int bb = b_row_p[k] + lane; bb < b_row_p[k + 1]; bb += 64) {
+      if (F.a_norms[ab] * F.b_norms[bb] < reps) continue;
+      const int j = b_col_i[bb], w = j >> 5, bit = j & 31;
+      if (canonical && !((canonical_bits(i, w) >> bit) & 1u)) continue;
+      atomicOr(&c_bm[(size_t)i * W + w], 1u << bit);
+    }
+  }
+}
+
 // ---- product-driven variants for a sparse C (BASELINE config 4: C 43 % full, 1.3 products per C block) --------------------------
 // The grid kernels test every (row, column) candidate against every block of A's row: nbr x nbc x |A row| bitmap tests
 // (config 4: 1.9 G for 18.6 M products; count 2.0 ms + fill 2.7 ms = 15 % of the multiply).  Here ONE WAVE owns a block row i of A
@@ -518,19 +541,21 @@ __global__ void __launch_bounds__(256) count_products_rows(const int* __restrict
                                                            const int* __restrict__ b_row_p, const int* __restrict__ b_col_i,
                                                            const uint32_t* __restrict__ c_bm, const int* __restrict__ c_pre,
                                                            const int* __restrict__ c_row_p, int nbr, int W, int* __restrict__ prod_cnt,
-                                                           unsigned long long* __restrict__ flop_out) {
+                                                           unsigned long long* __restrict__ flop_out, FilterArgs F) {
   const int lane = threadIdx.x & 63;
   const int i = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   unsigned long long flop = 0;
   if (i < nbr) {
     const unsigned long long m = (unsigned long long)rs[i];
+    const float reps = F.a_norms ? row_filter_eps(F, a_row_p[i + 1] - a_row_p[i]) : 0.0f;
     for (int ab = a_row_p[i]; ab < a_row_p[i + 1]; ++ab) {
       const int k = a_col_i[ab];
       const unsigned long long kk = (unsigned long long)ks[k];
       for (int bb = b_row_p[k] + lane; bb < b_row_p[k + 1]; bb += 64) {
+        if (F.a_norms && F.a_norms[ab] * F.b_norms[bb] < reps) continue;  // on-the-fly filter
         const int j = b_col_i[bb], w = j >> 5, bit = j & 31;
         const uint32_t cw = c_bm[(size_t)i * W + w];
-        if (!((cw >> bit) & 1u)) continue;  // retain_sparsity: no such C block
+        if (!((cw >> bit) & 1u)) continue;  // retain_sparsity / product matrix with symmetry: no such C block
         const int cb = c_row_p[i] + c_pre[(size_t)i * W + w] + __popc(cw & ((1u << bit) - 1u));
         atomicAdd(&prod_cnt[cb], 1);
         flop += 2ull * m * (unsigned long long)cs[j] * kk;
@@ -554,15 +579,17 @@ __global__ void __launch_bounds__(256) fill_products_rows(const int* __restrict_
                                                           const int64_t* __restrict__ b_blk_p, const uint32_t* __restrict__ c_bm,
                                                           const int* __restrict__ c_pre, const int* __restrict__ c_row_p,
                                                           const int64_t* __restrict__ prod_start, int nbr, int W, int* __restrict__ fill_cnt,
-                                                          Entry* __restrict__ entries) {
+                                                          Entry* __restrict__ entries, FilterArgs F) {
   const int lane = threadIdx.x & 63;
   const int i = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   if (i >= nbr) return;
+  const float reps = F.a_norms ? row_filter_eps(F, a_row_p[i + 1] - a_row_p[i]) : 0.0f;
   for (int ab = a_row_p[i]; ab < a_row_p[i + 1]; ++ab) {
     const int k = a_col_i[ab];
     const int kk = ks[k];
     const int64_t a_off = a_blk_p[ab];
     for (int bb = b_row_p[k] + lane; bb < b_row_p[k + 1]; bb += 64) {
+      if (F.a_norms && F.a_norms[ab] * F.b_norms[bb] < reps) continue;
       const int j = b_col_i[bb], w = j >> 5, bit = j & 31;
       const uint32_t cw = c_bm[(size_t)i * W + w];
       if (!((cw >> bit) & 1u)) continue;
@@ -926,7 +953,7 @@ template <int M, int N, int K>
 __device__ __forceinline__ void cblock_f64_exact(const Desc& d, const Entry first, const Entry* __restrict__ entries, const double* __restrict__ a_data,
                                                  const double* __restrict__ b_data, double* __restrict__ c_out,
                                                  const double* __restrict__ c_in, double alpha, double beta, const LaneMap& L, int lane,
-                                                 char* lds_a, char* lds_b, int dbg) {
+                                                 char* lds_a, char* lds_b, int dbg, double* __restrict__ norm_out) {
   constexpr int MA = (M + 7) / 8, NC = (N + 7) / 8, KS = (K + 3) / 4, K4 = 4 * KS;
   constexpr int CA = (M * K4 * 8 + 1023) / 1024, CB = (K * N * 8 + 1023) / 1024;
   double acc[MA][NC];
@@ -1063,6 +1090,7 @@ __device__ __forceinline__ void cblock_f64_exact(const Desc& d, const Entry firs
       const f64x2 w = __builtin_bit_cast(f64x2, ci[c]);
       v[0] += beta * w[0];
       v[1] += beta * w[1];
+      if (norm_out) *reinterpret_cast<f64x2*>(lds_a + c * 1024 + voff) = v;  // (the final values, for the norm below)
       if (dbg & 16)
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsc, voff, c * 1024, 0);
       else
@@ -1078,6 +1106,21 @@ __device__ __forceinline__ void cblock_f64_exact(const Desc& d, const Entry firs
         __builtin_amdgcn_raw_buffer_store_b128(v, rsc, voff, c * 1024, 2);
     }
   }
+  // squared Frobenius norm of the block as it was stored (the final block filter of a filtered multiply reads it instead of C):
+  // the block still sits in the wave's LDS slice
+  if (norm_out) {
+    double ss = 0.0;
+#pragma unroll
+    for (int c = 0; c < CC; ++c) {
+      const f64x2 v = *reinterpret_cast<const f64x2*>(lds_a + c * 1024 + voff);
+      const int idx = c * 128 + 2 * lane;
+      if (idx < M * N) ss += v[0] * v[0];
+      if (idx + 1 < M * N) ss += v[1] * v[1];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_down(ss, off, 64);
+    if (lane == 0) *norm_out = ss;
+  }
 }
 
 // C blocks of exactly M x N take the exact-size path; every other block of the launch the generic one.
@@ -1086,7 +1129,7 @@ __global__ void __launch_bounds__(256) mm_numeric_f64_hot(const Desc* __restrict
                                                           const double* __restrict__ a_data, const double* __restrict__ b_data,
                                                           double* __restrict__ c_out, const double* __restrict__ c_in, double alpha,
                                                           double beta, int lds_a_doubles, int lds_wave_doubles, int dbg, const int* __restrict__ order,
-                                                          const Work* __restrict__ work) {
+                                                          const Work* __restrict__ work, double* __restrict__ norms) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1103,7 +1146,8 @@ __global__ void __launch_bounds__(256) mm_numeric_f64_hot(const Desc* __restrict
   char* lds_b = lds_a + (size_t)lds_a_doubles * 8;
   const LaneMap L(lane);
   if (d.m == M && d.n == N) {
-    cblock_f64_exact<M, N, K>(d, first, entries, a_data, b_data, c_out, c_in, alpha, beta, L, lane, lds_a, lds_b, dbg);
+    cblock_f64_exact<M, N, K>(d, first, entries, a_data, b_data, c_out, c_in, alpha, beta, L, lane, lds_a, lds_b, dbg,
+                              norms ? norms + w.cb : nullptr);
     return;
   }
   // the few blocks of another size (tail block row / column): straight from global memory, as one 32 x 32 tile
@@ -1999,15 +2043,16 @@ __global__ void __launch_bounds__(256) filter_flags(const double* __restrict__ n
 template <typename T>
 __global__ void __launch_bounds__(256) filter_compact(const int* __restrict__ row_p, const int* __restrict__ col_i,
                                                       const int64_t* __restrict__ blk_p, const T* __restrict__ data,
-                                                      const int* __restrict__ rs, const int* __restrict__ cs, int nbr,
+                                                      const int* __restrict__ rs, const int* __restrict__ cs, int nbr, int S,
                                                       const int* __restrict__ keep, const int64_t* __restrict__ newidx,
                                                       const int64_t* __restrict__ newoff, int* __restrict__ d_col_i,
                                                       int64_t* __restrict__ d_blk_p, T* __restrict__ d_data) {
   const int lane = threadIdx.x & 63;
-  const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t wv = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int row = (int)(wv / S), sub = (int)(wv % S);
   if (row >= nbr) return;
   const int m = rs[row];
-  for (int b = row_p[row]; b < row_p[row + 1]; ++b) {
+  for (int b = row_p[row] + sub; b < row_p[row + 1]; b += S) {
     if (!keep[b]) continue;
     const int64_t t = newidx[b], off = newoff[b];
     if (lane == 0) {
@@ -2242,7 +2287,7 @@ __global__ void __launch_bounds__(256) build_work(const int* __restrict__ order,
   if (pos >= npos) return;
   const int cb = order[pos];
   Work w;
-  w.c_off = 0, w.cin_off = -1, w.prod_start = 0, w.prod_cnt = -1, w.m = 0, w.n = 0, w.a_lo = 0, w.b_lo = 0, w.w = 0, w.pad = 0;
+  w.c_off = 0, w.cin_off = -1, w.prod_start = 0, w.prod_cnt = -1, w.m = 0, w.n = 0, w.a_lo = 0, w.b_lo = 0, w.w = 0, w.cb = cb;
   if (cb >= 0 && cb < nblk) {
     const Desc d = descs[cb];
     w.c_off = d.c_off, w.cin_off = d.cin_off, w.prod_start = d.prod_start, w.prod_cnt = d.prod_cnt, w.m = d.m, w.n = d.n;
@@ -2303,15 +2348,32 @@ namespace dbcsr_amd {
 
 #define DBCSR_AMD_DMA_SIZES(X) X(13) X(16) X(23) X(32)
 
+// one wave per C block, only the blocks that are NOT m x n: their squared Frobenius norm (the exact-size kernel wrote the others')
+__global__ void __launch_bounds__(256) block_norms_other_sizes(const Desc* __restrict__ descs, int64_t nblk, const double* __restrict__ c_data,
+                                                               int m, int n, double* __restrict__ norms) {
+  const int lane = threadIdx.x & 63;
+  const int64_t cb = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (cb >= nblk) return;
+  const Desc d = descs[cb];
+  if (d.m == m && d.n == n) return;
+  const double* x = c_data + d.c_off;
+  double ss = 0.0;
+  for (int e = lane; e < d.m * d.n; e += 64) ss += x[e] * x[e];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) ss += __shfl_down(ss, off, 64);
+  if (lane == 0) norms[cb] = ss;
+}
+
 static bool launch_hot_f64(int m, int n, int k, dim3 grid, size_t lds_bytes, hipStream_t st, const Desc* descs, int64_t nblk,
                            const Entry* entries, const double* a_data, const double* b_data, double* c_out, const double* c_in,
-                           double alpha, double beta, int lds_a, int lds_wave, int dbg, const int* order, const Work* work, int wg_waves) {
+                           double alpha, double beta, int lds_a, int lds_wave, int dbg, const int* order, const Work* work, int wg_waves,
+                           double* norms) {
   if (m != n || m != k) return false;
   switch (m) {
 #define DBCSR_HOT_CASE(S_)                                                                                                      \
   case S_:                                                                                                                      \
     hipLaunchKernelGGL((mm_numeric_f64_hot<S_, S_, S_>), grid, dim3(64 * wg_waves), lds_bytes, st, descs, nblk, entries, a_data, b_data, c_out, \
-                       c_in, alpha, beta, lds_a, lds_wave, dbg, order, work);                                                   \
+                       c_in, alpha, beta, lds_a, lds_wave, dbg, order, work, norms);                                            \
     return true;
     DBCSR_AMD_HOT_SIZES(DBCSR_HOT_CASE)
 #undef DBCSR_HOT_CASE
@@ -2375,6 +2437,8 @@ struct Engine {
   FilterArgs filter = {nullptr, nullptr, 0.0f};
   int64_t flt_nblks = 0;
   DevBuf<int> order, order_cnt;
+  const void* norms_data = nullptr;  // norms64[] holds the block norms of the matrix with this data pointer (left by the numeric kernel)
+  int64_t norms_nblks = 0;
   int canonical_c = 0;  // dbcsr_amd_mm_set_canonical_product: the product matrix has symmetry, its index is in canonical form
   int wg_waves = 0;   // DBCSR_AMD_MM_WG_WAVES = 1 | 2 | 4: waves per workgroup of the one-wave-per-C-block kernels (0: by list length).  A workgroup's LDS is
                       // released when its LAST wave ends, so with product lists of uneven length fewer waves per workgroup keep
@@ -2422,6 +2486,15 @@ struct Engine {
   int dma_stages = 0;  // DBCSR_AMD_MM_KERNEL=dma2|dma3|dma4: LDS-DMA exact-size kernel with that many ring slots (0: off)
   int use_lds = 1;  // DBCSR_AMD_MM_KERNEL=direct selects the v1 kernel (A/B experiments)
 };
+
+// waves per block row for the kernels that stream whole blocks (norms, compaction): enough waves to keep the memory system busy
+static inline int row_split(int64_t nbr, int64_t nblks) {
+  if (nbr <= 0) return 1;
+  const int64_t per_row = nblks / nbr;
+  int64_t S = (65536 + nbr - 1) / nbr;
+  if (S > per_row) S = per_row;
+  return (int)std::max<int64_t>(1, std::min<int64_t>(S, 64));
+}
 
 template <typename TO>
 static int exclusive_scan(Engine* E, const int* in, int64_t n, TO* out, int64_t* total_dev, bool write_total_at_n, hipStream_t st) {
@@ -2583,21 +2656,32 @@ int dbcsr_amd_mm_symbolic_filtered(void* handle, libsmm_acc_data_t datatype, dou
   E->filter = FilterArgs{nullptr, nullptr, 0.0f};
   if (filtering) {
     if (E->a_norms.ensure((size_t)a->nblks + 1) || E->b_norms.ensure((size_t)b->nblks + 1)) return -1;
+    const int sa = row_split(nbr, a->nblks), sb = row_split(nbk, b->nblks);
     if (datatype == dbcsr_type_real_8) {
-      hipLaunchKernelGGL((bcsr_block_norms<double>), grid_for((int64_t)nbr * 64), dim3(256), 0, st, a->row_p, a->col_i, a->blk_p,
-                         static_cast<const double*>(a->data), a->row_blk_size, a->col_blk_size, nbr, 1.0, E->a_norms.p, (double*)nullptr);
-      hipLaunchKernelGGL((bcsr_block_norms<double>), grid_for((int64_t)nbk * 64), dim3(256), 0, st, b->row_p, b->col_i, b->blk_p,
-                         static_cast<const double*>(b->data), b->row_blk_size, b->col_blk_size, nbk, alpha, E->b_norms.p, (double*)nullptr);
+      hipLaunchKernelGGL((bcsr_block_norms<double>), grid_for((int64_t)nbr * sa * 64), dim3(256), 0, st, a->row_p, a->col_i, a->blk_p,
+                         static_cast<const double*>(a->data), a->row_blk_size, a->col_blk_size, nbr, sa, 1.0, E->a_norms.p, (double*)nullptr);
+      hipLaunchKernelGGL((bcsr_block_norms<double>), grid_for((int64_t)nbk * sb * 64), dim3(256), 0, st, b->row_p, b->col_i, b->blk_p,
+                         static_cast<const double*>(b->data), b->row_blk_size, b->col_blk_size, nbk, sb, alpha, E->b_norms.p, (double*)nullptr);
     } else {
-      hipLaunchKernelGGL((bcsr_block_norms<float>), grid_for((int64_t)nbr * 64), dim3(256), 0, st, a->row_p, a->col_i, a->blk_p,
-                         static_cast<const float*>(a->data), a->row_blk_size, a->col_blk_size, nbr, 1.0, E->a_norms.p, (double*)nullptr);
-      hipLaunchKernelGGL((bcsr_block_norms<float>), grid_for((int64_t)nbk * 64), dim3(256), 0, st, b->row_p, b->col_i, b->blk_p,
-                         static_cast<const float*>(b->data), b->row_blk_size, b->col_blk_size, nbk, alpha, E->b_norms.p, (double*)nullptr);
+      hipLaunchKernelGGL((bcsr_block_norms<float>), grid_for((int64_t)nbr * sa * 64), dim3(256), 0, st, a->row_p, a->col_i, a->blk_p,
+                         static_cast<const float*>(a->data), a->row_blk_size, a->col_blk_size, nbr, sa, 1.0, E->a_norms.p, (double*)nullptr);
+      hipLaunchKernelGGL((bcsr_block_norms<float>), grid_for((int64_t)nbk * sb * 64), dim3(256), 0, st, b->row_p, b->col_i, b->blk_p,
+                         static_cast<const float*>(b->data), b->row_blk_size, b->col_blk_size, nbk, sb, alpha, E->b_norms.p, (double*)nullptr);
     }
     E->filter = FilterArgs{E->a_norms.p, E->b_norms.p, (float)filter_eps};
   }
   // 2. pattern of C_out, its row prefix and row pointer
-  if (filtering)
+  // expected number of products against the number of (row, column) candidates: product-driven kernels for a sparse product
+  const double prod_est = (double)a->nblks * ((double)b->nblks / (double)std::max(nbk, 1));
+  const bool sparse_guess = E->force_symbolic == 3 || (E->force_symbolic == 0 && nbr >= 2048 && prod_est < 0.6 * (double)nbr * (double)nbc);
+  if (filtering && sparse_guess && !retain_sparsity) {
+    if (E->have_cin)
+      ACC_CHECK(hipMemcpyAsync(E->c_bm.p, E->cin_bm.p, sizeof(uint32_t) * (size_t)nbr * W, hipMemcpyDeviceToDevice, st));
+    else
+      ACC_CHECK(hipMemsetAsync(E->c_bm.p, 0, sizeof(uint32_t) * (size_t)nbr * W, st));
+    hipLaunchKernelGGL(c_bitmap_rows_filtered, grid_for((int64_t)nbr * 64), dim3(256), 0, st, a->row_p, a->col_i, b->row_p, b->col_i, nbr, W,
+                       E->canonical_c, E->filter, E->c_bm.p);
+  } else if (filtering)
     hipLaunchKernelGGL(c_bitmap_filtered, grid_for((int64_t)nbr * ((nbc + 63) / 64) * 64), dim3(256), 0, st, a->row_p, a->col_i, b->row_p,
                        E->b_bm.p, E->b_pre.p, E->have_cin ? E->cin_bm.p : (const uint32_t*)nullptr, nbr, nbc, W, (nbc + 63) / 64,
                        retain_sparsity ? 1 : 0, E->canonical_c, E->filter, E->c_bm.p);
@@ -2721,14 +2805,15 @@ int dbcsr_amd_mm_symbolic_filtered(void* handle, libsmm_acc_data_t datatype, dou
   const int nJ = (nbc + 63) / 64;
   E->grid_kernels = filtering || (((int64_t)nbr * nJ * 64 <= 256 * std::max<int64_t>(c_nblks, 1)) && !E->force_word_kernels);
   // sparse C (less than 60 % of the candidates are blocks) with enough block rows to fill the chip: product-driven kernels
-  E->rows_kernels = !filtering && (E->force_symbolic == 3 || (E->force_symbolic == 0 && nbr >= 2048 && 10 * c_nblks < 6 * (int64_t)nbr * nbc));
+  E->rows_kernels = E->force_symbolic == 3 || (E->force_symbolic == 0 && nbr >= 2048 && 10 * c_nblks < 6 * (int64_t)nbr * nbc);
   if (E->rows_kernels) {
     E->grid_kernels = false;
     ACC_CHECK(hipMemsetAsync(E->prod_cnt.p, 0, sizeof(int) * (size_t)c_nblks, st));
     hipLaunchKernelGGL(block_sizes_rows, grid_for((int64_t)nbr * W), dim3(256), 0, st, E->c_bm.p, E->c_pre.p, c_out_row_p, a->row_blk_size,
                        b->col_blk_size, nbr, W, E->blk_nze.p);
     hipLaunchKernelGGL(count_products_rows, grid_for((int64_t)nbr * 64), dim3(256), 0, st, a->row_p, a->col_i, a->row_blk_size, a->col_blk_size,
-                       b->col_blk_size, b->row_p, b->col_i, E->c_bm.p, E->c_pre.p, c_out_row_p, nbr, W, E->prod_cnt.p, E->dev_scalars.p + 3);
+                       b->col_blk_size, b->row_p, b->col_i, E->c_bm.p, E->c_pre.p, c_out_row_p, nbr, W, E->prod_cnt.p, E->dev_scalars.p + 3,
+                       E->filter);
   } else if (E->grid_kernels)
     hipLaunchKernelGGL(count_products_grid, grid_for((int64_t)nbr * nJ * 64), dim3(256), 0, st, a->row_p, a->col_i, a->row_blk_size,
                        a->col_blk_size, b->col_blk_size, E->b_bm.p, E->c_bm.p, E->c_pre.p, c_out_row_p, nbr, nbc, W, nJ,
@@ -2791,7 +2876,7 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
     if (E->tmp_i32.ensure((size_t)nblk + 1)) return -1;
     ACC_CHECK(hipMemsetAsync(E->tmp_i32.p, 0, sizeof(int) * (size_t)nblk, st));
     hipLaunchKernelGGL(fill_products_rows, grid_for((int64_t)nbr * 64), dim3(256), 0, st, a->row_p, a->col_i, a->blk_p, a->col_blk_size, b->row_p,
-                       b->col_i, b->blk_p, E->c_bm.p, E->c_pre.p, c_out->row_p, E->prod_start.p, nbr, W, E->tmp_i32.p, E->entries.p);
+                       b->col_i, b->blk_p, E->c_bm.p, E->c_pre.p, c_out->row_p, E->prod_start.p, nbr, W, E->tmp_i32.p, E->entries.p, E->filter);
     hipLaunchKernelGGL(finish_descs_rows, grid_for((int64_t)nbr * W), dim3(256), 0, st, c_in->row_p, c_in->blk_p, c_out->row_blk_size,
                        c_out->col_blk_size, E->have_cin ? E->cin_bm.p : (const uint32_t*)nullptr,
                        E->have_cin ? E->cin_pre.p : (const int*)nullptr, E->c_bm.p, E->c_pre.p, c_out->row_p, E->c_blk_p_ws.p, E->prod_start.p,
@@ -2832,6 +2917,14 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
       hipLaunchKernelGGL(build_work, grid_for(npos), dim3(256), 0, st, E->order.p, npos, E->descs.p, nblk, E->entries.p, E->work.p);
       hot_work = E->work.p;
     }
+  }
+  // a filtered multiply ends with the block filter on C's norms: the exact-size kernel leaves them behind (dbcsr_amd_bcsr_filter_count
+  // then skips its pass over C)
+  double* epi_norms = nullptr;
+  E->norms_data = nullptr;
+  if (hot_work && !E->cls_mode && E->filter.a_norms && !skip_empty) {
+    if (E->norms64.ensure((size_t)nblk + 1)) return -1;
+    epi_norms = E->norms64.p;
   }
   ACC_CHECK(hipEventRecord(E->ev[1], st));
   if (datatype == dbcsr_type_real_8) {
@@ -2920,8 +3013,14 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
                          (size_t)ww * lds_wave * sizeof(double) + (size_t)E->lds_pad, st, E->descs.p, nblk, E->entries.p,
                          static_cast<const double*>(a->data), static_cast<const double*>(b->data), static_cast<double*>(c_out->data),
                          static_cast<const double*>(c_in->data), alpha, beta, lds_a, lds_wave, E->dbg | (skip_empty ? 32 : 0), E->order.p,
-                         hot_work, ww)) {
+                         hot_work, ww, epi_norms)) {
         // launched: C blocks of the dominant size take the exact-size path, the others the generic one
+        if (epi_norms) {  // blocks of another size (tail block row / column) did not leave their norm: a pass over those only
+          hipLaunchKernelGGL(block_norms_other_sizes, grid_for(nblk * 64), dim3(256), 0, st, E->descs.p, nblk, static_cast<const double*>(c_out->data),
+                             E->hot_m, E->hot_n, epi_norms);
+          E->norms_data = c_out->data;
+          E->norms_nblks = nblk;
+        }
         snprintf(E->last_kernel, sizeof E->last_kernel, "mm_numeric_f64_hot<%d,%d,%d>", E->hot_m, E->hot_n, E->hot_k);
       } else {
       const bool pipe = E->use_pipe == 1 || (E->use_pipe < 0 && E->nproducts < 6 * nblk && E->nproducts > nblk + nblk / 2);
@@ -3130,13 +3229,18 @@ int dbcsr_amd_bcsr_filter_count(void* handle, libsmm_acc_data_t datatype, const 
     return -1;
   int64_t* dsc = reinterpret_cast<int64_t*>(E->dev_scalars.p);
   ACC_CHECK(hipMemsetAsync(dsc, 0, 16 * sizeof(int64_t), st));
+  const bool have_norms = E->norms_data != nullptr && E->norms_data == m->data && E->norms_nblks == nb && datatype == dbcsr_type_real_8;
+  E->norms_data = nullptr;
   if (nbr > 0 && nb > 0) {
-    if (datatype == dbcsr_type_real_8)
-      hipLaunchKernelGGL((bcsr_block_norms<double>), grid_for((int64_t)nbr * 64), dim3(256), 0, st, m->row_p, m->col_i, m->blk_p,
-                         static_cast<const double*>(m->data), m->row_blk_size, m->col_blk_size, nbr, 1.0, (float*)nullptr, E->norms64.p);
+    const int sm = row_split(nbr, nb);
+    if (have_norms) {
+      // left behind by the numeric kernel of the multiply that produced m
+    } else if (datatype == dbcsr_type_real_8)
+      hipLaunchKernelGGL((bcsr_block_norms<double>), grid_for((int64_t)nbr * sm * 64), dim3(256), 0, st, m->row_p, m->col_i, m->blk_p,
+                         static_cast<const double*>(m->data), m->row_blk_size, m->col_blk_size, nbr, sm, 1.0, (float*)nullptr, E->norms64.p);
     else
-      hipLaunchKernelGGL((bcsr_block_norms<float>), grid_for((int64_t)nbr * 64), dim3(256), 0, st, m->row_p, m->col_i, m->blk_p,
-                         static_cast<const float*>(m->data), m->row_blk_size, m->col_blk_size, nbr, 1.0, (float*)nullptr, E->norms64.p);
+      hipLaunchKernelGGL((bcsr_block_norms<float>), grid_for((int64_t)nbr * sm * 64), dim3(256), 0, st, m->row_p, m->col_i, m->blk_p,
+                         static_cast<const float*>(m->data), m->row_blk_size, m->col_blk_size, nbr, sm, 1.0, (float*)nullptr, E->norms64.p);
     hipLaunchKernelGGL(filter_flags, grid_for((int64_t)nbr * 64), dim3(256), 0, st, E->norms64.p, nb, m->row_p, m->col_i, m->row_blk_size,
                        m->col_blk_size, nbr, eps * eps, E->keep.p, E->blk_nze.p, E->row_nnz.p);
   }
@@ -3156,13 +3260,14 @@ int dbcsr_amd_bcsr_filter_apply(void* handle, libsmm_acc_data_t datatype, const 
   hipStream_t st = stream_of(stream);
   const int nbr = src->nblkrows;
   if (nbr == 0 || src->nblks == 0) return 0;
+  const int sc = row_split(nbr, src->nblks);
   if (datatype == dbcsr_type_real_8)
-    hipLaunchKernelGGL((filter_compact<double>), grid_for((int64_t)nbr * 64), dim3(256), 0, st, src->row_p, src->col_i, src->blk_p,
-                       static_cast<const double*>(src->data), src->row_blk_size, src->col_blk_size, nbr, E->keep.p, E->prod_start.p,
+    hipLaunchKernelGGL((filter_compact<double>), grid_for((int64_t)nbr * sc * 64), dim3(256), 0, st, src->row_p, src->col_i, src->blk_p,
+                       static_cast<const double*>(src->data), src->row_blk_size, src->col_blk_size, nbr, sc, E->keep.p, E->prod_start.p,
                        E->c_blk_p_ws.p, dst->col_i, dst->blk_p, static_cast<double*>(dst->data));
   else if (datatype == dbcsr_type_real_4)
-    hipLaunchKernelGGL((filter_compact<float>), grid_for((int64_t)nbr * 64), dim3(256), 0, st, src->row_p, src->col_i, src->blk_p,
-                       static_cast<const float*>(src->data), src->row_blk_size, src->col_blk_size, nbr, E->keep.p, E->prod_start.p,
+    hipLaunchKernelGGL((filter_compact<float>), grid_for((int64_t)nbr * sc * 64), dim3(256), 0, st, src->row_p, src->col_i, src->blk_p,
+                       static_cast<const float*>(src->data), src->row_blk_size, src->col_blk_size, nbr, sc, E->keep.p, E->prod_start.p,
                        E->c_blk_p_ws.p, dst->col_i, dst->blk_p, static_cast<float*>(dst->data));
   else
     return -10;

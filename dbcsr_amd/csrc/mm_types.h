@@ -52,7 +52,7 @@ struct Work {  // one position of the launch order: the C block's descriptor AND
   int32_t prod_cnt;  // -1: padding position (no C block)
   int16_t m, n;
   uint32_t a_lo, b_lo, w;  // the first Entry of the block (undefined when prod_cnt == 0)
-  uint32_t pad;
+  int32_t cb;              // index of the C block (order[pos])
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

@@ -194,6 +194,8 @@ class MultiplyEngine:
                                                 st.ptr)
         if rc != 0:
             raise RuntimeError("dbcsr_amd_bcsr_filter_count failed (%d)" % rc)
+        if nb.value == M.nblks:   # nothing falls below the threshold: no second copy of the matrix
+            return M
         out = DbcsrMatrix(M.row_blk_size, M.col_blk_size, row_p, torch.empty(nb.value, dtype=torch.int32, device=dev),
                           torch.empty(nb.value, dtype=torch.int64, device=dev), torch.empty(nz.value, dtype=M.dtype, device=dev), M.name)
         dst = out.desc()

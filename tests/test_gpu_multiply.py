@@ -156,8 +156,14 @@ def test_cannon_driver_single_gpu_ticks(nvirt, mode):
     assert rel_err(out.data, ref.data) <= TOL
 
 
+@pytest.mark.parametrize("symbolic", [None, "rows", "word"])
 @pytest.mark.parametrize("eps,retain,alpha", [(2.0, False, 1.0), (40.0, False, 0.5), (60.0, True, 1.0), (1e-30, False, 1.0)])
-def test_filter_eps_matches_oracle(eps, retain, alpha):
+def test_filter_eps_matches_oracle(eps, retain, alpha, symbolic, monkeypatch):
+    # (symbolic: the product-driven / per-word kernel families forced; None = the automatic choice)
+    if symbolic:
+        monkeypatch.setenv("DBCSR_AMD_MM_SYMBOLIC", symbolic)
+    else:
+        monkeypatch.delenv("DBCSR_AMD_MM_SYMBOLIC", raising=False)
     # on-the-fly product filter + final block filter (CP2K's linear-scaling mode); eps chosen so that a good part
     # of the products / blocks is actually dropped (U(0,1) 13..23-blocks have squared norms of ~50..180)
     A, B, Cm = O.perf_case(300, 280, 290, 0.5, 0.5, 0.6, [1, 13, 1, 23], [1, 23, 1, 5], [1, 13, 1, 7])
@@ -174,7 +180,7 @@ def test_filter_eps_matches_oracle(eps, retain, alpha):
         assert info["nproducts"] < info_full["nproducts"]  # the filter really removed products
     dA, dB, dC = to_dev(A), to_dev(B), to_dev(Cm)
     flop = [0]
-    dbcsr_multiply("N", "N", alpha, dA, dB, 1.0, dC, retain_sparsity=retain, filter_eps=eps, flop=flop)
+    dbcsr_multiply("N", "N", alpha, dA, dB, 1.0, dC, retain_sparsity=retain, filter_eps=eps, flop=flop, engine=MultiplyEngine())
     torch.cuda.synchronize()
     out = dev_to_bcsr(dC)
     assert np.array_equal(out.row_p, ref.row_p) and np.array_equal(out.col_i, ref.col_i) and np.array_equal(out.blk_p, ref.blk_p)
@@ -337,3 +343,28 @@ def test_symmetric_product_is_the_triangle_of_the_full_product(symm):
     assert S.data.size == want.size and rel_err(S.data, want) <= 1e-10
     nb = len(F.row_sizes)
     assert abs(c_sym.flop / c_full.flop - 0.5) < 1.5 / nb + 0.01   # half the products (the diagonal blocks are computed once in both)
+
+
+def test_filtered_sparse_product_takes_the_product_driven_kernels():
+    """CP2K's linear-scaling regime: sparse operands AND filter_eps.  At 4096 block rows and 1 % fill the automatic choice must be the
+    product-driven symbolic kernels (also for the filtered C pattern), with the same result as the candidate-driven ones."""
+    from dbcsr_amd.randmat import perf_matrices
+    res = {}
+    for symbolic in ("grid", None):
+        if symbolic:
+            os.environ["DBCSR_AMD_MM_SYMBOLIC"] = symbolic
+        else:
+            os.environ.pop("DBCSR_AMD_MM_SYMBOLIC", None)
+        try:
+            E = MultiplyEngine()
+            A, B, Cm = perf_matrices(4096 * 5, 4096 * 5, 4096 * 5, (0.99, 0.99, 0.99), [1, 5], [1, 5], [1, 5], dtype=torch.float64, engine=E)
+            flop = [0]
+            dbcsr_multiply("N", "N", 1.0, A, B, 1.0, Cm, filter_eps=3.0, flop=flop, engine=E)
+            torch.cuda.synchronize()
+            res[symbolic] = (dev_to_bcsr(Cm), flop[0])
+        finally:
+            os.environ.pop("DBCSR_AMD_MM_SYMBOLIC", None)
+    (g, fg), (r, fr) = res["grid"], res[None]
+    assert fg == fr and np.array_equal(g.row_p, r.row_p) and np.array_equal(g.col_i, r.col_i)
+    assert rel_err(r.data, g.data) <= 1e-12
+    assert 0 < r.nblks
