@@ -2364,6 +2364,31 @@ __global__ void __launch_bounds__(256) block_norms_other_sizes(const Desc* __res
   if (lane == 0) norms[cb] = ss;
 }
 
+// the same for a multiply of mixed sizes: the blocks whose (m, n) class had no run-time compiled kernel (class 9 = other sizes, or hiprtc failed)
+struct ClassSet {
+  int m[3], n[3], jit_mask;
+};
+__global__ void __launch_bounds__(256) block_norms_unserved_classes(const Desc* __restrict__ descs, int64_t nblk, const double* __restrict__ c_data,
+                                                                    ClassSet cs, double* __restrict__ norms) {
+  const int lane = threadIdx.x & 63;
+  const int64_t cb = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (cb >= nblk) return;
+  const Desc d = descs[cb];
+  int rm = 3, rn = 3;
+#pragma unroll
+  for (int q = 2; q >= 0; --q) {
+    if (cs.m[q] > 0 && d.m == cs.m[q]) rm = q;
+    if (cs.n[q] > 0 && d.n == cs.n[q]) rn = q;
+  }
+  if (rm < 3 && rn < 3 && ((cs.jit_mask >> (3 * rm + rn)) & 1)) return;  // its class kernel wrote the norm
+  const double* x = c_data + d.c_off;
+  double ss = 0.0;
+  for (int e = lane; e < d.m * d.n; e += 64) ss += x[e] * x[e];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) ss += __shfl_down(ss, off, 64);
+  if (lane == 0) norms[cb] = ss;
+}
+
 static bool launch_hot_f64(int m, int n, int k, dim3 grid, size_t lds_bytes, hipStream_t st, const Desc* descs, int64_t nblk,
                            const Entry* entries, const double* a_data, const double* b_data, double* c_out, const double* c_in,
                            double alpha, double beta, int lds_a, int lds_wave, int dbg, const int* order, const Work* work, int wg_waves,
@@ -2922,7 +2947,7 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
   // then skips its pass over C)
   double* epi_norms = nullptr;
   E->norms_data = nullptr;
-  if (hot_work && !E->cls_mode && E->filter.a_norms && !skip_empty) {
+  if ((hot_work || (E->cls_mode && E->class_g == 1)) && datatype == dbcsr_type_real_8 && E->filter.a_norms && !skip_empty) {
     if (E->norms64.ensure((size_t)nblk + 1)) return -1;
     epi_norms = E->norms64.p;
   }
@@ -2945,7 +2970,7 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
       const int g_lds_wave = g_lds_a + g_lds_b;
       const int g_maxt = (std::max(E->max_m, E->max_n) + 7) / 8;
       const int dbgv = E->dbg | (skip_empty ? 32 : 0);
-      int njit = 0, ngen = 0;
+      int njit = 0, ngen = 0, jit_mask = 0;
       for (int c = 0; c < kNumClasses; ++c) {
         if (E->cls_len[c] == 0) continue;
         const int* ord = E->order.p + E->cls_off[c];
@@ -2963,7 +2988,9 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
           double p_alpha = alpha, p_beta = beta;
           int p_skip = skip_empty;
           const Work* p_work = hot_work ? hot_work + E->cls_off[c] : nullptr;
-          void* args[] = {&p_descs, &p_nblk, &p_entries, &p_a, &p_b, &p_c, &p_ci, &p_alpha, &p_beta, &p_skip, &ord, &p_work};
+          double* p_norms = epi_norms;
+          void* args[] = {&p_descs, &p_nblk, &p_entries, &p_a, &p_b, &p_c, &p_ci, &p_alpha, &p_beta, &p_skip, &ord, &p_work, &p_norms};
+          jit_mask |= 1 << c;
           const unsigned cw = E->class_g == 1 ? (unsigned)ww : 4u;  // waves per workgroup (the G-block stream body keeps 4)
           ACC_CHECK(hipModuleLaunchKernel(ck.fn, (unsigned)(8 * E->cls_len[c]) / cw / (unsigned)E->class_g, 1, 1, 64 * cw, 1, 1,
                                           (unsigned)(cw * ck.wave_lds), st, args, nullptr));
@@ -2983,6 +3010,15 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
 #undef DBCSR_LAUNCH_G
           ++ngen;
         }
+      }
+      if (epi_norms) {  // the blocks the generic kernel handled did not leave their norm
+        ClassSet cs;
+        for (int q = 0; q < 3; ++q) cs.m[q] = E->cls_m[q], cs.n[q] = E->cls_n[q];
+        cs.jit_mask = jit_mask;
+        hipLaunchKernelGGL(block_norms_unserved_classes, grid_for(nblk * 64), dim3(256), 0, st, E->descs.p, nblk,
+                           static_cast<const double*>(c_out->data), cs, epi_norms);
+        E->norms_data = c_out->data;
+        E->norms_nblks = nblk;
       }
       snprintf(E->last_kernel, sizeof E->last_kernel, "mm_numeric_f64_class[%d jit + %d generic launches; m {%d,%d,%d} n {%d,%d,%d} k {%d,%d,%d}]", njit,
                ngen, E->cls_m[0], E->cls_m[1], E->cls_m[2], E->cls_n[0], E->cls_n[1], E->cls_n[2], E->cls_k[0], E->cls_k[1], E->cls_k[2]);

@@ -110,7 +110,7 @@ __device__ __forceinline__ void cblock_f64_classes(const Desc& d, const Entry fi
                                                    const double* __restrict__ a_data,
                                                    const double* __restrict__ b_data, double* __restrict__ c_out,
                                                    const double* __restrict__ c_in, double alpha, double beta, const LaneMap& L, int lane,
-                                                   char* lds) {
+                                                   char* lds, double* __restrict__ norm_out) {
   typedef ClassShape<M, N, K0, K1, K2> CS;
   constexpr int MA = CS::MA, NC = CS::NC;
   constexpr int AP = Pitch<M>::P;
@@ -285,6 +285,7 @@ __device__ __forceinline__ void cblock_f64_classes(const Desc& d, const Entry fi
       const f64x2 w = __builtin_bit_cast(f64x2, ci[c]);
       v[0] += beta * w[0];
       v[1] += beta * w[1];
+      if (norm_out) *reinterpret_cast<f64x2*>(lds + c * 1024 + voff) = v;  // (the final values, for the norm below)
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsc, voff, c * 1024, 2);
     }
   } else {
@@ -294,6 +295,20 @@ __device__ __forceinline__ void cblock_f64_classes(const Desc& d, const Entry fi
       __builtin_amdgcn_raw_buffer_store_b128(v, rsc, voff, c * 1024, 2);
     }
   }
+  // squared Frobenius norm of the stored block for the final filter of a filtered multiply (the block is still in LDS)
+  if (norm_out) {
+    double ss = 0.0;
+#pragma unroll
+    for (int c = 0; c < CC; ++c) {
+      const f64x2 v = *reinterpret_cast<const f64x2*>(lds + c * 1024 + voff);
+      const int idx = c * 128 + 2 * lane;
+      if (idx < M * N) ss += v[0] * v[0];
+      if (idx + 1 < M * N) ss += v[1] * v[1];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_down(ss, off, 64);
+    if (lane == 0) *norm_out = ss;
+  }
 }
 
 // one wave per C block; order[] holds the class's segment (per-XCD streams padded with -1, as for the other kernels)
@@ -301,7 +316,8 @@ template <int M, int N, int K0, int K1, int K2>
 __device__ __forceinline__ void mm_class_kernel_body(const Desc* __restrict__ descs, int64_t nblk, const Entry* __restrict__ entries,
                                                      const double* __restrict__ a_data, const double* __restrict__ b_data,
                                                      double* __restrict__ c_out, const double* __restrict__ c_in, double alpha, double beta,
-                                                     int skip_empty, const int* __restrict__ order, const Work* __restrict__ work, char* smem) {
+                                                     int skip_empty, const int* __restrict__ order, const Work* __restrict__ work,
+                                                     double* __restrict__ norms, char* smem) {
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
@@ -309,9 +325,11 @@ __device__ __forceinline__ void mm_class_kernel_body(const Desc* __restrict__ de
   Desc d;
   Entry first = Entry::make(0, 0, 0);
   bool have_first = false;
+  int64_t cbi = 0;
   if (work) {  // launch-order records: descriptor and first product in one read
     const Work w = work[pos];
     if (w.prod_cnt < 0) return;
+    cbi = w.cb;
     d.c_off = w.c_off, d.cin_off = w.cin_off, d.prod_start = w.prod_start, d.prod_cnt = w.prod_cnt, d.m = w.m, d.n = w.n;
     first.a_lo = w.a_lo, first.b_lo = w.b_lo, first.w = w.w;
     have_first = w.prod_cnt > 0;
@@ -319,11 +337,12 @@ __device__ __forceinline__ void mm_class_kernel_body(const Desc* __restrict__ de
     const int64_t cb = order[pos];
     if (cb < 0 || cb >= nblk) return;
     d = descs[cb];
+    cbi = cb;
   }
   if (skip_empty && d.prod_cnt == 0) return;
   const LaneMap L(lane);
   cblock_f64_classes<M, N, K0, K1, K2>(d, first, have_first, entries, a_data, b_data, c_out, c_in, alpha, beta, L, lane,
-                                       smem + (size_t)wid * ClassShape<M, N, K0, K1, K2>::WAVE_LDS);
+                                       smem + (size_t)wid * ClassShape<M, N, K0, K1, K2>::WAVE_LDS, norms ? norms + cbi : nullptr);
 }
 
 
@@ -582,14 +601,14 @@ extern "C" __global__ void __launch_bounds__(256, DBCSR_AMD_JIT_MINW)  // second
     mm_numeric_f64_class(const dbcsr_amd::Desc* __restrict__ descs, long nblk, const dbcsr_amd::Entry* __restrict__ entries,
                          const double* __restrict__ a_data, const double* __restrict__ b_data, double* __restrict__ c_out,
                          const double* __restrict__ c_in, double alpha, double beta, int skip_empty, const int* __restrict__ order,
-                         const dbcsr_amd::Work* __restrict__ work) {
+                         const dbcsr_amd::Work* __restrict__ work, double* __restrict__ norms) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
 #if defined(DBCSR_AMD_JIT_G) && DBCSR_AMD_JIT_G > 1
   dbcsr_amd::mm_class_stream_body<DBCSR_AMD_JIT_M, DBCSR_AMD_JIT_N, DBCSR_AMD_JIT_K0, DBCSR_AMD_JIT_K1, DBCSR_AMD_JIT_K2, DBCSR_AMD_JIT_G>(
       descs, nblk, entries, a_data, b_data, c_out, c_in, alpha, beta, skip_empty, order, smem);
 #else
   dbcsr_amd::mm_class_kernel_body<DBCSR_AMD_JIT_M, DBCSR_AMD_JIT_N, DBCSR_AMD_JIT_K0, DBCSR_AMD_JIT_K1, DBCSR_AMD_JIT_K2>(
-      descs, nblk, entries, a_data, b_data, c_out, c_in, alpha, beta, skip_empty, order, work, smem);
+      descs, nblk, entries, a_data, b_data, c_out, c_in, alpha, beta, skip_empty, order, work, norms, smem);
 #endif
 }
 #endif
