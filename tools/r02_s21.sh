@@ -1,5 +1,7 @@
 #!/bin/bash
-# A/B on ONE box after the scratch fix: library of commit a23725e against the current one
+# A/B on ONE box after the scratch fix: library of commit a23725e against the current one.
+# The old tree is made first (it is not kept in the repository):
+#   mkdir -p _ab/old && git archive a23725e dbcsr_amd bench.py include oracle/__init__.py oracle/oracle.py | tar -x -C _ab/old && make -C _ab/old/dbcsr_amd/csrc
 set -u
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 R=$PWD; O=$R/gpurun_out/s21; mkdir -p $O
