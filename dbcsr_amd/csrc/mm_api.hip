@@ -345,6 +345,19 @@ int dbcsr_amd_multiply(void* handle, char transa, char transb, libsmm_acc_data_t
   return 0;
 }
 
+int dbcsr_amd_bcsr_desymmetrized(void* handle, libsmm_acc_data_t datatype, const dbcsr_amd_bcsr* src, int antisymmetric, dbcsr_amd_bcsr* dst,
+                                 void* stream) {
+  if (!handle || !src || !dst) return -1;
+  if (datatype != dbcsr_type_real_8 && datatype != dbcsr_type_real_4) return -10;
+  Owned full;
+  int rc = twin(handle, datatype, src, 0, antisymmetric, full, stream);
+  if (rc == 0 && hipStreamSynchronize(stream_of(stream)) != hipSuccess) rc = -1;
+  if (rc) return rc;
+  *dst = full.m;
+  full.live = false;  // the caller releases it (dbcsr_amd_bcsr_release)
+  return 0;
+}
+
 int dbcsr_amd_multiply_symmetric_c(void* handle, char transa, char transb, libsmm_acc_data_t datatype, double alpha,
                                    const dbcsr_amd_bcsr* matrix_a, const dbcsr_amd_bcsr* matrix_b, double beta, const dbcsr_amd_bcsr* matrix_c,
                                    int antisymmetric, int retain_sparsity, double filter_eps, dbcsr_amd_bcsr* c_out, int64_t* flop, void* stream) {

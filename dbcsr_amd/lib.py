@@ -33,6 +33,7 @@ MM_SYMBOLS = [
     "dbcsr_amd_bcsr_crop_count", "dbcsr_amd_bcsr_crop_apply", "dbcsr_amd_bcsr_scale_window",
     "dbcsr_amd_multiply", "dbcsr_amd_bcsr_release", "dbcsr_amd_bcsr_desymmetrize_count", "dbcsr_amd_bcsr_desymmetrize_apply",
     "dbcsr_amd_bcsr_twin_count", "dbcsr_amd_bcsr_twin_apply", "dbcsr_amd_mm_set_canonical_product", "dbcsr_amd_multiply_symmetric_c",
+    "dbcsr_amd_bcsr_desymmetrized",
 ]
 
 
@@ -137,6 +138,7 @@ def load_library():
     L.dbcsr_amd_bcsr_twin_count.argtypes = [vp, BP, i32, vp, C.POINTER(i64), C.POINTER(i64), vp]
     L.dbcsr_amd_bcsr_twin_apply.argtypes = [vp, i32, BP, i32, i32, BP, vp]
     L.dbcsr_amd_mm_set_canonical_product.argtypes = [vp, i32]
+    L.dbcsr_amd_bcsr_desymmetrized.argtypes = [vp, i32, BP, i32, BP, vp]
     L.dbcsr_amd_multiply_symmetric_c.argtypes = [vp, C.c_char, C.c_char, i32, C.c_double, BP, BP, C.c_double, BP, i32, i32, C.c_double, BP,
                                                  C.POINTER(i64), vp]
     L.dbcsr_amd_mm_stats.argtypes = [vp, C.POINTER(MnkStat), i32, C.POINTER(i32), vp]

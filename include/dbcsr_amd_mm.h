@@ -180,6 +180,9 @@ int dbcsr_amd_bcsr_desymmetrize_apply(void* handle, libsmm_acc_data_t datatype, 
  *     blocks that are not stored in canonical form (blocks of C_in are kept wherever they are); 0 switches it off again.
  *   dbcsr_amd_multiply_symmetric_c: the whole sequence in one call; matrix_c and c_out hold the stored triangle (row <= column),
  *     no limits (the reference's own tests run symmetric products with full limits only, tests/dbcsr_test_multiply.F:196-200). */
+/* desymmetrize in one call: dst's arrays are allocated by the library (dbcsr_amd_bcsr_release frees them), size arrays borrowed from src */
+int dbcsr_amd_bcsr_desymmetrized(void* handle, libsmm_acc_data_t datatype, const dbcsr_amd_bcsr* src, int antisymmetric, dbcsr_amd_bcsr* dst,
+  void* stream);
 int dbcsr_amd_bcsr_twin_count(void* handle, const dbcsr_amd_bcsr* src, int mode, int32_t* dst_row_p, int64_t* nblks, int64_t* nze, void* stream);
 int dbcsr_amd_bcsr_twin_apply(void* handle, libsmm_acc_data_t datatype, const dbcsr_amd_bcsr* src, int mode, int antisymmetric,
   dbcsr_amd_bcsr* dst, void* stream);

@@ -106,13 +106,17 @@ def test_reference_perf_driver_through_resident_engine(name, tmp_path):
 
 
 @needs_resident
-@pytest.mark.parametrize("name", R.names(lambda p: p["values"] and R.nonsymmetric(p)))
+@pytest.mark.parametrize("name", R.names(lambda p: p["values"] and p.get("data_type", 3) == 3))
 def test_dump_driver_through_resident_engine(name):
+    """every double-precision case of the reference dumps -- symmetric / antisymmetric operands and product matrices included --
+    through the patched host: dbcsr_multiply hands the multiply to the device-resident engine"""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import base64
     import make_ref_fixtures as F
     ref = R.RefResult(name)
-    got = F.run_case(ref.params, exe=os.path.join(HOST_RES, "dbcsr_ref_dump"), env={"OMP_NUM_THREADS": "4", "DBCSR_AMD_RESIDENT": "1"})
+    got, stdout = F.run_case(ref.params, exe=os.path.join(HOST_RES, "dbcsr_ref_dump"), env={"OMP_NUM_THREADS": "4", "DBCSR_AMD_RESIDENT": "1v"},
+                             with_stdout=True)
+    assert "dbcsr_amd_resident:" in stdout, "the multiply did not take the device-resident path:\n" + stdout[-1500:]
     assert got["nblks"] == ref.nblks and got["flop"] == ref.flop
     assert np.array_equal(np.asarray(got["row"]) - 1, ref.rows) and np.array_equal(np.asarray(got["col"], np.int32) - 1, ref.col_i)
     data = np.frombuffer(base64.b64decode(got["values_b64"]), "<f8") if ref.nblks else np.zeros(0)

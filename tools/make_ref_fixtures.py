@@ -131,7 +131,7 @@ def parse_dump(path):
     return out
 
 
-def run_case(c, exe=DUMP, env=None):
+def run_case(c, exe=DUMP, env=None, with_stdout=False):
     with tempfile.TemporaryDirectory() as td:
         nml, out = os.path.join(td, "case.nml"), os.path.join(td, "out.txt")
         write_nml(c, nml)
@@ -140,7 +140,7 @@ def run_case(c, exe=DUMP, env=None):
         r = subprocess.run([exe, nml, out], cwd=td, env=e, capture_output=True, text=True, timeout=600)
         if r.returncode != 0 or not os.path.exists(out):
             raise RuntimeError("dbcsr_ref_dump failed on %s:\n%s\n%s" % (c["name"], r.stdout[-2000:], r.stderr[-2000:]))
-        return parse_dump(out)
+        return (parse_dump(out), r.stdout) if with_stdout else parse_dump(out)
 
 
 def main():
