@@ -122,3 +122,16 @@ def test_dump_driver_through_resident_engine(name):
     data = np.frombuffer(base64.b64decode(got["values_b64"]), "<f8") if ref.nblks else np.zeros(0)
     scale = max(np.max(np.abs(ref.data)), 1e-300) if ref.nblks else 1.0
     assert data.size == ref.data.size and np.max(np.abs(data - ref.data), initial=0.0) <= (5e-6 if R.np_dtype(ref.params) == np.float32 else 1e-10) * scale
+
+
+@needs_resident
+@pytest.mark.parametrize("prog", ["dbcsr_unittest1", "dbcsr_unittest3"])
+def test_reference_unittests_through_resident_engine(prog, tmp_path):
+    """the reference's own multiply unit tests (all symmetry / transposition / limit / type combinations of tests/dbcsr_test_multiply.F) on the
+    patched host: what the glue accepts (real(8), with or without symmetry) runs on the device-resident engine, the rest falls through
+    to the reference path; the program checks every result against its dense computation itself."""
+    r = subprocess.run([os.path.join(HOST_RES, prog)], cwd=tmp_path, env=dict(ENV_RES, DBCSR_AMD_RESIDENT="1v"), capture_output=True, text=True,
+                       timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "ERROR" not in r.stdout.upper().replace("ERROR_TOLERANCE", "") or "PASSED" in r.stdout.upper(), r.stdout[-3000:]
+    assert r.stdout.count("dbcsr_amd_resident:") > 10, "hardly any multiply took the device-resident path"
