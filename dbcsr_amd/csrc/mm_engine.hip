@@ -2646,6 +2646,7 @@ int dbcsr_amd_mm_symbolic_filtered(void* handle, libsmm_acc_data_t datatype, dou
   E->nbr = nbr;
   E->W = W;
   E->retain = retain_sparsity != 0;
+  E->norms_data = nullptr;  // block norms left by an earlier numeric phase belong to that product only
   E->have_cin = c_in->nblks > 0;
   if (E->b_bm.ensure((size_t)nbk * W + 1) || E->b_pre.ensure((size_t)nbk * W + 1) || E->c_bm.ensure((size_t)nbr * W + 1) ||
       E->c_pre.ensure((size_t)nbr * W + 1) || E->row_nnz.ensure((size_t)nbr + 1) || E->dev_scalars.ensure(16))
@@ -2947,7 +2948,7 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
   // then skips its pass over C)
   double* epi_norms = nullptr;
   E->norms_data = nullptr;
-  if ((hot_work || (E->cls_mode && E->class_g == 1)) && datatype == dbcsr_type_real_8 && E->filter.a_norms && !skip_empty) {
+  if ((hot_work || (E->cls_mode && E->class_g == 1)) && datatype == dbcsr_type_real_8 && E->filter.a_norms && !skip_empty && !E->retain) {
     if (E->norms64.ensure((size_t)nblk + 1)) return -1;
     epi_norms = E->norms64.p;
   }
