@@ -106,9 +106,9 @@ def test_reference_perf_driver_through_resident_engine(name, tmp_path):
 
 
 @needs_resident
-@pytest.mark.parametrize("name", R.names(lambda p: p["values"] and p.get("data_type", 3) == 3))
+@pytest.mark.parametrize("name", R.names(lambda p: p["values"]))
 def test_dump_driver_through_resident_engine(name):
-    """every double-precision case of the reference dumps -- symmetric / antisymmetric operands and product matrices included --
+    """every case of the reference dumps -- single precision, symmetric / antisymmetric operands and product matrices included --
     through the patched host: dbcsr_multiply hands the multiply to the device-resident engine"""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import base64
