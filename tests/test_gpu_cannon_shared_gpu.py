@@ -2,7 +2,7 @@
 host-staged debug transport -- RCCL does not allow two ranks on one device), every rank multiplies its tiles with the
 real kernels, rank 0 compares the gathered C with the CPU oracle's global multiply (tools/run_dist_check.py).
 Covers what the gloo CPU tests cannot: the HIP engine's symbolic / init_c / in-place accumulate path under N > 1,
-with both schedules, and (``+dist``) distributed input whose blocks start in HBM on arbitrary ranks: packing, exchange and
+with both schedules (also on eight ranks: the 4 x 2 grid of BASELINE's 8-GPU configurations, two A images per rank), and (``+dist``) distributed input whose blocks start in HBM on arbitrary ranks: packing, exchange and
 sorting of make_images (cannon.redistribute) on the device."""
 import os
 import socket
@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,mode", [(2, "gather"), (2, "ticks"), (4, "ticks"), (4, "gather"), (4, "ticks+dist"), (2, "gather+dist"), (4, "gather+filter"), (2, "ticks+filter")])
+@pytest.mark.parametrize("world,mode", [(2, "gather"), (2, "ticks"), (4, "ticks"), (4, "gather"), (4, "ticks+dist"), (2, "gather+dist"), (4, "gather+filter"), (2, "ticks+filter"), (8, "ticks"), (8, "gather+dist")])
 def test_cannon_hip_engine_ranks_share_one_gpu(world, mode):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
