@@ -140,6 +140,9 @@ Pool g_dev_pool{false}, g_host_pool{true};
 }
 
 namespace dbcsr_amd {
+hipError_t pool_malloc(void** p, size_t nbytes) { return g_dev_pool.allocate(p, nbytes); }
+hipError_t pool_free(void* p) { return p ? g_dev_pool.deallocate(p) : hipSuccess; }
+
 // Last-error bookkeeping: the reference prints and returns -1 (acc_error.cpp);
 // the Fortran host then aborts.  We do the same but never exit() from the
 // library.

@@ -13,6 +13,11 @@ int check(hipError_t e, const char* what, const char* file, int line);
 // include/dbcsr_acc.h); NULL means the null stream.
 static inline hipStream_t stream_of(void* handle) { return handle ? *static_cast<hipStream_t*>(handle) : (hipStream_t)0; }
 
+// device memory through the caching allocator of the acc runtime (acc_runtime.hip): what c_dbcsr_acc_dev_mem_allocate / _deallocate
+// use, for the matrices the library itself hands out (dbcsr_amd_multiply's result and temporaries)
+hipError_t pool_malloc(void** p, size_t nbytes);
+hipError_t pool_free(void* p);
+
 }  // namespace dbcsr_amd
 
 #define ACC_CHECK(call)                                                        \

@@ -5,7 +5,7 @@
 // (k, columns) in make_m2s, dbcsr_mm_cannon.F:194-214; beta acts on the window of C only), retain_sparsity, filter_eps
 // (on-the-fly product filter + final block filter, dbcsr_mm_multrec.F:373-383) -- written on top of the primitives of
 // dbcsr_amd_mm.h, so that a Fortran / C host needs one binding instead of re-implementing the sequence.  The Python
-// mirror dbcsr_amd/multiply.py does the same with torch tensors as storage; here storage comes from hipMalloc and the
+// mirror dbcsr_amd/multiply.py does the same with torch tensors as storage; here storage comes from the library's caching device allocator and the
 // result is handed to the caller (dbcsr_amd_bcsr_release frees it).
 #include <hip/hip_runtime.h>
 
@@ -36,10 +36,10 @@ struct Owned {
   }
   void release() {
     if (!live) return;
-    (void)hipFree(m.row_p);
-    (void)hipFree(m.col_i);
-    (void)hipFree(m.blk_p);
-    (void)hipFree(m.data);
+    (void)pool_free(m.row_p);
+    (void)pool_free(m.col_i);
+    (void)pool_free(m.blk_p);
+    (void)pool_free(m.data);
     m.row_p = m.col_i = nullptr;
     m.blk_p = nullptr;
     m.data = nullptr;
@@ -57,16 +57,16 @@ int alloc_arrays(Owned& o, int nbr, int nbc, const int32_t* rs, const int32_t* c
   o.m.col_blk_size = cs;
   o.m.nblks = nblks;
   o.live = true;
-  if (with_row_p && hipMalloc(reinterpret_cast<void**>(&o.m.row_p), sizeof(int32_t) * ((size_t)nbr + 1)) != hipSuccess) return -1;
-  if (hipMalloc(reinterpret_cast<void**>(&o.m.col_i), sizeof(int32_t) * (size_t)(nblks > 0 ? nblks : 1)) != hipSuccess) return -1;
-  if (hipMalloc(reinterpret_cast<void**>(&o.m.blk_p), sizeof(int64_t) * (size_t)(nblks > 0 ? nblks : 1)) != hipSuccess) return -1;
-  if (hipMalloc(&o.m.data, esz * (size_t)(nze > 0 ? nze : 1)) != hipSuccess) return -1;
+  if (with_row_p && pool_malloc(reinterpret_cast<void**>(&o.m.row_p), sizeof(int32_t) * ((size_t)nbr + 1)) != hipSuccess) return -1;
+  if (pool_malloc(reinterpret_cast<void**>(&o.m.col_i), sizeof(int32_t) * (size_t)(nblks > 0 ? nblks : 1)) != hipSuccess) return -1;
+  if (pool_malloc(reinterpret_cast<void**>(&o.m.blk_p), sizeof(int64_t) * (size_t)(nblks > 0 ? nblks : 1)) != hipSuccess) return -1;
+  if (pool_malloc(&o.m.data, esz * (size_t)(nze > 0 ? nze : 1)) != hipSuccess) return -1;
   return 0;
 }
 
 int alloc_row_p(Owned& o, int nbr) {
   o.live = true;
-  return hipMalloc(reinterpret_cast<void**>(&o.m.row_p), sizeof(int32_t) * ((size_t)nbr + 1)) == hipSuccess ? 0 : -1;
+  return pool_malloc(reinterpret_cast<void**>(&o.m.row_p), sizeof(int32_t) * ((size_t)nbr + 1)) == hipSuccess ? 0 : -1;
 }
 
 // copy of src restricted to a window (negative bound = unbounded); also the way to learn nblks / nze of a matrix
@@ -217,10 +217,10 @@ extern "C" {
 
 int dbcsr_amd_bcsr_release(dbcsr_amd_bcsr* m) {
   if (!m) return -1;
-  (void)hipFree(m->row_p);
-  (void)hipFree(m->col_i);
-  (void)hipFree(m->blk_p);
-  (void)hipFree(m->data);
+  (void)pool_free(m->row_p);
+  (void)pool_free(m->col_i);
+  (void)pool_free(m->blk_p);
+  (void)pool_free(m->data);
   m->row_p = m->col_i = nullptr;
   m->blk_p = nullptr;
   m->data = nullptr;

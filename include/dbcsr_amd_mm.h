@@ -146,7 +146,7 @@ int dbcsr_amd_bcsr_fill_random_dist(void* handle, libsmm_acc_data_t datatype, co
  * transa/transb 'N' | 'T' | 'C' (real data: 'C' == 'T'); limits = {first_row, last_row, first_column, last_column, first_k,
  * last_k}, 1-based inclusive full-matrix indices, 0 = not given, NULL = no limits (inside the window beta scales C, outside it C
  * is unchanged); retain_sparsity and filter_eps as in the reference.  c_out: row_p / col_i / blk_p / data are allocated by the
- * library (hipMalloc) and belong to the caller afterwards -- dbcsr_amd_bcsr_release frees them; the size arrays are borrowed
+ * library (its caching device allocator) and belong to the caller afterwards -- ONLY dbcsr_amd_bcsr_release frees them; the size arrays are borrowed
  * from matrix_c.  *flop (may be NULL) receives the reference's flop count.  Returns when the result is complete. */
 int dbcsr_amd_multiply(void* handle, char transa, char transb, libsmm_acc_data_t datatype, double alpha, const dbcsr_amd_bcsr* matrix_a,
   const dbcsr_amd_bcsr* matrix_b, double beta, const dbcsr_amd_bcsr* matrix_c, const int64_t* limits, int retain_sparsity,
