@@ -916,6 +916,7 @@ __device__ __forceinline__ void cblock_f64_lds(const Desc& d, const Entry* __res
 #pragma unroll
       for (int c = 0; c < CA; ++c)
         if (c < nca) *reinterpret_cast<u32x4*>(lds_a + c * 1024 + voff) = ra[c];
+      DBCSR_AMD_LDS_ORDER();
 #pragma unroll
       for (int c = 0; c < CB; ++c)
         if (c < ncb) *reinterpret_cast<u32x4*>(lds_b + c * 1024 + voff) = rb[c];
@@ -1016,6 +1017,7 @@ __device__ __forceinline__ void cblock_f64_exact(const Desc& d, const Entry firs
     if (!(dbg & 4)) {
 #pragma unroll
       for (int c = 0; c < CA; ++c) *reinterpret_cast<u32x4*>(lds_a + c * 1024 + voff) = ra[c];
+      DBCSR_AMD_LDS_ORDER();
 #pragma unroll
       for (int c = 0; c < CB; ++c) *reinterpret_cast<u32x4*>(lds_b + c * 1024 + voff) = rb[c];
     }
@@ -1355,6 +1357,7 @@ __global__ void __launch_bounds__(256) mm_numeric_f64_pipe(const Desc* __restric
 #pragma unroll
       for (int c = 0; c < CMAX; ++c)
         if (c < nca) *reinterpret_cast<u32x4*>(X.lds_a + c * 1024 + X.voff) = ra[c];
+      DBCSR_AMD_LDS_ORDER();
 #pragma unroll
       for (int c = 0; c < CMAX; ++c)
         if (c < ncb) *reinterpret_cast<u32x4*>(X.lds_b + c * 1024 + X.voff) = rb[c];

@@ -190,6 +190,7 @@ __device__ __forceinline__ void cblock_f64_classes(const Desc& d, const Entry fi
 #pragma unroll
     for (int c = 0; c < CS::CAMAX; ++c)
       if (DBCSR_EXACT_ALL_PIECES || c < nca) *reinterpret_cast<u32x4*>(lds_a + staged_offset<M>(c, lane)) = ra[c];
+    DBCSR_AMD_LDS_ORDER();
     // B's columns have ks elements: padded pitch when ks is a multiple of 16 (then ks is 16 or 32 and divides 128)
     const int sh = __builtin_amdgcn_readfirstlane((ks & 15) == 0 ? (ks == 16 ? 4 : 5) : 31);
 #pragma unroll
@@ -440,6 +441,7 @@ __device__ __forceinline__ void mm_class_stream_body(const Desc* __restrict__ de
   auto store = [&](int ks) {
 #pragma unroll
     for (int c = 0; c < CS::CAMAX; ++c) *reinterpret_cast<u32x4*>(lds_a + staged_offset<M>(c, lane)) = ra[c];
+    DBCSR_AMD_LDS_ORDER();
     const int sh = __builtin_amdgcn_readfirstlane((ks & 15) == 0 ? (ks == 16 ? 4 : 5) : 31);
 #pragma unroll
     for (int c = 0; c < CS::CBMAX; ++c) *reinterpret_cast<u32x4*>(lds_b + c * 1024 + lane * 16 + 16 * ((c * 128 + lane * 2) >> sh)) = rb[c];

@@ -45,6 +45,11 @@ struct Desc {  // one C block
   int16_t m, n;
 };
 
+// The A image of a product may end inside the B image's first piece in LDS: the B pieces are stored AFTER the A pieces and overwrite that
+// tail.  Every lane's own addresses are disjoint, so only the order of the two groups of ds_write instructions makes this correct
+// (one wave, in-order LDS queue): the compiler must not move a B store above an A store.
+#define DBCSR_AMD_LDS_ORDER() asm volatile("" ::: "memory")
+
 struct Work {  // one position of the launch order: the C block's descriptor AND its first product, 48 bytes.  A wave reads
                // work[pos] (neighbouring waves read neighbouring records) and can request its first operands at once:
                // the dependent chain order[pos] -> descs[cb] -> entries[prod_start] -> operands becomes work[pos] -> operands

@@ -1,0 +1,83 @@
+"""Randomised parity sweep: 160 seeded multiplies with random shapes, block-size mixes (single size, mixed, tails, tiny blocks), fills,
+transposes, alpha / beta (including 0 and 1), retain_sparsity, filter_eps and product-matrix symmetry through the dbcsr_multiply mirror
+against the CPU oracle -- index bit-exact, flop identical, values 1e-10 (fp64) / 2e-5 (fp32).  The hand-picked cases of the other
+files pin known corners; this one walks the combinations nobody thought of (empty rows, C blocks without products, single-block
+matrices, lists longer and shorter than the kernels' windows) through whatever kernel the engine picks."""
+import numpy as np
+import pytest
+import torch
+
+from dbcsr_amd.multiply import MultiplyEngine, dbcsr_multiply
+from oracle import oracle as O
+from tests.gpu_util import dev_to_bcsr, to_dev
+
+pytestmark = pytest.mark.gpu
+
+MIXES = [[1, 23], [1, 13, 1, 23, 1, 32], [1, 5], [1, 4], [1, 32], [2, 7, 1, 32], [1, 1, 1, 3], [1, 16, 1, 8], [3, 9, 1, 2], [1, 29, 1, 31]]
+
+
+def make_case(seed):
+    rng = np.random.default_rng(seed)
+    mix_m, mix_n, mix_k = (MIXES[int(rng.integers(len(MIXES)))] for _ in range(3))
+    symm_c = "N" if rng.random() < 0.8 else ("S" if rng.random() < 0.7 else "A")
+    if symm_c != "N":
+        mix_n = mix_m
+    M = int(rng.integers(1, 420))
+    N = M if symm_c != "N" else int(rng.integers(1, 420))
+    K = int(rng.integers(1, 420))
+    sp = tuple(float(x) for x in rng.choice([0.0, 0.3, 0.6, 0.8, 0.95, 0.999], size=3))
+    ta, tb = (str(x) for x in rng.choice(["N", "T"], size=2))
+    alpha = float(rng.choice([1.0, -0.5, 0.0, 2.25]))
+    beta = float(rng.choice([1.0, 0.0, -1.5, 0.5]))
+    retain = bool(rng.random() < 0.2)
+    eps = float(rng.choice([0.0, 0.0, 0.0, 3.0, 25.0]))
+    dtype = np.float32 if (symm_c == "N" and rng.random() < 0.2) else np.float64
+    return dict(M=M, N=N, K=K, sp=sp, mix_m=mix_m, mix_n=mix_n, mix_k=mix_k, ta=ta, tb=tb, alpha=alpha, beta=beta, retain=retain, eps=eps,
+                symm_c=symm_c, dtype=dtype)
+
+
+FORCED = [{"DBCSR_AMD_MM_CLASSES": "2"}, {"DBCSR_AMD_MM_SYMBOLIC": "rows"}, {"DBCSR_AMD_MM_CLASSES": "2", "DBCSR_AMD_MM_SYMBOLIC": "rows"},
+          {"DBCSR_AMD_MM_WG_WAVES": "4", "DBCSR_AMD_MM_CLASSES": "2"}, {"DBCSR_AMD_MM_SYMBOLIC": "word"}, {"DBCSR_AMD_MM_HOT": "0"}]
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_random_multiply_forced_paths(seed, monkeypatch):
+    """the same sweep with the run-time compiled class kernels, the product-driven / per-word symbolic kernels, four waves per workgroup
+    or the generic kernels forced (they engage by themselves only at sizes the oracle needs minutes for)"""
+    for k in ("DBCSR_AMD_MM_CLASSES", "DBCSR_AMD_MM_SYMBOLIC", "DBCSR_AMD_MM_WG_WAVES", "DBCSR_AMD_MM_HOT"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in FORCED[seed % len(FORCED)].items():
+        monkeypatch.setenv(k, v)
+    run_case(make_case(5000 + seed))
+
+
+@pytest.mark.parametrize("seed", range(160))
+def test_random_multiply_matches_oracle(seed):
+    run_case(make_case(1000 + seed))
+
+
+def run_case(c):
+    sm, sn, sk = O.make_block_sizes(c["M"], c["mix_m"]), O.make_block_sizes(c["N"], c["mix_n"]), O.make_block_sizes(c["K"], c["mix_k"])
+    c0 = O.RANDMAT_SEED_INIT
+    dt = c["dtype"]
+    Cm = (O.make_random_matrix(sm, sn, c["sp"][2], c0 + 1, dt) if c["symm_c"] == "N"
+          else O.make_random_matrix_symmetric(sm, c["sp"][2], c0 + 1, c["symm_c"]))
+    A = O.make_random_matrix(sk, sm, c["sp"][0], c0 + 2, dt) if c["ta"] == "T" else O.make_random_matrix(sm, sk, c["sp"][0], c0 + 2, dt)
+    B = O.make_random_matrix(sn, sk, c["sp"][1], c0 + 3, dt) if c["tb"] == "T" else O.make_random_matrix(sk, sn, c["sp"][1], c0 + 3, dt)
+    wide = lambda X: O.Bcsr(X.row_sizes, X.col_sizes, X.row_p, X.col_i, X.blk_p, X.data.astype(np.float64))
+    ref, info = O.multiply(c["ta"], c["tb"], c["alpha"], wide(A), wide(B), c["beta"], wide(Cm), retain_sparsity=c["retain"], filter_eps=c["eps"],
+                           c_symmetry=None if c["symm_c"] == "N" else c["symm_c"])
+    dA, dB, dC = to_dev(A), to_dev(B), to_dev(Cm)
+    dC.symmetry = c["symm_c"]
+    flop = [0]
+    dbcsr_multiply(c["ta"], c["tb"], c["alpha"], dA, dB, c["beta"], dC, retain_sparsity=c["retain"], filter_eps=c["eps"] or None, flop=flop,
+                   engine=MultiplyEngine())
+    torch.cuda.synchronize()
+    out = dev_to_bcsr(dC)
+    assert np.array_equal(out.row_p, ref.row_p) and np.array_equal(out.col_i, ref.col_i), c
+    assert flop[0] == info["flop"], c
+    if ref.data.size:
+        scale = max(float(np.max(np.abs(ref.data))), 1e-300)
+        tol = 1e-10 if dt == np.float64 else 2e-5
+        assert out.data.size == ref.data.size
+        assert float(np.max(np.abs(out.data.astype(np.float64) - ref.data))) <= tol * scale, c
