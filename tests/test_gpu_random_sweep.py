@@ -3,6 +3,8 @@ transposes, alpha / beta (including 0 and 1), retain_sparsity, filter_eps and pr
 against the CPU oracle -- index bit-exact, flop identical, values 1e-10 (fp64) / 2e-5 (fp32).  The hand-picked cases of the other
 files pin known corners; this one walks the combinations nobody thought of (empty rows, C blocks without products, single-block
 matrices, lists longer and shorter than the kernels' windows) through whatever kernel the engine picks."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -40,7 +42,7 @@ FORCED = [{"DBCSR_AMD_MM_CLASSES": "2"}, {"DBCSR_AMD_MM_SYMBOLIC": "rows"}, {"DB
           {"DBCSR_AMD_MM_WG_WAVES": "4", "DBCSR_AMD_MM_CLASSES": "2"}, {"DBCSR_AMD_MM_SYMBOLIC": "word"}, {"DBCSR_AMD_MM_HOT": "0"}]
 
 
-@pytest.mark.parametrize("seed", range(60))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("DBCSR_AMD_SWEEP_FORCED", "60"))))   # (a longer walk: set the variable)
 def test_random_multiply_forced_paths(seed, monkeypatch):
     """the same sweep with the run-time compiled class kernels, the product-driven / per-word symbolic kernels, four waves per workgroup
     or the generic kernels forced (they engage by themselves only at sizes the oracle needs minutes for)"""
@@ -51,7 +53,7 @@ def test_random_multiply_forced_paths(seed, monkeypatch):
     run_case(make_case(5000 + seed))
 
 
-@pytest.mark.parametrize("seed", range(160))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("DBCSR_AMD_SWEEP_PLAIN", "160"))))
 def test_random_multiply_matches_oracle(seed):
     run_case(make_case(1000 + seed))
 
