@@ -324,6 +324,10 @@ def mat_init(mat_n, x, y, seed):
 
 
 def stack_init(nstack, nc, na, nb, m, n, k, rseed=1):
+    # the reference's INIT_STACK (acc_bench.h:48-79) advances by nstack / nc + (rand() mod ... - ...) entries per C block: with fewer
+    # than two entries per C block on average the step can stay zero for ever -- the restatement loops exactly as the original would
+    if nstack < 2 * nc:
+        raise ValueError("stack_init: needs nstack >= 2 * nc (the reference's generator does not terminate below that)")
     out = np.empty(3 * nstack, np.int32)
     lib().orc_stack_init(out, nstack, nc, na, nb, m, n, k, rseed, 1)
     return out
