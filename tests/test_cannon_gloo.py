@@ -1,6 +1,6 @@
 """N > 1 path on CPU: the Cannon driver (distribution, skewed schedule, owner-direct panel
-exchange, in-place tick accumulation) under the gloo backend with world sizes 2, 4 and 6
-(2x1, 2x2 and the non-square 3x2 grid with nvirt = 6), checked against the oracle's global
+exchange, in-place tick accumulation) under the gloo backend with world sizes 2, 4, 6 and 8
+(2x1, 2x2, the non-square 3x2 grid with nvirt = 6 and BASELINE's 4x2 grid with nvirt = 4), checked against the oracle's global
 multiply.  The local arithmetic is the oracle here (tests/cpu_backend.py); on a GPU node the
 same driver runs on the HIP engine with the nccl (= RCCL) backend."""
 import os
@@ -64,7 +64,7 @@ def _worker(rank, world, port, alpha, beta, q, mode, retain=False, eps=None):
 
 
 @pytest.mark.parametrize("world,mode", [(2, "gather"), (4, "gather+given"), (6, "gather"), (4, "ticks"), (6, "ticks+given"),
-                                        (4, "ticks+dist"), (6, "gather+dist"), (2, "ticks+dist")])
+                                        (4, "ticks+dist"), (6, "gather+dist"), (2, "ticks+dist"), (8, "ticks"), (8, "gather+dist")])
 def test_cannon_matches_global_oracle(world, mode):
     _run_and_compare(world, mode)
 
