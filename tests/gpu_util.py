@@ -1,5 +1,4 @@
 """Helpers shared by the -m gpu parity tests (device <-> oracle plumbing)."""
-import ctypes as C
 
 import numpy as np
 import torch

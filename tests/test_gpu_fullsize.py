@@ -7,7 +7,6 @@ not seconds, so here the device result is checked against identities instead):
   * transposition: checksum(B^T A^T) = checksum(A B), same number of blocks;
   * idempotence: alpha = 0, beta = 1, retain_sparsity leaves C bit-identical.
 Tolerance 1e-10 relative (north star), structure exact."""
-import numpy as np
 import pytest
 import torch
 

@@ -10,7 +10,6 @@ oracle/_ref/host_cpu/dbcsr_ref_dump (tests/fortran/dbcsr_ref_dump.F90, this repo
 import json
 import os
 import subprocess
-import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
