@@ -138,3 +138,30 @@ def test_norms_match_oracle():
     assert lib.c_calculate_norms(dm.data_ptr(), len(sizes), do.data_ptr(), dn.data_ptr(), out.data_ptr(), st.ptr) == 0
     torch.cuda.synchronize()
     assert np.allclose(out.cpu().numpy(), ref, rtol=1e-6)
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("DBCSR_AMD_SWEEP_STACKS", "0"))))
+def test_random_triplets_and_stacks_exact(seed):
+    """(off by default: set DBCSR_AMD_SWEEP_STACKS=N; not yet run on hardware.)  libsmm_acc_process on random (m, n, k) up to 45 (beyond
+    32: the direct kernel), random stack lengths around the group sizes and c offsets sorted, binned or shuffled: integer-valued inputs, so
+    the result must be EXACT whatever the summation order."""
+    rng = np.random.default_rng(900 + seed)
+    m, n, k = (int(x) for x in rng.integers(1, 46, size=3))
+    if seed % 4 == 0:   # the LDS-staged range
+        m, n, k = (int(x) for x in rng.integers(1, 33, size=3))
+    nstack = int(rng.choice([2, 7, 8, 9, 15, 16, 17, 31, 33, 100, 257]))
+    na, nb = int(rng.integers(1, 60)), int(rng.integers(1, 60))
+    nc = int(rng.integers(1, max(2, nstack // 2 + 1)))   # INIT_STACK needs at least two entries per C block on average
+    a = O.mat_init(na, m, k, 42)
+    b = O.mat_init(nb, k, n, 24)
+    stack = O.stack_init(nstack, nc, na, nb, m, n, k, rseed=int(rng.integers(1, 1000)))
+    order = seed % 3
+    if order:   # 1: shuffled entries (runs of length one), 2: binned by c offset as the host does for small blocks
+        ent = np.asarray(stack, np.int32).reshape(-1, 3)
+        ent = ent[rng.permutation(len(ent))] if order == 1 else ent[np.argsort((ent[:, 2].astype(np.int64) * (ent[:, 2] + 3)) % 4096, kind="stable")]
+        stack = np.ascontiguousarray(ent.reshape(-1))
+    c_ref = np.zeros(nc * m * n)
+    O.stack_calc(stack, c_ref, a, b, m, n, k, b_transposed=False)
+    rc, c = run_stack(stack, a, b, np.zeros(nc * m * n), m, n, k, L.dbcsr_type_real_8)
+    assert rc >= 0
+    assert np.array_equal(c, c_ref), (m, n, k, nstack, order)
