@@ -307,6 +307,13 @@ class CannonMultiply:
                 if transport == "native":
                     raise RuntimeError("dbcsr_amd.cannon: native RCCL transport unavailable on some rank (%s)" % (err,))
                 sys.stderr.write("dbcsr_amd.cannon: native RCCL transport unavailable (%s), using torch.distributed\n" % (err or "another rank",))
+        # ranks of the RCCL communicator the panels travel on (0: no RCCL -- one rank, or the gloo / host-staged debug path)
+        self.rccl_ranks = 0
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            if self.comm is not None:
+                self.rccl_ranks = self.comm.world          # as ncclCommInitRank was told (dbcsr_amd_comm_create)
+            elif dist.get_backend() == "nccl":
+                self.rccl_ranks = dist.get_world_size()
         self.mode = mode
         self.local_first = local_first
         self._host = None

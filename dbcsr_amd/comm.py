@@ -14,21 +14,42 @@ from .matrix import StreamHandle
 
 class NativeComm:
     def __init__(self, group=None):
+        """Collective over the group.  Every step that can fail locally is AGREED ON before the next collective step, so that a
+        rank without a usable librccl makes all ranks raise together instead of leaving the others inside a broadcast or inside
+        ncclCommInitRank (the caller falls back to torch.distributed)."""
+        self.h = None
         self.L = _lib.load_library()
         world = dist.get_world_size(group) if dist.is_initialized() else 1
         rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.rank, self.world = rank, world
         ident = C.create_string_buffer(128)
-        if rank == 0 and self.L.dbcsr_amd_comm_unique_id(ident) != 0:
-            raise RuntimeError("dbcsr_amd_comm_unique_id failed (is librccl available?)")
+        ok = 1 if self.L.dbcsr_amd_comm_available() == 1 else 0
+        if ok and rank == 0 and self.L.dbcsr_amd_comm_unique_id(ident) != 0:
+            ok = 0
+        if not self._agree(ok, group):
+            raise RuntimeError("librccl not usable on some rank (dbcsr_amd_comm_available / dbcsr_amd_comm_unique_id)")
         if world > 1:  # the host's job: hand rank 0's id to everybody (MPI_Bcast in a Fortran host)
             box = [bytes(ident.raw)]
             dist.broadcast_object_list(box, src=0, group=group)
             ident = C.create_string_buffer(box[0], 128)
-        self.h = C.c_void_p()
-        if self.L.dbcsr_amd_comm_create(C.byref(self.h), ident, world, rank) != 0:
-            raise RuntimeError("dbcsr_amd_comm_create failed")
-        self.rank, self.world = rank, world
+        h = C.c_void_p()
+        ok = 1 if self.L.dbcsr_amd_comm_create(C.byref(h), ident, world, rank) == 0 else 0
+        if ok:
+            self.h = h
+        if not self._agree(ok, group):
+            self.close()
+            raise RuntimeError("dbcsr_amd_comm_create failed on some rank")
         self.stream = torch.cuda.Stream()  # communication stream: transfers overlap the local multiply
+
+    @staticmethod
+    def _agree(ok, group):
+        """logical AND of a local flag over the group, through torch's own communicator"""
+        if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+            return bool(ok)
+        dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+        t = torch.tensor([int(ok)], dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+        return int(t.item()) == 1
 
     def close(self):
         if getattr(self, "h", None):

@@ -83,6 +83,8 @@ using dbcsr_amd::stream_of;
 
 extern "C" {
 
+int dbcsr_amd_comm_available(void) { return rccl().ok ? 1 : 0; }
+
 int dbcsr_amd_comm_unique_id(char id[DBCSR_AMD_COMM_ID_BYTES]) {
   Rccl& r = rccl();
   if (!r.ok || !id) return -1;

@@ -950,11 +950,15 @@ __device__ __forceinline__ void cblock_f64_lds(const Desc& d, const Entry* __res
 // a product costs its buffer loads, LDS copies, ds_reads with immediate offsets and MFMAs and next to nothing else
 // (the generic path: 103 VALU + 98 SALU instructions per 23^3 product besides the 54 MFMAs).  Products of the
 // block with another inner dimension (the tail block column of A) are multiplied straight from global memory.
-template <int M, int N, int K>
+typedef const volatile double __attribute__((address_space(3))) lds_vd;  // volatile LDS read: never paired into ds_read2_b64
+// VAR: 0 = production (no ablation branch is compiled in), 1 = the run-time ablation switches of DBCSR_AMD_MM_DBG (profiling),
+// 2 = production with the fragment reads kept as single ds_read_b64 (the compiler pairs them into ds_read2_b64 otherwise)
+template <int M, int N, int K, int VAR>
 __device__ __forceinline__ void cblock_f64_exact(const Desc& d, const Entry first, const Entry* __restrict__ entries, const double* __restrict__ a_data,
                                                  const double* __restrict__ b_data, double* __restrict__ c_out,
                                                  const double* __restrict__ c_in, double alpha, double beta, const LaneMap& L, int lane,
-                                                 char* lds_a, char* lds_b, int dbg, double* __restrict__ norm_out) {
+                                                 char* lds_a, char* lds_b, int dbg_rt, double* __restrict__ norm_out) {
+  const int dbg = VAR == 1 ? dbg_rt : 0;
   constexpr int MA = (M + 7) / 8, NC = (N + 7) / 8, KS = (K + 3) / 4, K4 = 4 * KS;
   constexpr int CA = (M * K4 * 8 + 1023) / 1024, CB = (K * N * 8 + 1023) / 1024;
   double acc[MA][NC];
@@ -1032,9 +1036,19 @@ __device__ __forceinline__ void cblock_f64_exact(const Desc& d, const Entry firs
     for (int s = 0; s < KS; ++s) {
       double av[MA], bv[NC];
 #pragma unroll
-      for (int a = 0; a < MA; ++a) av[a] = pa[a][s * 4 * M];
+      for (int a = 0; a < MA; ++a) {
+        if constexpr (VAR == 2)
+          av[a] = *(lds_vd*)(pa[a] + s * 4 * M);
+        else
+          av[a] = pa[a][s * 4 * M];
+      }
 #pragma unroll
-      for (int c = 0; c < NC; ++c) bv[c] = (s == KS - 1 && (K & 3)) ? pbt[c][0] : pb[c][4 * s];
+      for (int c = 0; c < NC; ++c) {
+        if constexpr (VAR == 2)
+          bv[c] = (s == KS - 1 && (K & 3)) ? *(lds_vd*)(pbt[c]) : *(lds_vd*)(pb[c] + 4 * s);
+        else
+          bv[c] = (s == KS - 1 && (K & 3)) ? pbt[c][0] : pb[c][4 * s];
+      }
 #pragma unroll
       for (int a = 0; a < MA; ++a)
 #pragma unroll
@@ -1126,7 +1140,7 @@ __device__ __forceinline__ void cblock_f64_exact(const Desc& d, const Entry firs
 }
 
 // C blocks of exactly M x N take the exact-size path; every other block of the launch the generic one.
-template <int M, int N, int K>
+template <int M, int N, int K, int VAR>
 __global__ void __launch_bounds__(256) mm_numeric_f64_hot(const Desc* __restrict__ descs, int64_t nblk, const Entry* __restrict__ entries,
                                                           const double* __restrict__ a_data, const double* __restrict__ b_data,
                                                           double* __restrict__ c_out, const double* __restrict__ c_in, double alpha,
@@ -1148,7 +1162,7 @@ __global__ void __launch_bounds__(256) mm_numeric_f64_hot(const Desc* __restrict
   char* lds_b = lds_a + (size_t)lds_a_doubles * 8;
   const LaneMap L(lane);
   if (d.m == M && d.n == N) {
-    cblock_f64_exact<M, N, K>(d, first, entries, a_data, b_data, c_out, c_in, alpha, beta, L, lane, lds_a, lds_b, dbg,
+    cblock_f64_exact<M, N, K, VAR>(d, first, entries, a_data, b_data, c_out, c_in, alpha, beta, L, lane, lds_a, lds_b, dbg,
                               norms ? norms + w.cb : nullptr);
     return;
   }
@@ -2395,12 +2409,22 @@ __global__ void __launch_bounds__(256) block_norms_unserved_classes(const Desc* 
 static bool launch_hot_f64(int m, int n, int k, dim3 grid, size_t lds_bytes, hipStream_t st, const Desc* descs, int64_t nblk,
                            const Entry* entries, const double* a_data, const double* b_data, double* c_out, const double* c_in,
                            double alpha, double beta, int lds_a, int lds_wave, int dbg, const int* order, const Work* work, int wg_waves,
-                           double* norms) {
+                           double* norms, int variant) {
   if (m != n || m != k) return false;
+  // profiling variants exist for the benchmark's block size only (ablation switches; unpaired fragment reads)
+  if (m == 23 && (variant == 1 || variant == 2)) {
+    if (variant == 1)
+      hipLaunchKernelGGL((mm_numeric_f64_hot<23, 23, 23, 1>), grid, dim3(64 * wg_waves), lds_bytes, st, descs, nblk, entries, a_data, b_data, c_out,
+                         c_in, alpha, beta, lds_a, lds_wave, dbg, order, work, norms);
+    else
+      hipLaunchKernelGGL((mm_numeric_f64_hot<23, 23, 23, 2>), grid, dim3(64 * wg_waves), lds_bytes, st, descs, nblk, entries, a_data, b_data, c_out,
+                         c_in, alpha, beta, lds_a, lds_wave, dbg, order, work, norms);
+    return true;
+  }
   switch (m) {
 #define DBCSR_HOT_CASE(S_)                                                                                                      \
   case S_:                                                                                                                      \
-    hipLaunchKernelGGL((mm_numeric_f64_hot<S_, S_, S_>), grid, dim3(64 * wg_waves), lds_bytes, st, descs, nblk, entries, a_data, b_data, c_out, \
+    hipLaunchKernelGGL((mm_numeric_f64_hot<S_, S_, S_, 0>), grid, dim3(64 * wg_waves), lds_bytes, st, descs, nblk, entries, a_data, b_data, c_out, \
                        c_in, alpha, beta, lds_a, lds_wave, dbg, order, work, norms);                                            \
     return true;
     DBCSR_AMD_HOT_SIZES(DBCSR_HOT_CASE)
@@ -2496,7 +2520,8 @@ struct Engine {
   bool rows_kernels = false;  // product-driven symbolic kernels (sparse C); DBCSR_AMD_MM_SYMBOLIC=rows forces, =grid / =word exclude
   int force_symbolic = 0;     // 0 automatic, 1 word, 2 grid, 3 rows
   bool grid_kernels = false, force_word_kernels = false;  // DBCSR_AMD_MM_SYMBOLIC=word forces the per-word symbolic kernels
-  int dbg = 0;      // DBCSR_AMD_MM_DBG: ablation switches of the LDS kernel (profiling only)
+  int dbg = 0;      // DBCSR_AMD_MM_DBG: ablation switches of the LDS kernel (profiling only; the exact-size kernel honours them in its VAR = 1 build)
+  int hot_variant = 0;  // DBCSR_AMD_MM_HOT_VARIANT: 2 = exact-size kernel with unpaired ds_read_b64 fragment reads (23^3 only)
   int use_pipe = -1, pipe_g = 8;  // multi-block pipelined kernel: -1 automatic (short product lists only), DBCSR_AMD_MM_KERNEL=pipe|lds1 forces; DBCSR_AMD_MM_PIPE_G = blocks per wave
   // (m, n) classes (mixed block sizes, see order_count_cls): DBCSR_AMD_MM_CLASSES = 0 never, 1 automatic, 2 always when the sizes allow
   int use_classes = 1;
@@ -2576,6 +2601,7 @@ int dbcsr_amd_mm_create(void** handle) {
       hipHostMalloc(reinterpret_cast<void**>(&E->cls_host_lens), (2 * kNumClasses + 1) * sizeof(int64_t), hipHostMallocDefault) != hipSuccess)
     return -1;
   if (const char* k = getenv("DBCSR_AMD_MM_DBG")) E->dbg = atoi(k);
+  if (const char* k = getenv("DBCSR_AMD_MM_HOT_VARIANT")) E->hot_variant = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_HOT")) E->use_hot = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_TINY")) E->use_tiny = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_LDS_PAD")) E->lds_pad = atoi(k);
@@ -3053,7 +3079,7 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
                          (size_t)ww * lds_wave * sizeof(double) + (size_t)E->lds_pad, st, E->descs.p, nblk, E->entries.p,
                          static_cast<const double*>(a->data), static_cast<const double*>(b->data), static_cast<double*>(c_out->data),
                          static_cast<const double*>(c_in->data), alpha, beta, lds_a, lds_wave, E->dbg | (skip_empty ? 32 : 0), E->order.p,
-                         hot_work, ww, epi_norms)) {
+                         hot_work, ww, epi_norms, (E->dbg & ~32) ? 1 : E->hot_variant)) {
         // launched: C blocks of the dominant size take the exact-size path, the others the generic one
         if (epi_norms) {  // blocks of another size (tail block row / column) did not leave their norm: a pass over those only
           hipLaunchKernelGGL(block_norms_other_sizes, grid_for(nblk * 64), dim3(256), 0, st, E->descs.p, nblk, static_cast<const double*>(c_out->data),

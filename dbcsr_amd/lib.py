@@ -37,7 +37,7 @@ MM_SYMBOLS = [
 ]
 
 
-COMM_SYMBOLS = ["dbcsr_amd_comm_unique_id", "dbcsr_amd_comm_create", "dbcsr_amd_comm_destroy", "dbcsr_amd_comm_rank", "dbcsr_amd_comm_exchange",
+COMM_SYMBOLS = ["dbcsr_amd_comm_available", "dbcsr_amd_comm_unique_id", "dbcsr_amd_comm_create", "dbcsr_amd_comm_destroy", "dbcsr_amd_comm_rank", "dbcsr_amd_comm_exchange",
                 "dbcsr_amd_comm_allgather"]
 
 
@@ -142,6 +142,7 @@ def load_library():
     L.dbcsr_amd_multiply_symmetric_c.argtypes = [vp, C.c_char, C.c_char, i32, C.c_double, BP, BP, C.c_double, BP, i32, i32, C.c_double, BP,
                                                  C.POINTER(i64), vp]
     L.dbcsr_amd_mm_stats.argtypes = [vp, C.POINTER(MnkStat), i32, C.POINTER(i32), vp]
+    L.dbcsr_amd_comm_available.argtypes = []
     L.dbcsr_amd_comm_unique_id.argtypes = [C.c_char_p]
     L.dbcsr_amd_comm_create.argtypes = [C.POINTER(vp), C.c_char_p, i32, i32]
     L.dbcsr_amd_comm_destroy.argtypes = [vp]

@@ -31,6 +31,10 @@ typedef struct dbcsr_amd_comm_op {
   int32_t reserved;
 } dbcsr_amd_comm_op;
 
+/* 1 when librccl could be loaded with every entry point this file uses, else 0.  Local, never blocks: the host calls it on every
+ * rank and agrees on the answer (an allreduce of its own) BEFORE the collective create call, so that no rank waits in
+ * ncclCommInitRank for a peer that cannot get there */
+int dbcsr_amd_comm_available(void);
 /* rank 0: fill `id` (ncclGetUniqueId); the host distributes it to every rank */
 int dbcsr_amd_comm_unique_id(char id[DBCSR_AMD_COMM_ID_BYTES]);
 /* collective over the nranks processes: communicator on the calling thread's current device (one process per GPU) */
