@@ -44,19 +44,22 @@ struct Pool {
     const size_t g = p >> 3 > 4096 ? p >> 3 : 4096;
     return (n + g - 1) / g * g;
   }
-  long long capacity() {
-    if (cap >= 0) return cap;
-    const char* env = getenv(host ? "DBCSR_AMD_ACC_HOST_POOL_MB" : "DBCSR_AMD_ACC_POOL_MB");
-    if (env) {
-      cap = atoll(env) << 20;
-    } else if (host) {
-      cap = 16ll << 30;
-    } else {
-      size_t f = 0, t = 0;
-      cap = hipMemGetInfo(&f, &t) == hipSuccess ? (long long)(t / 4) : 0;
-      (void)hipGetLastError();
-    }
-    if (cap < 0) cap = 0;
+  std::once_flag cap_once;
+  long long capacity() {  // read once, whichever OpenMP thread of the host comes first
+    std::call_once(cap_once, [this] {
+      long long c;
+      const char* env = getenv(host ? "DBCSR_AMD_ACC_HOST_POOL_MB" : "DBCSR_AMD_ACC_POOL_MB");
+      if (env) {
+        c = atoll(env) << 20;
+      } else if (host) {
+        c = 16ll << 30;
+      } else {
+        size_t f = 0, t = 0;
+        c = hipMemGetInfo(&f, &t) == hipSuccess ? (long long)(t / 4) : 0;
+        (void)hipGetLastError();
+      }
+      cap = c < 0 ? 0 : c;
+    });
     return cap;
   }
   hipError_t raw_alloc(void** p, size_t n) { return host ? hipHostMalloc(p, n, hipHostMallocDefault) : hipMalloc(p, n); }
@@ -115,13 +118,23 @@ struct Pool {
         live.erase(it);
       }
     }
-    if (!known || capacity() <= 0 || (long long)info.second > capacity()) return raw_free(p);
+    const long long cap_now = capacity();
+    if (!known) {
+      // not handed out by this pool (or handed back already): a block that sits in the cache must not reach hipFree underneath it
+      std::lock_guard<std::mutex> lk(mu);
+      for (auto& kv : free_)
+        if (kv.second.first == p) {
+          fprintf(stderr, "dbcsr_acc: double free of %p ignored (the block is in the allocator's cache)\n", p);
+          return hipSuccess;
+        }
+    }
+    if (!known || cap_now <= 0 || (long long)info.second > cap_now) return raw_free(p);
     const hipError_t e = hipDeviceSynchronize();  // what hipFree / hipHostFree imply: nothing in flight may still use the block
     if (e != hipSuccess) return e;
     std::lock_guard<std::mutex> lk(mu);
     free_.insert({info, {p, ++stamp}});
     cached += info.second;
-    trim_locked((size_t)capacity());
+    trim_locked((size_t)cap_now);
     return hipSuccess;
   }
   size_t cached_on(int dev) {

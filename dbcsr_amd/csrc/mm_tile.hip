@@ -1,0 +1,386 @@
+// mm_tile.hip -- the numeric kernels of the tile dataflow (mm_tile.h).  A translation unit of its own because it is compiled with
+// -mllvm -structurizecfg-skip-uniform-regions: the product loop chooses one of nine accumulator sets with a wave-uniform switch,
+// and without the option the compiler restructures that switch into a chain of flow blocks whose joins copy whole accumulator
+// sets (and spill some): 400 v_mov_b64 and 116 bytes of scratch against none (tests/test_kernel_resources.py pins it).
+#include "common.h"
+#include "mm_types.h"
+#include "smm_core.h"
+#include "mm_tile.h"
+
+namespace dbcsr_amd {
+
+// ---- numeric kernel --------------------------------------------------------------------------------------------------
+
+
+// minimum over the wavefront as a scalar: DPP row shifts and row broadcasts (no LDS, no index registers), result from lane 63
+__device__ __forceinline__ unsigned tile_wave_min(unsigned v) {
+  // (the control word must be a literal: one call per step)
+  {
+    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)0xffffffff, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v = o < v ? o : v;
+  }
+  {
+    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)0xffffffff, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v = o < v ? o : v;
+  }
+  {
+    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)0xffffffff, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v = o < v ? o : v;
+  }
+  {
+    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)0xffffffff, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v = o < v ? o : v;
+  }
+  {
+    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)0xffffffff, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+    v = o < v ? o : v;
+  }
+  {
+    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)0xffffffff, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+    v = o < v ? o : v;
+  }
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+template <int M, int N, int K, int RDV>
+struct TileKernel {
+  static constexpr int MA = (M + 7) / 8, NC = (N + 7) / 8, KS = (K + 3) / 4;
+  static constexpr int ABYTES = M * K * 8, BBYTES = K * N * 8;
+  static constexpr int SA = (ABYTES + 15) & ~15, SB = (BBYTES + 15) & ~15, SLOT = SA + SB;
+  static constexpr int PIECES = (ABYTES + 1023) / 1024 + (BBYTES + 1023) / 1024;
+  static constexpr int CBYTES = ((M * N * 8 + 1023) / 1024) * 1024;
+  static constexpr int RING = (2 * SLOT > CBYTES ? 2 * SLOT : CBYTES) + 64;  // per wave; + 64: fragment reads of lanes past the last column, whole 16-byte lanes of the C staging
+  static_assert(MA == 3 && NC == 3, "sub-tiles of 3 x 3 C blocks are sized for blocks of 17..24 (9 accumulators per block and lane)");
+  static_assert(PIECES < 32, "vmcnt budget");
+  static_assert(KS >= 3, "first / middle / last k step");
+};
+
+// Fragments of k step s of the product staged in a ring slot.  ONE address register per operand: pa = slot + lane part of A,
+// pb = slot + lane part of B, every fragment at a compile-time offset from them.  No clamping: a lane whose row (column) is past
+// the block reads the neighbouring element -- finite data of the block, or the slot's padding, which the masked last DMA piece
+// fills with the zeros of its out-of-range bytes -- and only pollutes accumulator rows (columns) that are never stored.  In the
+// last k step of a K that is not a multiple of 4 the lanes past the end get an exact zero on the A side and a finite B value
+// (element (0, col + 1), or the zero padding after the last column).
+template <int M, int N, int K, int RDV>
+__device__ __forceinline__ void tile_frags(int s, const double* pa, const double* pb, bool ktail_dead, double (&av)[3], double (&bv)[3]) {
+  typedef TileKernel<M, N, K, RDV> TK;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    if constexpr (RDV == 1)
+      av[a] = *(const volatile double __attribute__((address_space(3)))*)(pa + 8 * a + s * 4 * M);
+    else
+      av[a] = pa[8 * a + s * 4 * M];
+    if (s == TK::KS - 1 && (K & 3)) av[a] = ktail_dead ? 0.0 : av[a];
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    if constexpr (RDV == 1)
+      bv[c] = *(const volatile double __attribute__((address_space(3)))*)(pb + 8 * K * c + 4 * s);
+    else
+      bv[c] = pb[8 * K * c + 4 * s];
+  }
+}
+
+// nine MFMAs of one k step, accumulators updated IN PLACE.  Written as inline asm with tied ("+v") accumulator operands: with the
+// builtin, each MFMA defines a new value, and across the nine-way choice of the accumulator set the compiler kept two register
+// homes per set and copied whole sets at every join (dozens of v_mov_b64 per product).  Dependent MFMAs on the same accumulator
+// are nine instructions apart, as in the compiler's own sequences (no software wait states needed at that distance); the s_nop
+// covers a fragment register written by a VALU select just before (k tail).
+__device__ __forceinline__ void tile_mfma9(double (&acc)[3][3], const double (&av)[3], const double (&bv)[3]) {
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) acc[a][c] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[a], bv[c], acc[a][c], 0, 0, 0);
+}
+
+// acc += the product staged in a ring slot.  Two fragment stages: the reads of step s + 1 are issued, then the MFMAs of step s run
+// (the asm statements are volatile: they keep their order, and the fragment reads cannot sink below the statement that uses them)
+template <int M, int N, int K, int RDV>
+__device__ __forceinline__ void tile_multiply(double (&acc)[3][3], const double* pa, const double* pb, bool ktail_dead) {
+  typedef TileKernel<M, N, K, RDV> TK;
+  double av[2][3], bv[2][3];
+  tile_frags<M, N, K, RDV>(0, pa, pb, ktail_dead, av[0], bv[0]);
+#pragma unroll
+  for (int ks = 0; ks < TK::KS; ++ks) {
+    __builtin_amdgcn_sched_barrier(0);
+    if (ks + 1 < TK::KS) tile_frags<M, N, K, RDV>(ks + 1, pa, pb, ktail_dead, av[(ks + 1) & 1], bv[(ks + 1) & 1]);
+    __builtin_amdgcn_sched_barrier(0);
+    tile_mfma9(acc, av[ks & 1], bv[ks & 1]);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// C_out block <- alpha * acc (+ beta * C_in block), through the wave's LDS area, in whole 1 KiB pieces with the streaming hint
+template <int M, int N>
+__device__ __forceinline__ void tile_store_block(const double (&acc)[3][3], char* stage, int64_t c_off, int64_t cin_off, double* __restrict__ c_out,
+                                                 const double* __restrict__ c_in, double alpha, double beta, const LaneMap& L, int voff) {
+  constexpr int CC = (M * N * 8 + 1023) / 1024;
+  typedef double f64x2 __attribute__((ext_vector_type(2)));
+  double* lds_c = reinterpret_cast<double*>(stage);
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int row = 8 * a + L.rowd, col = 8 * c + L.coll;
+      if (row < M && col < N) lds_c[row + M * col] = alpha * acc[a][c];
+    }
+  const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc((void*)(c_out + c_off), 0, M * N * 8, 0x00020000);
+  if (cin_off >= 0) {
+    const __amdgpu_buffer_rsrc_t rsi = __builtin_amdgcn_make_buffer_rsrc((void*)(c_in + cin_off), 0, M * N * 8, 0x00020000);
+    u32x4 ci[CC];
+#pragma unroll
+    for (int c = 0; c < CC; ++c) ci[c] = __builtin_amdgcn_raw_buffer_load_b128(rsi, voff, c * 1024, 0);
+#pragma unroll
+    for (int c = 0; c < CC; ++c) {
+      f64x2 v = *reinterpret_cast<const f64x2*>(stage + c * 1024 + voff);
+      const f64x2 w = __builtin_bit_cast(f64x2, ci[c]);
+      v[0] += beta * w[0];
+      v[1] += beta * w[1];
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsc, voff, c * 1024, 2);
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < CC; ++c) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(stage + c * 1024 + voff);
+      __builtin_amdgcn_raw_buffer_store_b128(v, rsc, voff, c * 1024, 2);
+    }
+  }
+}
+
+// One persistent workgroup per CU, 8 waves; workgroup b belongs to the team of XCD b % 8 (round-robin dispatch; a different
+// placement costs L2 hits, never correctness).
+template <int M, int N, int K, int RDV>
+__global__ void __launch_bounds__(512) mm_numeric_f64_tile(TileArgs P) {
+  typedef TileKernel<M, N, K, RDV> TK;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, voff = lane * 16;
+  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int xcd = blockIdx.x & 7, cu = blockIdx.x >> 3;
+  const int q = cu * 8 + wid;  // position in the team
+  char* ring = smem + wid * TK::RING;
+  const unsigned ring_lds = lds_offset_of(ring);
+  const LaneMap L(lane);
+  const TileGeom G = P.G;
+  unsigned* team = P.prog + xcd * 256;
+  // lane parts of the fragment addresses inside a ring slot (doubles): constant for the whole life of the wave
+  const int la = L.rowl + M * L.kq, lb = TK::SA / 8 + L.kq + K * L.coll;
+  const bool ktail_dead = (K & 3) != 0 && (4 * (TK::KS - 1) + L.kq) >= K;
+  const bool in_team = q < G.team_rows * kTeamCols && q < 256;
+  int window = __builtin_amdgcn_readfirstlane(P.window);
+  unsigned seen_min = 0;  // last minimum read from the team (the true minimum only grows: a stale value is conservative)
+  const __amdgpu_buffer_rsrc_t rs_team = __builtin_amdgcn_make_buffer_rsrc((void*)team, 0, 1024, 0x00020000);
+  // Publishing is branch-free: every lane issues the store, the lanes other than 0 with an offset past the end of the buffer
+  // descriptor (dropped by the bounds check).  A divergent branch inside the product loop would make the compiler restructure the
+  // whole loop body -- including the nine-way choice of the accumulator set, whose joins then copy whole sets.
+  const int pub_off = lane == 0 ? 4 * q : 0x7ffffff0;
+  // Stores to the team's counters are rationed: 256 waves share eight cache lines, and a store per product (29 M per multiply of
+  // config 2, every one a partial-line write) took longer than the multiply itself.  A wave republishes only when its need has
+  // moved on by a quantum (an eighth of the window): what it publishes is a LOWER bound of what it still needs, so publishing
+  // late is always safe, and the team's view of it lags by less than the quantum.
+  const unsigned quantum = window > 8 ? (unsigned)window >> 3 : 1u;
+  unsigned published = 0;
+  auto publish = [&](unsigned g) {
+    published = g;
+    if (P.pub_policy == 0)
+      __builtin_amdgcn_raw_buffer_store_b32(g, rs_team, pub_off, 0, 16);  // sc1: written through, visible device-wide
+    else
+      __builtin_amdgcn_raw_buffer_store_b32(g, rs_team, pub_off, 0, 0);   // into this XCD's L2 (where the whole team reads it)
+  };
+  // next-need protocol: the wave that holds the minimum may always go on
+  auto admit = [&](unsigned g) {
+    if (window <= 0) return;
+    if (g <= seen_min + (unsigned)window) {  // inside the window already: no traffic at all, except the rationed progress report
+      if (g >= published + quantum) publish(g);
+      return;
+    }
+    publish(g);
+    int polls = 0;
+    for (;;) {
+      // the 256 counters of the team in one 1 KiB read (sc1: not from this CU's vector cache)
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_team, voff, 0, 16);
+      unsigned m = v[0] < v[1] ? v[0] : v[1];
+      const unsigned m2 = v[2] < v[3] ? v[2] : v[3];
+      m = m < m2 ? m : m2;
+      seen_min = tile_wave_min(m);
+      if (g <= seen_min + (unsigned)window) break;
+      if (++polls > (1 << 15)) {  // never hang on the protocol: go on unthrottled
+        window = 0;
+        atomicAdd(P.flags, lane == 0 ? 1 : 0);
+        publish(kTileDone);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+  };
+  double acc[kTileSlots][3][3];
+  for (int s = 0; in_team && s < G.nseq; ++s) {
+    const int st = xcd + 8 * s;
+    if (st >= G.nSR * G.nSC) break;
+    const int tr = (st / G.nSC) * G.team_rows + q / kTeamCols, tc = (st % G.nSC) * kTeamCols + q % kTeamCols;
+    if (tr >= G.nTR || tc >= G.nTC) {  // no sub-tile here (edge of the matrix): do not hold the team back
+      if (window > 0) publish((unsigned)((s + 1) * G.kspan));
+      continue;
+    }
+    const TileDesc* td = P.tdescs + ((int64_t)tr * G.nTC + tc);
+    const int n = __builtin_amdgcn_readfirstlane(td->n_main);
+    const int64_t ls = td->list_start;
+    const TileEntry* e = P.entries + ls;
+#pragma unroll
+    for (int sl = 0; sl < kTileSlots; ++sl)
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[sl][a][c] = 0.0;
+    // The list is read with vector loads (lane l holds entry base + l) and handed out with v_readlane: no scalar-load latency
+    // between two products, and no SMEM in flight next to the fragment reads
+    int ebase = 0;
+    u32x4 ev = {0u, 0u, 0u, 0u};
+    const __amdgpu_buffer_rsrc_t rs_list = __builtin_amdgcn_make_buffer_rsrc((void*)e, 0, n * 16, 0x00020000);
+    auto load_window = [&](int base) {
+      ebase = base;
+      ev = __builtin_amdgcn_raw_buffer_load_b128(rs_list, voff, base * 16, 0);  // entries base .. base + 63 (zeros past the end)
+    };
+    auto entry_at = [&](int i) {  // i wave-uniform, ebase <= i < n
+      if (i - ebase >= 64) load_window(i);
+      const int j = __builtin_amdgcn_readfirstlane(i - ebase);
+      TileEntry en;
+      en.a_lo = (uint32_t)__builtin_amdgcn_readlane((int)ev[0], j);
+      en.b_lo = (uint32_t)__builtin_amdgcn_readlane((int)ev[1], j);
+      en.w = (uint32_t)__builtin_amdgcn_readlane((int)ev[2], j);
+      en.k = (uint32_t)__builtin_amdgcn_readlane((int)ev[3], j);
+      return en;
+    };
+    auto issue = [&](const TileEntry& en, int slot) {
+      const uint64_t ao = (uint64_t)en.a_lo | ((uint64_t)((en.w >> 16) & 0xffu) << 32), bo = (uint64_t)en.b_lo | ((uint64_t)(en.w >> 24) << 32);
+      const unsigned lds = ring_lds + (unsigned)slot * TK::SLOT;
+      dma_block<TK::ABYTES>(P.a_data + ao, lds, voff);
+      dma_block<TK::BBYTES>(P.b_data + bo, lds + TK::SA, voff);
+    };
+    load_window(0);
+    TileEntry cur = {0u, 0u, 0u, 0u}, nxt = {0u, 0u, 0u, 0u};
+    if (n > 0) {
+      cur = entry_at(0);
+      admit((unsigned)(s * G.kspan) + cur.k);
+      issue(cur, 0);
+    }
+    for (int p = 0; p < n; ++p) {
+      const bool more = p + 1 < n;
+      if (more) {
+        nxt = entry_at(p + 1);
+        admit((unsigned)(s * G.kspan) + nxt.k);
+        issue(nxt, (p + 1) & 1);
+        dma_wait<TK::PIECES>();  // the pieces of product p have landed (loads return in order; a pending store only makes this wait longer)
+      } else {
+        dma_wait<0>();
+      }
+      const double* sl = reinterpret_cast<const double*>(ring + (p & 1) * TK::SLOT);
+      const double *pa = sl + la, *pb = sl + lb;
+      // one multiply body per accumulator set (the set is a compile-time choice: registers cannot be indexed)
+      switch (cur.w & 15u) {
+#define DBCSR_TILE_CASE(S_) \
+  case S_: tile_multiply<M, N, K, RDV>(acc[S_], pa, pb, ktail_dead); break;
+        DBCSR_TILE_CASE(0) DBCSR_TILE_CASE(1) DBCSR_TILE_CASE(2) DBCSR_TILE_CASE(3) DBCSR_TILE_CASE(4)
+        DBCSR_TILE_CASE(5) DBCSR_TILE_CASE(6) DBCSR_TILE_CASE(7)
+#undef DBCSR_TILE_CASE
+        default: tile_multiply<M, N, K, RDV>(acc[8], pa, pb, ktail_dead); break;
+      }
+      cur = nxt;
+    }
+    // the wave needs nothing below the next super-tile any more: do not hold the team back during the epilogue
+    if (window > 0) publish((unsigned)((s + 1) * G.kspan));
+#pragma unroll
+    for (int sl2 = 0; sl2 < kTileSlots; ++sl2) {
+      const int64_t c_off = td->c_off[sl2];
+      if (c_off >= 0) tile_store_block<M, N>(acc[sl2], ring, c_off, td->cin_off[sl2], P.c_out, P.c_in, P.alpha, P.beta, L, voff);
+    }
+  }
+  if (q < 256) publish(kTileDone);
+}
+
+// products of the tiles' C blocks whose inner block has another size than K (the tail block column of A): C += alpha * A * B on
+// the finished block, one wavefront per sub-tile (all products of a C block are in one list: no two waves touch a block)
+template <int M, int N>
+__global__ void __launch_bounds__(256) tile_remainder(TileGeom G, const TileDesc* __restrict__ tdescs, const TileEntry* __restrict__ entries,
+                                                      const double* __restrict__ a_data, const double* __restrict__ b_data, double* __restrict__ c_out,
+                                                      double alpha) {
+  const int lane = threadIdx.x & 63;
+  const int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (t >= (int64_t)G.nTR * G.nTC) return;
+  const TileDesc* td = tdescs + t;
+  const int n_rem = td->n_rem;
+  if (n_rem == 0) return;
+  const LaneMap L(lane);
+  const TileEntry* e = entries + td->list_start + td->n_main;
+  for (int p = 0; p < n_rem; ++p) {
+    const TileEntry en = e[p];
+    const uint64_t ao = (uint64_t)en.a_lo | ((uint64_t)((en.w >> 16) & 0xffu) << 32), bo = (uint64_t)en.b_lo | ((uint64_t)(en.w >> 24) << 32);
+    const int ks = (int)((en.w >> 8) & 0xffu), slot = (int)(en.w & 15u);
+    double acc[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) acc[a][c] = 0.0;
+    block_product_f64<3, 3, false>(acc, a_data + ao, b_data + bo, M, N, ks, L);
+    double* C = c_out + td->c_off[slot];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int row = 8 * a + L.rowd, col = 8 * c + L.coll;
+        if (row < M && col < N) C[row + (size_t)M * col] += alpha * acc[a][c];
+      }
+  }
+}
+
+
+int tile_lds_bytes(int m, int n, int k) {
+  if (m != n || m != k) return 0;
+  switch (m) {
+#define DBCSR_TILE_LDS(S_) \
+  case S_: return 8 * TileKernel<S_, S_, S_, 0>::RING;
+    DBCSR_AMD_TILE_SIZES(DBCSR_TILE_LDS)
+#undef DBCSR_TILE_LDS
+    default: return 0;
+  }
+}
+
+template <int S_, int RDV>
+static int tile_launch_one(unsigned nwg, hipStream_t st, const TileArgs& P) {
+  typedef TileKernel<S_, S_, S_, RDV> TK;
+  static bool attr = false;
+  if (!attr) {  // more than 64 KB of dynamic LDS needs the attribute, once per kernel
+    ACC_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(mm_numeric_f64_tile<S_, S_, S_, RDV>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * TK::RING));
+    attr = true;
+  }
+  hipLaunchKernelGGL((mm_numeric_f64_tile<S_, S_, S_, RDV>), dim3(nwg), dim3(512), 8 * TK::RING, st, P);
+  return check(hipGetLastError(), "mm_numeric_f64_tile", __FILE__, __LINE__);
+}
+
+int tile_launch(int m, int n, int k, int rdv, unsigned nwg, hipStream_t st, const TileArgs& P) {
+  if (m != n || m != k) return 1;
+  switch (m) {
+#define DBCSR_TILE_LAUNCH(S_) \
+  case S_: return rdv ? tile_launch_one<S_, 1>(nwg, st, P) : tile_launch_one<S_, 0>(nwg, st, P);
+    DBCSR_AMD_TILE_SIZES(DBCSR_TILE_LAUNCH)
+#undef DBCSR_TILE_LAUNCH
+    default: return 1;
+  }
+}
+
+int tile_launch_remainder(int m, int n, hipStream_t st, const TileGeom& G, const TileDesc* tdescs, const TileEntry* entries, const double* a_data,
+                          const double* b_data, double* c_out, double alpha) {
+  if (m != n) return 1;
+  const int64_t nT = (int64_t)G.nTR * G.nTC;
+  const dim3 grid((unsigned)((nT * 64 + 255) / 256));
+  switch (m) {
+#define DBCSR_TILE_REM(S_)                                                                                                              \
+  case S_:                                                                                                                              \
+    hipLaunchKernelGGL((tile_remainder<S_, S_>), grid, dim3(256), 0, st, G, tdescs, entries, a_data, b_data, c_out, alpha);             \
+    return check(hipGetLastError(), "tile_remainder", __FILE__, __LINE__);
+    DBCSR_AMD_TILE_SIZES(DBCSR_TILE_REM)
+#undef DBCSR_TILE_REM
+    default: return 1;
+  }
+}
+
+}  // namespace dbcsr_amd

@@ -110,6 +110,22 @@ class MultiplyEngine:
         v = self.L.dbcsr_amd_mm_last_kernel(self.h)
         return v.decode() if v else ""
 
+    def plan_stats(self):
+        """(multiplies that reused the previous plan, multiplies that ran their symbolic phase) since the engine was made"""
+        a, b = C.c_int64(), C.c_int64()
+        if self.L.dbcsr_amd_mm_plan_stats(self.h, C.byref(a), C.byref(b)) != 0:
+            raise RuntimeError("dbcsr_amd_mm_plan_stats failed")
+        return a.value, b.value
+
+    def tile_stats(self):
+        """(waves that gave up waiting in the k window, sub-tile lists that disagreed with the per-block counts) of the last numeric
+        call, or None when it did not run the tile kernel (dbcsr_amd_mm_tile_stats)"""
+        a, b = C.c_int(), C.c_int()
+        rc = self.L.dbcsr_amd_mm_tile_stats(self.h, C.byref(a), C.byref(b))
+        if rc < 0:
+            raise RuntimeError("dbcsr_amd_mm_tile_stats failed (%d)" % rc)
+        return None if rc else (a.value, b.value)
+
     def last_timing(self):
         """(ms_fill, ms_numeric) of the last numeric call, from HIP events on its stream."""
         f, n = C.c_float(), C.c_float()

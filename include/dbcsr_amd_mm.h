@@ -200,6 +200,17 @@ const char* dbcsr_amd_mm_kernel_name(libsmm_acc_data_t datatype);
 /* name (with its template arguments) of the block-product kernel the last dbcsr_amd_mm_numeric of this handle launched */
 const char* dbcsr_amd_mm_last_kernel(void* handle);
 
+/* Plan reuse: a multiply whose A, B and C_in have exactly the index arrays (row_p, col_i, blk_p, block sizes) of the previous
+ * multiply of this handle -- every SCF step of a CP2K run -- skips its symbolic phase: the engine keeps device copies of the last
+ * call's index arrays and compares the incoming ones on the device (one small kernel, one flag).  Multiplies with filter_eps > 0
+ * never reuse (their pattern depends on the values).  DBCSR_AMD_MM_PLAN=0 switches it off.  Counters since the handle was made: */
+int dbcsr_amd_mm_plan_stats(void* handle, int64_t* reused, int64_t* built);
+
+/* Diagnostics of the tile kernel (dbcsr_amd/csrc/mm_tile.h) in the last dbcsr_amd_mm_numeric of this handle: waves that gave up
+ * waiting in the team's k window (they went on unthrottled: speed only), sub-tiles whose product list disagreed with the per-block
+ * product counts (must be 0).  Returns 1 when that call did not run the tile kernel.  Synchronises the device. */
+int dbcsr_amd_mm_tile_stats(void* handle, int* waves_gave_up, int* list_mismatches);
+
 #if defined(__cplusplus)
 }
 #endif

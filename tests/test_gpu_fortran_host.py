@@ -27,6 +27,19 @@ needs_host = pytest.mark.skipif(not os.path.exists(os.path.join(HOST, "dbcsr_per
                                 reason="reference Fortran host not built (tools/build_dbcsr_host.py acc)")
 
 
+
+# "... PASSED !" lines of the reference's unit test programs (counted on the unchanged CPU build, oracle/_ref/host_cpu)
+EXPECTED_PASSED = {"dbcsr_unittest1": 8124, "dbcsr_unittest3": 756}
+
+
+def check_unittest_output(out, prog):
+    """the reference's multiply tests print one "... PASSED !" line per case and "... FAILED !" before aborting
+    (tests/dbcsr_test_multiply.F:497-511): every case must have passed, none failed, and nothing may report an error"""
+    up = out.upper()
+    assert " FAILED !" not in up, out[-3000:]
+    assert up.count("PASSED !") == EXPECTED_PASSED[prog], (up.count("PASSED !"), EXPECTED_PASSED[prog])
+    assert "ERROR" not in up.replace("ERROR_TOLERANCE", ""), out[-3000:]
+
 def write_perf(c, path):
     def d(x):  # the reference's ator() wants a decimal point: 1.0d0, not 1d0
         m, _, e = ("%.17e" % x).partition("e")
@@ -65,7 +78,7 @@ def test_reference_perf_driver_through_acc_backend(name, tmp_path):
 def test_reference_unittests_through_acc_backend(prog, tmp_path):
     r = subprocess.run([os.path.join(HOST, prog)], cwd=tmp_path, env=ENV, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert "ERROR" not in r.stdout.upper().replace("ERROR_TOLERANCE", "") or "PASSED" in r.stdout.upper(), r.stdout[-3000:]
+    check_unittest_output(r.stdout, prog)
 
 
 @needs_host
@@ -133,5 +146,5 @@ def test_reference_unittests_through_resident_engine(prog, tmp_path):
     r = subprocess.run([os.path.join(HOST_RES, prog)], cwd=tmp_path, env=dict(ENV_RES, DBCSR_AMD_RESIDENT="1v"), capture_output=True, text=True,
                        timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert "ERROR" not in r.stdout.upper().replace("ERROR_TOLERANCE", "") or "PASSED" in r.stdout.upper(), r.stdout[-3000:]
+    check_unittest_output(r.stdout, prog)
     assert r.stdout.count("dbcsr_amd_resident:") > 10, "hardly any multiply took the device-resident path"
