@@ -2543,7 +2543,7 @@ struct Engine {
   int dbg = 0;      // DBCSR_AMD_MM_DBG: ablation switches of the LDS kernel (profiling only; the exact-size kernel honours them in its VAR = 1 build)
   // XCD-wide C tiles in registers (mm_tile.h): DBCSR_AMD_MM_TILE = 0 never, 1 automatic, 2 whenever the sizes allow;
   // DBCSR_AMD_MM_TILE_WINDOW = k window of the team (inner blocks; 0: no throttle); DBCSR_AMD_MM_TILE_RDV = 1: unpaired fragment reads
-  int use_tile = 0, tile_window = 256, tile_rdv = 0, tile_pub = 0;  // DBCSR_AMD_MM_TILE_PUB: progress stores written through (0) / left in L2 (1)
+  int use_tile = 0, tile_window = 256, tile_rdv = 0, tile_pub = 1, tile_prefetch = 0;  // DBCSR_AMD_MM_TILE_PUB: progress stores written through (0) / left in L2 (1)
   int hot_cnt_m = 0, hot_cnt_k = 0, hot_cnt_n = 0;  // block rows / inner blocks / block columns of the dominant size
   DevBuf<uint32_t> a_bm, bt_bm, tile_prog;
   DevBuf<int> a_pre, tile_rows, tile_cols, tile_cnt, tile_flags;
@@ -2739,6 +2739,7 @@ static int run_tile_f64(Engine* E, hipStream_t st, const dbcsr_amd_bcsr* a, cons
   P.G = G;
   P.window = E->tile_window;
   P.pub_policy = E->tile_pub;
+  P.prefetch = E->tile_prefetch;
   ACC_CHECK(hipEventRecord(E->ev[1], st));  // the timed numeric launch starts here (the index work above counts as fill time)
   if (tile_launch(S_, S_, S_, E->tile_rdv, (unsigned)(8 * cu_per_xcd), st, P)) return -1;
   if (tile_launch_remainder(S_, S_, st, G, E->tdescs.p, E->tentries.p, P.a_data, P.b_data, P.c_out, alpha)) return -1;
@@ -2787,6 +2788,7 @@ int dbcsr_amd_mm_create(void** handle) {
   if (const char* k = getenv("DBCSR_AMD_MM_TILE_WINDOW")) E->tile_window = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_TILE_RDV")) E->tile_rdv = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_TILE_PUB")) E->tile_pub = atoi(k);
+  if (const char* k = getenv("DBCSR_AMD_MM_TILE_PREFETCH")) E->tile_prefetch = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_HOT")) E->use_hot = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_TINY")) E->use_tiny = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_LDS_PAD")) E->lds_pad = atoi(k);
@@ -3809,6 +3811,9 @@ int dbcsr_amd_mm_tile_stats(void* handle, int* waves_gave_up, int* list_mismatch
   ACC_CHECK(hipMemcpy(h, E->tile_flags.p, sizeof h, hipMemcpyDeviceToHost));
   if (waves_gave_up) *waves_gave_up = h[0];
   if (list_mismatches) *list_mismatches = h[1];
+  if (getenv("DBCSR_AMD_MM_TILE_VERBOSE"))
+    fprintf(stderr, "dbcsr_amd tile kernel: %d waves gave up, %lld reads of the team counters, %lld products waited for the window (of %lld)\n", h[0],
+            16ll * h[2], 16ll * h[3], (long long)E->nproducts);
   return 0;
 }
 

@@ -65,10 +65,11 @@ struct TileArgs {
   const double* c_in;
   double alpha, beta;
   unsigned* prog;  // [8][256] progress of the team's waves (zeroed before the launch)
-  int* flags;      // [0]: waves that gave up waiting (diagnostic)
+  int* flags;      // diagnostics: [0] waves that gave up waiting, [1] list mismatches (index kernels), [2] polls / 16, [3] blocked products / 16
   TileGeom G;
   int window;      // W, in inner blocks; <= 0: no throttle
   int pub_policy;  // progress stores: 0 = written through (device scope), 1 = left in the XCD's L2
+  int prefetch;    // 1: the blocks of the product after the next one are pulled into L2 ahead of their DMA
 };
 
 // block sizes the tile kernels are built for (cubes)

@@ -179,6 +179,9 @@ __global__ void __launch_bounds__(512) mm_numeric_f64_tile(TileArgs P) {
   // late is always safe, and the team's view of it lags by less than the quantum.
   const unsigned quantum = window > 8 ? (unsigned)window >> 3 : 1u;
   unsigned published = 0;
+  unsigned pf_sink = 0;             // destination of the L2 prefetch loads (see the product loop)
+  const int pf_off = lane * 128;    // one dword per 128-byte line
+  unsigned n_polls = 0, n_blocked = 0;  // diagnostics: reads of the team's counters / products that had to wait for the window
   auto publish = [&](unsigned g) {
     published = g;
     if (P.pub_policy == 0)
@@ -195,7 +198,9 @@ __global__ void __launch_bounds__(512) mm_numeric_f64_tile(TileArgs P) {
     }
     publish(g);
     int polls = 0;
+    ++n_blocked;
     for (;;) {
+      ++n_polls;
       // the 256 counters of the team in one 1 KiB read (sc1: not from this CU's vector cache)
       const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_team, voff, 0, 16);
       unsigned m = v[0] < v[1] ? v[0] : v[1];
@@ -269,7 +274,23 @@ __global__ void __launch_bounds__(512) mm_numeric_f64_tile(TileArgs P) {
         nxt = entry_at(p + 1);
         admit((unsigned)(s * G.kspan) + nxt.k);
         issue(nxt, (p + 1) & 1);
-        dma_wait<TK::PIECES>();  // the pieces of product p have landed (loads return in order; a pending store only makes this wait longer)
+        if (P.prefetch && p + 2 < n) {
+          // pull the blocks of product p + 2 into this XCD's L2 ahead of their DMA (one dword per 128-byte line, lanes past the
+          // block are dropped by the descriptor's bounds check; the loaded values are never used): the ring holds one product in
+          // flight per wave, which covers an L2 hit but not a trip over the fabric
+          const TileEntry pf = entry_at(p + 2);
+          const uint64_t ao = (uint64_t)pf.a_lo | ((uint64_t)((pf.w >> 16) & 0xffu) << 32), bo = (uint64_t)pf.b_lo | ((uint64_t)(pf.w >> 24) << 32);
+          const dma_rsrc_t ra = dma_make_rsrc(P.a_data + ao, (unsigned)TK::ABYTES), rb = dma_make_rsrc(P.b_data + bo, (unsigned)TK::BBYTES);
+          // (inline asm: the compiler must never wait for these loads; they all land in ONE register that nothing else may use,
+          // kept alive until the wave's last wait)
+          asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, 0 offen sc1\n\tbuffer_load_dword %0, %1, %3, 0 offen sc1"
+                       : "+v"(pf_sink)
+                       : "v"(pf_off), "s"(ra), "s"(rb)
+                       : "memory");
+          dma_wait<TK::PIECES + 2>();
+        } else {
+          dma_wait<TK::PIECES>();  // the pieces of product p have landed (loads return in order; a pending store only makes this wait longer)
+        }
       } else {
         dma_wait<0>();
       }
@@ -295,6 +316,12 @@ __global__ void __launch_bounds__(512) mm_numeric_f64_tile(TileArgs P) {
     }
   }
   if (q < 256) publish(kTileDone);
+  dma_wait<0>();
+  asm volatile("" ::"v"(pf_sink));
+  if (P.window > 0) {
+    atomicAdd(P.flags + 2, lane == 0 ? (int)(n_polls >> 4) : 0);   // (in units of 16: the sum over 2048 waves stays in range)
+    atomicAdd(P.flags + 3, lane == 0 ? (int)(n_blocked >> 4) : 0);
+  }
 }
 
 // products of the tiles' C blocks whose inner block has another size than K (the tail block column of A): C += alpha * A * B on

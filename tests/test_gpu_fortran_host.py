@@ -96,6 +96,44 @@ def test_dump_driver_through_acc_backend(name):
     assert data.size == ref.data.size and np.max(np.abs(data - ref.data), initial=0.0) <= (5e-6 if R.np_dtype(ref.params) == np.float32 else 1e-10) * scale
 
 
+# ---- the unchanged host's G2G variant (DBCSR_USE_ACC_G2G=1: src/mm/dbcsr_mm.F:909-922 -> multiply_cannon_g2g,
+# dbcsr_mm_cannon.F:1773-2836): panels uploaded once and kept as device pointers, block norms computed ON THE DEVICE by
+# c_calculate_norms (its only in-situ caller, src/mm/dbcsr_mm_common.F:117-130), four OpenMP threads driving the acc ABI at once --
+ENV_G2G = dict(ENV, DBCSR_USE_ACC_G2G="1")   # (logical parameters are read as integers, src/core/dbcsr_config.F:306-318)
+
+
+@needs_host
+@pytest.mark.parametrize("name", sorted(k for k, v in GOLD.items() if v["check"] == "T" and v["data_type"] == 3))
+def test_reference_perf_driver_through_acc_backend_g2g(name, tmp_path):
+    c = GOLD[name]
+    write_perf(c, tmp_path / "case.perf")
+    r = subprocess.run([os.path.join(HOST, "dbcsr_perf"), str(tmp_path / "case.perf")], cwd=tmp_path, env=ENV_G2G, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert re.search(r"ACC: Use G2G algorithm\s+T", r.stdout), "the host did not switch to the G2G algorithm:\n" + r.stdout[:3000]
+    m = re.search(r"checksum\(C_out\)\s*=\s*([0-9.E+-]+)", r.stdout)
+    mp = re.search(r"checksum\(C_out\) POS\s*=\s*([0-9.E+-]+)", r.stdout)
+    assert m and mp, r.stdout[-3000:]
+    assert abs(float(m.group(1)) / c["checksum"] - 1.0) <= c["threshold"]
+    assert abs(float(mp.group(1)) / c["checksum_pos"] - 1.0) <= c["threshold"]
+
+
+@needs_host
+@pytest.mark.parametrize("name", R.names(lambda p: p["values"] and R.np_dtype(p) == np.float64))
+def test_dump_driver_through_acc_backend_g2g(name):
+    """the double-precision reference dumps (filter_eps cases included: their block norms now come from c_calculate_norms on
+    the device) through the unchanged host's G2G algorithm"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import base64
+    import make_ref_fixtures as F
+    ref = R.RefResult(name)
+    got = F.run_case(ref.params, exe=os.path.join(HOST, "dbcsr_ref_dump"), env={"OMP_NUM_THREADS": "4", "DBCSR_USE_ACC_G2G": "1"})
+    assert got["nblks"] == ref.nblks and got["flop"] == ref.flop
+    assert np.array_equal(np.asarray(got["row"]) - 1, ref.rows) and np.array_equal(np.asarray(got["col"], np.int32) - 1, ref.col_i)
+    data = np.frombuffer(base64.b64decode(got["values_b64"]), "<f8") if ref.nblks else np.zeros(0)
+    scale = max(np.max(np.abs(ref.data)), 1e-300) if ref.nblks else 1.0
+    assert data.size == ref.data.size and np.max(np.abs(data - ref.data), initial=0.0) <= 1e-10 * scale
+
+
 # ---- the call-site change of INTEGRATION.md section 2, compiled into the reference (tools/build_dbcsr_host.py resident):
 # dbcsr_multiply of the otherwise unchanged library hands the whole multiply to the device-resident engine -------------------
 HOST_RES = os.path.join(ROOT, "oracle", "_ref", "host_resident")

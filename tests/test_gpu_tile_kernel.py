@@ -19,7 +19,7 @@ SPARSE_C = (23 * 60 + 16, 23 * 64 + 16, 23 * 62 + 16, 0.93, 0.93, 0.95, [1, 23],
 MANY = (23 * 170 + 16, 23 * 150 + 16, 23 * 160 + 16, 0.9, 0.9, 0.9, [1, 23], [1, 23], [1, 23])       # 16 super-tiles: two per XCD
 TAILS = (23 * 40 + 16 + 7, 23 * 44 + 9, 23 * 42 + 16 + 5, 0.7, 0.7, 0.8, [20, 23, 1, 16, 1, 7], [22, 23, 1, 9], [21, 23, 1, 16, 1, 5])
 
-ENV_KEYS = ("DBCSR_AMD_MM_TILE", "DBCSR_AMD_MM_TILE_WINDOW", "DBCSR_AMD_MM_TILE_RDV", "DBCSR_AMD_MM_KERNEL", "DBCSR_AMD_MM_HOT", "DBCSR_AMD_MM_CLASSES",
+ENV_KEYS = ("DBCSR_AMD_MM_TILE", "DBCSR_AMD_MM_TILE_WINDOW", "DBCSR_AMD_MM_TILE_RDV", "DBCSR_AMD_MM_TILE_PUB", "DBCSR_AMD_MM_TILE_PREFETCH", "DBCSR_AMD_MM_KERNEL", "DBCSR_AMD_MM_HOT", "DBCSR_AMD_MM_CLASSES",
             "DBCSR_AMD_MM_DBG", "DBCSR_AMD_MM_WG_WAVES")
 
 
@@ -61,6 +61,15 @@ def test_tile_kernel_any_window(monkeypatch, window):
     # the k window of the team is a speed knob: a window of one inner block serialises the team, none lets every wave run free
     gave_up = run(monkeypatch, {"DBCSR_AMD_MM_TILE_WINDOW": window}, MANY)
     assert gave_up == 0
+
+
+@pytest.mark.parametrize("env", [{"DBCSR_AMD_MM_TILE_PUB": "0"}, {"DBCSR_AMD_MM_TILE_PUB": "1"}, {"DBCSR_AMD_MM_TILE_PREFETCH": "1"},
+                                 {"DBCSR_AMD_MM_TILE_PREFETCH": "1", "DBCSR_AMD_MM_TILE_WINDOW": "16"}],
+                         ids=lambda e: "-".join("%s=%s" % (k[18:], v) for k, v in e.items()))
+def test_tile_kernel_store_policy_and_prefetch(monkeypatch, env):
+    # progress stores written through or left in the XCD's L2, operand blocks pulled into L2 one product earlier: speed knobs only
+    assert run(monkeypatch, env, MANY) == 0
+    run(monkeypatch, env, H2O)
 
 
 def test_tile_kernel_unpaired_fragment_reads(monkeypatch):
