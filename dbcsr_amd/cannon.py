@@ -316,6 +316,8 @@ class CannonMultiply:
                 self.rccl_ranks = dist.get_world_size()
         self.mode = mode
         self.local_first = local_first
+        self._engines = {}
+        self.last_engine = engine
         self._host = None
         self._owned = None
         world = dist.get_world_size() if dist.is_initialized() else 1
@@ -431,6 +433,18 @@ class CannonMultiply:
         bmax = max([m.data_numel for v, m in self.B_img.items() if g.b_owner(v, c) != g.rank] + [0])
         self._abuf = [torch.empty(amax, dtype=dtype, device=self.device) for _ in range(2)]
         self._bbuf = [torch.empty(bmax, dtype=dtype, device=self.device) for _ in range(2)]
+
+    def _engine(self, key):
+        """The local multiply engine for one of the multiplies of a step.  An engine keeps the plan (symbolic product, product lists,
+        launch order) of its LAST multiply and reuses it when the next one has the same index arrays (include/dbcsr_amd_mm.h: plan
+        reuse) -- which is the case for every repetition of a distributed multiply, per tick / per part of the gather schedule.  So
+        each of them gets an engine of its own; `None` is the step's first multiply (the caller's engine)."""
+        if key is None or not hasattr(self.eng, "plan_stats"):
+            return self.eng
+        e = self._engines.get(key)
+        if e is None:
+            e = self._engines[key] = type(self.eng)()
+        return e
 
     def _native_selftest(self, timeout_s=60.0):
         """One tiny ring exchange through the native transport before it is trusted with the panels; returns None or what went
@@ -562,7 +576,7 @@ class CannonMultiply:
         return works, staged
 
     def _multiply_gather(self, alpha, beta):
-        eng = self.eng
+        eng = self.last_engine = self.eng
         works, staged = self._post_all()                       # panels travel over all links ...
 
         def arrived():
@@ -588,6 +602,7 @@ class CannonMultiply:
             return Cout, counts
         # local-first: the images owned on both sides are multiplied while the rest is still in flight
         C1, cnt1 = eng.multiply_local(alpha, s1[0], s1[1], beta, self.C_in)
+        eng = self.last_engine = self._engine("gather-2")   # the second part keeps its own plan
         auto_k = getattr(eng, "_auto_kchunks", None)
         if auto_k is not None and auto_k(s2[0], 0.0) > 1:  # large A block-rows: passes over k (multiply.py)
             arrived()
@@ -709,7 +724,8 @@ class CannonMultiply:
             A = DbcsrMatrix(Ai.row_blk_size, Ai.col_blk_size, Ai.row_p, Ai.col_i, Ai.blk_p, ca, "A")
             B = DbcsrMatrix(Bi.row_blk_size, Bi.col_blk_size, Bi.row_p, Bi.col_i, Bi.blk_p, cb, "B")
             if Ai.nblks and Bi.nblks:
-                cnt = eng.accumulate(alpha, A, B, Cout)
+                te = self.last_engine = self._engine(("tick", tick))   # one plan per tick
+                cnt = te.accumulate(alpha, A, B, Cout)
                 flop += cnt.flop
                 nprod += cnt.nproducts
                 self.last_tick_flop = cnt.flop

@@ -37,2321 +37,11 @@
 #include "mm_types.h"
 #include "mm_jit.h"
 
-namespace dbcsr_amd {
-
-// ----------------------------------------------------------------------------
-// small utilities
-// ----------------------------------------------------------------------------
-template <typename T>
-struct DevBuf {
-  T* p = nullptr;
-  size_t cap = 0;
-  int ensure(size_t n) {
-    if (n <= cap) return 0;
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    cap = 0;
-    size_t want = n + n / 8 + 64;
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), want * sizeof(T));
-    if (e != hipSuccess) return check(e, "hipMalloc(workspace)", __FILE__, __LINE__);
-    cap = want;
-    return 0;
-  }
-  void release() {
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    cap = 0;
-  }
-};
-
-
-// ----------------------------------------------------------------------------
-// exclusive scan (int32 in -> TO out), three small kernels
-// ----------------------------------------------------------------------------
-constexpr int kScanThreads = 256;
-constexpr int kScanItems = 16;
-constexpr int kScanChunk = kScanThreads * kScanItems;
-
-__device__ __forceinline__ int64_t block_exclusive_scan(int64_t v, int64_t* total) {
-  __shared__ int64_t wsum[kScanThreads / 64];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  int64_t inc = v;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const int64_t t = __shfl_up(inc, off, 64);
-    if (lane >= off) inc += t;
-  }
-  if (lane == 63) wsum[w] = inc;
-  __syncthreads();
-  int64_t woff = 0, tot = 0;
-#pragma unroll
-  for (int i = 0; i < kScanThreads / 64; ++i) {
-    if (i < w) woff += wsum[i];
-    tot += wsum[i];
-  }
-  __syncthreads();
-  *total = tot;
-  return woff + inc - v;
-}
-
-__global__ void __launch_bounds__(kScanThreads) scan_reduce(const int* __restrict__ in, int64_t n, int64_t* __restrict__ partial) {
-  const int64_t base = (int64_t)blockIdx.x * kScanChunk;
-  int64_t s = 0;
-  for (int it = 0; it < kScanItems; ++it) {
-    const int64_t i = base + (int64_t)it * kScanThreads + threadIdx.x;
-    if (i < n) s += in[i];
-  }
-  int64_t tot;
-  (void)block_exclusive_scan(s, &tot);
-  if (threadIdx.x == 0) partial[blockIdx.x] = tot;
-}
-
-__global__ void __launch_bounds__(kScanThreads) scan_partials(int64_t* __restrict__ partial, int np, int64_t* __restrict__ total_out) {
-  int64_t carry = 0;
-  for (int base = 0; base < np; base += kScanThreads) {
-    const int i = base + threadIdx.x;
-    const int64_t v = i < np ? partial[i] : 0;
-    int64_t tot;
-    const int64_t ex = block_exclusive_scan(v, &tot);
-    if (i < np) partial[i] = carry + ex;
-    carry += tot;
-  }
-  if (threadIdx.x == 0 && total_out) *total_out = carry;
-}
-
-template <typename TO>
-__global__ void __launch_bounds__(kScanThreads) scan_apply(const int* __restrict__ in, int64_t n, const int64_t* __restrict__ partial,
-                                                            TO* __restrict__ out, int write_total_at_n) {
-  const int64_t base = (int64_t)blockIdx.x * kScanChunk;
-  // thread t owns kScanItems consecutive items
-  const int64_t first = base + (int64_t)threadIdx.x * kScanItems;
-  int v[kScanItems];
-  int64_t s = 0;
-#pragma unroll
-  for (int it = 0; it < kScanItems; ++it) {
-    const int64_t i = first + it;
-    v[it] = i < n ? in[i] : 0;
-    s += v[it];
-  }
-  int64_t tot;
-  int64_t ex = block_exclusive_scan(s, &tot) + partial[blockIdx.x];
-#pragma unroll
-  for (int it = 0; it < kScanItems; ++it) {
-    const int64_t i = first + it;
-    if (i < n) out[i] = (TO)ex;
-    ex += v[it];
-    if (write_total_at_n && i == n - 1) out[n] = (TO)ex;
-  }
-}
-
-// ----------------------------------------------------------------------------
-// symbolic kernels
-// ----------------------------------------------------------------------------
-
-// one wavefront per block row: set bit (row, col) for every block
-__global__ void __launch_bounds__(256) bitmap_from_index(const int* __restrict__ row_p, const int* __restrict__ col_i, int nbr, int W,
-                                                         uint32_t* __restrict__ bm) {
-  const int lane = threadIdx.x & 63;
-  const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (row >= nbr) return;
-  for (int b = row_p[row] + lane; b < row_p[row + 1]; b += 64) {
-    const int j = col_i[b];
-    atomicOr(&bm[(size_t)row * W + (j >> 5)], 1u << (j & 31));
-  }
-}
-
-// Product matrix with symmetry, index in canonical (checkerboard) form: the local multiply computes block (i, j) only when it
-// is the stored one of the pair (i, j) / (j, i) (dbcsr_mm_csr.F:280-292, checker_tr of dbcsr_dist_operations.F:65-75): the
-// diagonal, (i + j) even above it, (i + j) odd below it.  Bits of word w of row i that may receive products:
-__device__ __forceinline__ uint32_t canonical_bits(int i, int w) {
-  const uint32_t even = (i & 1) ? 0xAAAAAAAAu : 0x55555555u;      // columns j of this word with (i + j) even (32 w is even)
-  const int d = i - 32 * w;                                       // position of the diagonal relative to the word
-  const uint32_t upper = d <= 0 ? 0xFFFFFFFFu : (d >= 32 ? 0u : ~((1u << d) - 1u));  // columns j >= i
-  return (even & upper) | (~even & ~upper);
-}
-
-// thread per (row i, word w)
-__global__ void __launch_bounds__(256) c_bitmap(const int* __restrict__ a_row_p, const int* __restrict__ a_col_i,
-                                                const uint32_t* __restrict__ b_bm, const uint32_t* __restrict__ cin_bm, int nbr, int W,
-                                                int retain, int canonical, uint32_t* __restrict__ c_bm) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (int64_t)nbr * W) return;
-  const int i = (int)(t / W), w = (int)(t % W);
-  uint32_t v = 0u;
-  if (!retain) {
-    for (int ab = a_row_p[i]; ab < a_row_p[i + 1]; ++ab) v |= b_bm[(size_t)a_col_i[ab] * W + w];
-    if (canonical) v &= canonical_bits(i, w);
-  }
-  c_bm[t] = v | (cin_bm ? cin_bm[t] : 0u);
-}
-
-// one wavefront per row: exclusive prefix of popcounts inside the row + row total
-__global__ void __launch_bounds__(256) row_prefix(const uint32_t* __restrict__ bm, int nbr, int W, int* __restrict__ pre,
-                                                  int* __restrict__ row_nnz) {
-  const int lane = threadIdx.x & 63;
-  const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (row >= nbr) return;
-  int carry = 0;
-  for (int base = 0; base < W; base += 64) {
-    const int w = base + lane;
-    const int c = w < W ? __popc(bm[(size_t)row * W + w]) : 0;
-    int inc = c;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const int t = __shfl_up(inc, off, 64);
-      if (lane >= off) inc += t;
-    }
-    if (w < W) pre[(size_t)row * W + w] = carry + inc - c;
-    carry += __shfl(inc, 63, 64);
-  }
-  if (lane == 0 && row_nnz) row_nnz[row] = carry;
-}
-
-// thread per (row i, word w): per C block product count, block size, flop
-__global__ void __launch_bounds__(256) count_products(const int* __restrict__ a_row_p, const int* __restrict__ a_col_i,
-                                                      const int* __restrict__ rs, const int* __restrict__ ks, const int* __restrict__ cs,
-                                                      const uint32_t* __restrict__ b_bm, const uint32_t* __restrict__ c_bm,
-                                                      const int* __restrict__ c_pre, const int* __restrict__ c_row_p, int nbr, int W,
-                                                      int* __restrict__ prod_cnt, int* __restrict__ blk_nze,
-                                                      unsigned long long* __restrict__ flop_out) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  unsigned long long flop = 0;
-  if (t < (int64_t)nbr * W) {
-    const int i = (int)(t / W), w = (int)(t % W);
-    uint32_t v = c_bm[t];
-    if (v) {
-      const int m = rs[i];
-      int cb = c_row_p[i] + c_pre[t];
-      const int a0 = a_row_p[i], a1 = a_row_p[i + 1];
-      while (v) {
-        const int bit = __ffs(v) - 1;
-        v &= v - 1;
-        const int n = cs[32 * w + bit];
-        int cnt = 0;
-        long long ksum = 0;
-        for (int ab = a0; ab < a1; ++ab) {
-          const int k = a_col_i[ab];
-          if ((b_bm[(size_t)k * W + w] >> bit) & 1u) {
-            ++cnt;
-            ksum += ks[k];
-          }
-        }
-        prod_cnt[cb] = cnt;
-        blk_nze[cb] = m * n;
-        flop += 2ull * (unsigned long long)m * n * ksum;
-        ++cb;
-      }
-    }
-  }
-  // block reduce, one atomic per workgroup
-  __shared__ unsigned long long red[4];
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) flop += __shfl_down(flop, off, 64);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = flop;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned long long s = red[0] + red[1] + red[2] + red[3];
-    if (s) atomicAdd(flop_out, s);
-  }
-}
-
-// thread per (row i, word w): emit C index, descriptors and product lists
-__global__ void __launch_bounds__(256)
-fill_products(const int* __restrict__ a_row_p, const int* __restrict__ a_col_i, const int64_t* __restrict__ a_blk_p,
-              const int* __restrict__ b_row_p, const int64_t* __restrict__ b_blk_p, const int* __restrict__ cin_row_p,
-              const int64_t* __restrict__ cin_blk_p, const int* __restrict__ rs, const int* __restrict__ ks,
-              const int* __restrict__ cs, const uint32_t* __restrict__ b_bm, const int* __restrict__ b_pre,
-              const uint32_t* __restrict__ cin_bm, const int* __restrict__ cin_pre, const uint32_t* __restrict__ c_bm,
-              const int* __restrict__ c_pre, const int* __restrict__ c_row_p, const int64_t* __restrict__ prod_start,
-              const int64_t* __restrict__ c_blk_p_ws, int nbr, int W, int* __restrict__ c_col_i, int64_t* __restrict__ c_blk_p,
-              Desc* __restrict__ descs, Entry* __restrict__ entries) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (int64_t)nbr * W) return;
-  const int i = (int)(t / W), w = (int)(t % W);
-  uint32_t v = c_bm[t];
-  if (!v) return;
-  const int m = rs[i];
-  int cb = c_row_p[i] + c_pre[t];
-  const int a0 = a_row_p[i], a1 = a_row_p[i + 1];
-  const uint32_t cinw = cin_bm ? cin_bm[t] : 0u;
-  while (v) {
-    const int bit = __ffs(v) - 1;
-    v &= v - 1;
-    const uint32_t below = (1u << bit) - 1u;
-    const int j = 32 * w + bit;
-    int64_t p = prod_start[cb];
-    int cnt = 0;
-    for (int ab = a0; ab < a1; ++ab) {
-      const int k = a_col_i[ab];
-      const uint32_t bw = b_bm[(size_t)k * W + w];
-      if ((bw >> bit) & 1u) {
-        const int bidx = b_row_p[k] + b_pre[(size_t)k * W + w] + __popc(bw & below);
-        entries[p + cnt] = Entry::make(a_blk_p[ab], b_blk_p[bidx], ks[k]);
-        ++cnt;
-      }
-    }
-    Desc d;
-    d.c_off = c_blk_p_ws[cb];
-    d.cin_off = -1;
-    if ((cinw >> bit) & 1u) d.cin_off = cin_blk_p[cin_row_p[i] + cin_pre[t] + __popc(cinw & below)];
-    d.prod_start = p;
-    d.prod_cnt = cnt;
-    d.m = (int16_t)m;
-    d.n = (int16_t)cs[j];
-    descs[cb] = d;
-    c_col_i[cb] = j;
-    c_blk_p[cb] = d.c_off;
-    ++cb;
-  }
-}
-
-
-
-// ---- on-the-fly filtering (dbcsr_mm_csr.F:276, dbcsr_mm_cannon.F:1040-1113) ------------------------
-// A product A(i,k)*B(k,j) is skipped when ||A(i,k)||^2 * ||alpha B(k,j)||^2 < (eps / max(1, #blocks in A row i))^2,
-// all in single precision as the reference (norms are fp32 values of fp64 sums).  a_norms == nullptr: no filter.
-struct FilterArgs {
-  const float* a_norms;
-  const float* b_norms;
-  float eps;
-};
-
-__device__ __forceinline__ float row_filter_eps(const FilterArgs& F, int nblks_in_a_row) {
-  const float e = F.eps / (float)(nblks_in_a_row > 1 ? nblks_in_a_row : 1);
-  return e * e;
-}
-
-// one wavefront per block row: norms[b] = (float) sum (scale * x)^2 over block b
-template <typename T>
-__global__ void __launch_bounds__(256) bcsr_block_norms(const int* __restrict__ row_p, const int* __restrict__ col_i,
-                                                        const int64_t* __restrict__ blk_p, const T* __restrict__ data,
-                                                        const int* __restrict__ rs, const int* __restrict__ cs, int nbr, int S, double scale,
-                                                        float* __restrict__ norms, double* __restrict__ norms64) {
-  // S waves share a block row (wave s takes the blocks b = s mod S): a long row is not one wave's serial stream
-  const int lane = threadIdx.x & 63;
-  const int64_t wv = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int row = (int)(wv / S), sub = (int)(wv % S);
-  if (row >= nbr) return;
-  const int m = rs[row];
-  for (int b = row_p[row] + sub; b < row_p[row + 1]; b += S) {
-    const int ne = m * cs[col_i[b]];
-    const T* d = data + blk_p[b];
-    double s = 0.0;
-    for (int e = lane; e < ne; e += 64) {
-      const double x = scale * (double)d[e];
-      s += x * x;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    if (lane == 0) {
-      if (norms) norms[b] = (float)s;
-      if (norms64) norms64[b] = s;
-    }
-  }
-}
-
-// C pattern under filtering: one lane per (row i, column j) candidate, bit set iff C_in has the block or at
-// least one product survives the filter (a new C block is only created by a product that is executed)
-__global__ void __launch_bounds__(256) c_bitmap_filtered(const int* __restrict__ a_row_p, const int* __restrict__ a_col_i,
-                                                         const int* __restrict__ b_row_p, const uint32_t* __restrict__ b_bm,
-                                                         const int* __restrict__ b_pre, const uint32_t* __restrict__ cin_bm, int nbr,
-                                                         int nbc, int W, int nJ, int retain, int canonical, FilterArgs F,
-                                                         uint32_t* __restrict__ c_bm) {
-  const int lane = threadIdx.x & 63;
-  const int64_t wv = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (wv >= (int64_t)nbr * nJ) return;
-  const int i = (int)(wv / nJ), jb = (int)(wv % nJ);
-  const int j = jb * 64 + lane, w = j >> 5, bit = j & 31;
-  bool any = false;
-  if (!retain && j < nbc && !(canonical && !((canonical_bits(i, w) >> bit) & 1u))) {
-    const int a0 = a_row_p[i], a1 = a_row_p[i + 1];
-    const float reps = row_filter_eps(F, a1 - a0);
-    const uint32_t below = (1u << bit) - 1u;
-    for (int ab = a0; ab < a1; ++ab) {
-      const int k = a_col_i[ab];
-      const uint32_t bw = b_bm[(size_t)k * W + w];
-      if ((bw >> bit) & 1u) {
-        const int bidx = b_row_p[k] + b_pre[(size_t)k * W + w] + __popc(bw & below);
-        if (!(F.a_norms[ab] * F.b_norms[bidx] < reps)) any = true;
-      }
-    }
-  }
-  const unsigned long long mask = __ballot(any);
-  if (lane == 0) {
-    const int w0 = 2 * jb;
-    c_bm[(size_t)i * W + w0] = (uint32_t)mask | (cin_bm ? cin_bm[(size_t)i * W + w0] : 0u);
-    if (w0 + 1 < W) c_bm[(size_t)i * W + w0 + 1] = (uint32_t)(mask >> 32) | (cin_bm ? cin_bm[(size_t)i * W + w0 + 1] : 0u);
-  }
-}
-
-
-// ---- dense-grid variants: one lane per (row i, column j) candidate ------------
-// The per-word kernels above expose only nbr*W threads, each walking up to 32 C
-// blocks x |A-row| serially (v1 profile: 1.6 + 4.0 ms for config 2).  When C is not
-// extremely sparse it is much faster to give every candidate (i, j) its own lane:
-// a wavefront covers 64 consecutive columns of one row, so the walk over A's row
-// is wave-uniform (scalar loads) and the B bitmap words are two broadcast loads.
-__global__ void __launch_bounds__(256) count_products_grid(const int* __restrict__ a_row_p, const int* __restrict__ a_col_i,
-                                                           const int* __restrict__ rs, const int* __restrict__ ks,
-                                                           const int* __restrict__ cs, const uint32_t* __restrict__ b_bm,
-                                                           const uint32_t* __restrict__ c_bm, const int* __restrict__ c_pre,
-                                                           const int* __restrict__ c_row_p, int nbr, int nbc, int W, int nJ,
-                                                           int* __restrict__ prod_cnt, int* __restrict__ blk_nze,
-                                                           unsigned long long* __restrict__ flop_out, const int* __restrict__ b_row_p,
-                                                           const int* __restrict__ b_pre, FilterArgs F) {
-  const int lane = threadIdx.x & 63;
-  const int64_t wv = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  unsigned long long flop = 0;
-  if (wv < (int64_t)nbr * nJ) {
-    const int i = (int)(wv / nJ), jb = (int)(wv % nJ);
-    const int j = jb * 64 + lane, w = j >> 5, bit = j & 31;
-    const uint32_t cw = w < W ? c_bm[(size_t)i * W + w] : 0u;
-    const bool present = (cw >> bit) & 1u;
-    if (__ballot(present)) {
-      const int a0 = a_row_p[i], a1 = a_row_p[i + 1];
-      const float reps = F.a_norms ? row_filter_eps(F, a1 - a0) : 0.0f;
-      int cnt = 0;
-      long long ksum = 0;
-      for (int ab = a0; ab < a1; ++ab) {
-        const int k = a_col_i[ab];
-        const uint32_t bw = w < W ? b_bm[(size_t)k * W + w] : 0u;
-        if ((bw >> bit) & 1u) {
-          if (F.a_norms) {
-            const int bidx = b_row_p[k] + b_pre[(size_t)k * W + w] + __popc(bw & ((1u << bit) - 1u));
-            if (F.a_norms[ab] * F.b_norms[bidx] < reps) continue;
-          }
-          ++cnt;
-          ksum += ks[k];
-        }
-      }
-      if (present) {
-        const int cb = c_row_p[i] + c_pre[(size_t)i * W + w] + __popc(cw & ((1u << bit) - 1u));
-        const int m = rs[i], n = cs[j];
-        prod_cnt[cb] = cnt;
-        blk_nze[cb] = m * n;
-        flop = 2ull * (unsigned long long)m * n * (unsigned long long)ksum;
-      }
-    }
-  }
-  __shared__ unsigned long long red[4];
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) flop += __shfl_down(flop, off, 64);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = flop;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned long long t = red[0] + red[1] + red[2] + red[3];
-    if (t) atomicAdd(flop_out, t);
-  }
-}
-
-__global__ void __launch_bounds__(256)
-fill_products_grid(const int* __restrict__ a_row_p, const int* __restrict__ a_col_i, const int64_t* __restrict__ a_blk_p,
-                   const int* __restrict__ b_row_p, const int64_t* __restrict__ b_blk_p, const int* __restrict__ cin_row_p,
-                   const int64_t* __restrict__ cin_blk_p, const int* __restrict__ rs, const int* __restrict__ ks,
-                   const int* __restrict__ cs, const uint32_t* __restrict__ b_bm, const int* __restrict__ b_pre,
-                   const uint32_t* __restrict__ cin_bm, const int* __restrict__ cin_pre, const uint32_t* __restrict__ c_bm,
-                   const int* __restrict__ c_pre, const int* __restrict__ c_row_p, const int64_t* __restrict__ prod_start,
-                   const int64_t* __restrict__ c_blk_p_ws, int nbr, int nbc, int W, int nJ, int* __restrict__ c_col_i,
-                   int64_t* __restrict__ c_blk_p, Desc* __restrict__ descs, Entry* __restrict__ entries, FilterArgs F) {
-  const int lane = threadIdx.x & 63;
-  const int64_t wv = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (wv >= (int64_t)nbr * nJ) return;
-  const int i = (int)(wv / nJ), jb = (int)(wv % nJ);
-  const int j = jb * 64 + lane, w = j >> 5, bit = j & 31;
-  const uint32_t cw = w < W ? c_bm[(size_t)i * W + w] : 0u;
-  const bool present = (cw >> bit) & 1u;
-  if (!__ballot(present)) return;
-  const uint32_t below = (1u << bit) - 1u;
-  const int cb = present ? c_row_p[i] + c_pre[(size_t)i * W + w] + __popc(cw & below) : 0;
-  const int64_t p0 = present ? prod_start[cb] : 0;
-  const int a0 = a_row_p[i], a1 = a_row_p[i + 1];
-  const float reps = F.a_norms ? row_filter_eps(F, a1 - a0) : 0.0f;
-  int cnt = 0;
-  // A's row is walked in chunks of 64 blocks: first a cheap pass that only tests the B bitmap and records the
-  // hits of this lane in a 64-bit mask, then the expensive part (index look-ups, entry store) runs per HIT -- about
-  // fill x 64 trips per chunk instead of 64 (v4: 0.85 ms for config 2 with the one-pass loop).
-  for (int base = a0; base < a1; base += 64) {
-    const int top = min(base + 64, a1);
-    unsigned long long hits = 0ull;
-    for (int ab = base; ab < top; ++ab) {
-      const int k = a_col_i[ab];
-      const uint32_t bw = w < W ? b_bm[(size_t)k * W + w] : 0u;
-      if (present && ((bw >> bit) & 1u)) hits |= 1ull << (ab - base);
-    }
-    while (hits) {
-      const int ab = base + __ffsll((long long)hits) - 1;
-      hits &= hits - 1;
-      const int k = a_col_i[ab];
-      const uint32_t bw = b_bm[(size_t)k * W + w];
-      const int bidx = b_row_p[k] + b_pre[(size_t)k * W + w] + __popc(bw & below);
-      if (F.a_norms && F.a_norms[ab] * F.b_norms[bidx] < reps) continue;
-      entries[p0 + cnt] = Entry::make(a_blk_p[ab], b_blk_p[bidx], ks[k]);
-      ++cnt;
-    }
-  }
-  if (present) {
-    Desc d;
-    d.c_off = c_blk_p_ws[cb];
-    d.cin_off = -1;
-    if (cin_bm) {
-      const uint32_t cinw = cin_bm[(size_t)i * W + w];
-      if ((cinw >> bit) & 1u) d.cin_off = cin_blk_p[cin_row_p[i] + cin_pre[(size_t)i * W + w] + __popc(cinw & below)];
-    }
-    d.prod_start = p0;
-    d.prod_cnt = cnt;
-    d.m = (int16_t)rs[i];
-    d.n = (int16_t)cs[j];
-    descs[cb] = d;
-    c_col_i[cb] = j;
-    c_blk_p[cb] = d.c_off;
-  }
-}
-
-
-// C pattern under filtering, product-driven (sparse C): one wave per block row i ORs the bit of every product that passes the
-// on-the-fly filter into row i of c_bm, which starts as C_in's pattern (the candidate-driven c_bitmap_filtered tests
-// nbr x nbc x |A row| combinations)
-__global__ void __launch_bounds__(256) c_bitmap_rows_filtered(const int* __restrict__ a_row_p, const int* __restrict__ a_col_i,
-                                                              const int* __restrict__ b_row_p, const int* __restrict__ b_col_i, int nbr, int W,
-                                                              int canonical, FilterArgs F, uint32_t* __restrict__ c_bm) {
-  const int lane = threadIdx.x & 63;
-  const int i = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-  if (i >= nbr) return;
-  const float reps = row_filter_eps(F, a_row_p[i + 1] - a_row_p[i]);
-  for (int ab = a_row_p[i]; ab < a_row_p[i + 1]; ++ab) {
-    const int k = a_col_i[ab];
-    for (int bb = b_row_p[k] + lane; bb < b_row_p[k + 1]; bb += 64) {
-      if (F.a_norms[ab] * F.b_norms[bb] < reps) continue;
-      const int j = b_col_i[bb], w = j >> 5, bit = j & 31;
-      if (canonical && !((canonical_bits(i, w) >> bit) & 1u)) continue;
-      atomicOr(&c_bm[(size_t)i * W + w], 1u << bit);
-    }
-  }
-}
-
-// ---- product-driven variants for a sparse C (BASELINE config 4: C 43 % full, 1.3 products per C block) --------------------------
-// The grid kernels test every (row, column) candidate against every block of A's row: nbr x nbc x |A row| bitmap tests
-// (config 4: 1.9 G for 18.6 M products; count 2.0 ms + fill 2.7 ms = 15 % of the multiply).  Here ONE WAVE owns a block row i of A
-// (hence of C) and walks its blocks A(i, k) in ascending k; the lanes take the blocks B(k, j) of row k, look up the C block by
-// bitmap rank and bump its counter.  Work is proportional to the number of products.  Inside a step all lanes hit different C
-// blocks, steps are sequential and no other wave touches row i, so the list slots handed out by the atomic in the fill pass
-// follow ascending k: same lists as the other kernels.
-__global__ void __launch_bounds__(256) count_products_rows(const int* __restrict__ a_row_p, const int* __restrict__ a_col_i,
-                                                           const int* __restrict__ rs, const int* __restrict__ ks, const int* __restrict__ cs,
-                                                           const int* __restrict__ b_row_p, const int* __restrict__ b_col_i,
-                                                           const uint32_t* __restrict__ c_bm, const int* __restrict__ c_pre,
-                                                           const int* __restrict__ c_row_p, int nbr, int W, int* __restrict__ prod_cnt,
-                                                           unsigned long long* __restrict__ flop_out, FilterArgs F) {
-  const int lane = threadIdx.x & 63;
-  const int i = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-  unsigned long long flop = 0;
-  if (i < nbr) {
-    const unsigned long long m = (unsigned long long)rs[i];
-    const float reps = F.a_norms ? row_filter_eps(F, a_row_p[i + 1] - a_row_p[i]) : 0.0f;
-    for (int ab = a_row_p[i]; ab < a_row_p[i + 1]; ++ab) {
-      const int k = a_col_i[ab];
-      const unsigned long long kk = (unsigned long long)ks[k];
-      for (int bb = b_row_p[k] + lane; bb < b_row_p[k + 1]; bb += 64) {
-        if (F.a_norms && F.a_norms[ab] * F.b_norms[bb] < reps) continue;  // on-the-fly filter
-        const int j = b_col_i[bb], w = j >> 5, bit = j & 31;
-        const uint32_t cw = c_bm[(size_t)i * W + w];
-        if (!((cw >> bit) & 1u)) continue;  // retain_sparsity / product matrix with symmetry: no such C block
-        const int cb = c_row_p[i] + c_pre[(size_t)i * W + w] + __popc(cw & ((1u << bit) - 1u));
-        atomicAdd(&prod_cnt[cb], 1);
-        flop += 2ull * m * (unsigned long long)cs[j] * kk;
-      }
-    }
-  }
-  __shared__ unsigned long long red[4];
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) flop += __shfl_down(flop, off, 64);
-  if (lane == 0) red[threadIdx.x >> 6] = flop;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned long long t = red[0] + red[1] + red[2] + red[3];
-    if (t) atomicAdd(flop_out, t);
-  }
-}
-
-__global__ void __launch_bounds__(256) fill_products_rows(const int* __restrict__ a_row_p, const int* __restrict__ a_col_i,
-                                                          const int64_t* __restrict__ a_blk_p, const int* __restrict__ ks,
-                                                          const int* __restrict__ b_row_p, const int* __restrict__ b_col_i,
-                                                          const int64_t* __restrict__ b_blk_p, const uint32_t* __restrict__ c_bm,
-                                                          const int* __restrict__ c_pre, const int* __restrict__ c_row_p,
-                                                          const int64_t* __restrict__ prod_start, int nbr, int W, int* __restrict__ fill_cnt,
-                                                          Entry* __restrict__ entries, FilterArgs F) {
-  const int lane = threadIdx.x & 63;
-  const int i = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-  if (i >= nbr) return;
-  const float reps = F.a_norms ? row_filter_eps(F, a_row_p[i + 1] - a_row_p[i]) : 0.0f;
-  for (int ab = a_row_p[i]; ab < a_row_p[i + 1]; ++ab) {
-    const int k = a_col_i[ab];
-    const int kk = ks[k];
-    const int64_t a_off = a_blk_p[ab];
-    for (int bb = b_row_p[k] + lane; bb < b_row_p[k + 1]; bb += 64) {
-      if (F.a_norms && F.a_norms[ab] * F.b_norms[bb] < reps) continue;
-      const int j = b_col_i[bb], w = j >> 5, bit = j & 31;
-      const uint32_t cw = c_bm[(size_t)i * W + w];
-      if (!((cw >> bit) & 1u)) continue;
-      const int cb = c_row_p[i] + c_pre[(size_t)i * W + w] + __popc(cw & ((1u << bit) - 1u));
-      const int slot = atomicAdd(&fill_cnt[cb], 1);
-      entries[prod_start[cb] + slot] = Entry::make(a_off, b_blk_p[bb], kk);
-    }
-  }
-}
-
-// thread per (row, bitmap word): element counts of the C blocks in index order (count pass of the rows variant) ...
-__global__ void __launch_bounds__(256) block_sizes_rows(const uint32_t* __restrict__ c_bm, const int* __restrict__ c_pre,
-                                                        const int* __restrict__ c_row_p, const int* __restrict__ rs, const int* __restrict__ cs,
-                                                        int nbr, int W, int* __restrict__ blk_nze) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (int64_t)nbr * W) return;
-  const int i = (int)(t / W), w = (int)(t % W);
-  uint32_t v = c_bm[t];
-  int cb = c_row_p[i] + c_pre[t];
-  while (v) {
-    const int bit = __ffs(v) - 1;
-    v &= v - 1;
-    blk_nze[cb++] = rs[i] * cs[32 * w + bit];
-  }
-}
-
-// ... and their descriptors / index entries (fill pass)
-__global__ void __launch_bounds__(256)
-finish_descs_rows(const int* __restrict__ cin_row_p, const int64_t* __restrict__ cin_blk_p, const int* __restrict__ rs,
-                  const int* __restrict__ cs, const uint32_t* __restrict__ cin_bm, const int* __restrict__ cin_pre,
-                  const uint32_t* __restrict__ c_bm, const int* __restrict__ c_pre, const int* __restrict__ c_row_p,
-                  const int64_t* __restrict__ c_blk_p_ws, const int64_t* __restrict__ prod_start, const int* __restrict__ prod_cnt, int nbr,
-                  int W, int* __restrict__ c_col_i, int64_t* __restrict__ c_blk_p, Desc* __restrict__ descs) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (int64_t)nbr * W) return;
-  const int i = (int)(t / W), w = (int)(t % W);
-  uint32_t v = c_bm[t];
-  if (!v) return;
-  int cb = c_row_p[i] + c_pre[t];
-  const uint32_t cinw = cin_bm ? cin_bm[t] : 0u;
-  while (v) {
-    const int bit = __ffs(v) - 1;
-    v &= v - 1;
-    const uint32_t below = (1u << bit) - 1u;
-    const int j = 32 * w + bit;
-    Desc d;
-    d.c_off = c_blk_p_ws[cb];
-    d.cin_off = -1;
-    if ((cinw >> bit) & 1u) d.cin_off = cin_blk_p[cin_row_p[i] + cin_pre[t] + __popc(cinw & below)];
-    d.prod_start = prod_start[cb];
-    d.prod_cnt = prod_cnt[cb];
-    d.m = (int16_t)rs[i];
-    d.n = (int16_t)cs[j];
-    descs[cb] = d;
-    c_col_i[cb] = j;
-    c_blk_p[cb] = d.c_off;
-    ++cb;
-  }
-}
-
-// ---- C structure only (multi-tick / Cannon use): emit the sorted index of the pattern
-// computed by the symbolic phase and describe where each block's initial value comes from.
-__global__ void __launch_bounds__(256)
-emit_index(const int* __restrict__ cin_row_p, const int64_t* __restrict__ cin_blk_p, const int* __restrict__ rs,
-           const int* __restrict__ cs, const uint32_t* __restrict__ cin_bm, const int* __restrict__ cin_pre,
-           const uint32_t* __restrict__ c_bm, const int* __restrict__ c_pre, const int* __restrict__ c_row_p,
-           const int64_t* __restrict__ c_blk_p_ws, int nbr, int W, int* __restrict__ c_col_i, int64_t* __restrict__ c_blk_p,
-           Desc* __restrict__ descs) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (int64_t)nbr * W) return;
-  const int i = (int)(t / W), w = (int)(t % W);
-  uint32_t v = c_bm[t];
-  if (!v) return;
-  int cb = c_row_p[i] + c_pre[t];
-  const uint32_t cinw = cin_bm ? cin_bm[t] : 0u;
-  while (v) {
-    const int bit = __ffs(v) - 1;
-    v &= v - 1;
-    const uint32_t below = (1u << bit) - 1u;
-    const int j = 32 * w + bit;
-    Desc d;
-    d.c_off = c_blk_p_ws[cb];
-    d.cin_off = -1;
-    if ((cinw >> bit) & 1u) d.cin_off = cin_blk_p[cin_row_p[i] + cin_pre[t] + __popc(cinw & below)];
-    d.prod_start = 0;
-    d.prod_cnt = 0;
-    d.m = (int16_t)rs[i];
-    d.n = (int16_t)cs[j];
-    descs[cb] = d;
-    c_col_i[cb] = j;
-    c_blk_p[cb] = d.c_off;
-    ++cb;
-  }
-}
-
-// one wavefront per C block: C_out = beta * C_in where the block existed, 0 elsewhere
-template <typename T>
-__global__ void __launch_bounds__(256) init_c_blocks(const Desc* __restrict__ descs, int64_t nblk, T* __restrict__ c_out,
-                                                     const T* __restrict__ c_in, T beta) {
-  const int lane = threadIdx.x & 63;
-  const int64_t cb = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (cb >= nblk) return;
-  const Desc d = descs[cb];
-  const int ne = (int)d.m * (int)d.n;
-  T* C = c_out + d.c_off;
-  if (d.cin_off >= 0) {
-    const T* Ci = c_in + d.cin_off;
-    for (int e = lane; e < ne; e += 64) C[e] = beta * Ci[e];
-  } else {
-    for (int e = lane; e < ne; e += 64) C[e] = (T)0;
-  }
-}
-
-// ----------------------------------------------------------------------------
-// processing order of the C blocks (speed only; results do not depend on it)
-//
-// v2 measurement (profiles/r01_v2_*): with C swept row by row every B block is
-// fetched from HBM once per A block-row that needs it (L2 miss rate 50 %,
-// ~127 GB of HBM reads for 1.7 GB of operands, kernel HBM-bound at 5.5 TB/s).
-// Order used instead: C is swept in COLUMN PANELS narrow enough that the B panel
-// (all rows x panel columns) stays resident in the 256 MB Infinity Cache; inside
-// a panel, block row i belongs to XCD (i mod 8), so its A block-row is fetched
-// into exactly one private L2 and reused by all C blocks of that row-panel.
-// order[] holds, for each XCD, its (panel-major, row-minor) list of C block
-// indices, padded with -1 to a common length so that the contiguous workgroup
-// ranges xcd_remap() hands to each XCD coincide with these lists.
-// ----------------------------------------------------------------------------
-// A key is (XCD x, panel p, row group g): the RG block rows i = 8 (g RG + t) + x, t < RG, restricted to panel p.
-// The rows of a group are walked TOGETHER, column by column, so that a B block fetched for C(i,j) is still in
-// L2 when C(i',j) of another row of the group needs it (142 (1 - 0.9^RG) distinct B blocks per column instead
-// of 14.2 RG); RG is chosen so that the group's A block-rows fit the XCD's 4 MB L2 together.
-// key = (x * NP + p) * NG + g ; cnt[key] = number of C blocks of the group inside the panel
-__device__ __forceinline__ int panel_rank(const int* __restrict__ c_pre, const int* __restrict__ row_nnz, int i, int W, int w) {
-  return w < W ? c_pre[(size_t)i * W + w] : row_nnz[i];  // C blocks of row i left of bitmap word w
-}
-
-__global__ void __launch_bounds__(256) order_count(const int* __restrict__ c_pre, const int* __restrict__ row_nnz, int nbr, int W, int PW,
-                                                   int NP, int NG, int RG, int* __restrict__ cnt) {
-  const int key = blockIdx.x * blockDim.x + threadIdx.x;
-  if (key >= 8 * NP * NG) return;
-  const int g = key % NG, p = (key / NG) % NP, x = key / (NG * NP);
-  int c = 0;
-  for (int t = 0; t < RG; ++t) {
-    const int i = 8 * (g * RG + t) + x;
-    if (i < nbr) c += panel_rank(c_pre, row_nnz, i, W, (p + 1) * PW) - panel_rank(c_pre, row_nnz, i, W, p * PW);
-  }
-  cnt[key] = c;
-}
-
-// thread per (row i, bitmap word w): position of each C block in the order of its XCD
-__global__ void __launch_bounds__(256) order_fill(const uint32_t* __restrict__ c_bm, const int* __restrict__ c_pre,
-                                                  const int* __restrict__ row_nnz, const int* __restrict__ c_row_p,
-                                                  const int64_t* __restrict__ base, int nbr, int W, int PW, int NP, int NG, int RG,
-                                                  int64_t len, int* __restrict__ order) {
-  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (tid >= (int64_t)nbr * W) return;
-  const int i = (int)(tid / W), w = (int)(tid % W);
-  uint32_t v = c_bm[tid];
-  if (!v) return;
-  const int x = i & 7, r = i >> 3, g = r / RG, t = r % RG, p = w / PW;
-  const int key = (x * NP + p) * NG + g;
-  const int64_t dst0 = (int64_t)x * len + (base[key] - base[(size_t)x * NP * NG]);
-  const int w0 = p * PW;
-  int cb = c_row_p[i] + c_pre[tid];
-  while (v) {
-    const int bit = __ffs(v) - 1;
-    v &= v - 1;
-    const uint32_t below = (1u << bit) - 1u;
-    // blocks of the group that come before (column j, row slot t): all blocks of the group's rows with a smaller
-    // column (inside the panel), plus the rows before t that own column j
-    int before = 0;
-    for (int tt = 0; tt < RG; ++tt) {
-      const int ii = 8 * (g * RG + tt) + x;
-      if (ii >= nbr) break;
-      const uint32_t ww = c_bm[(size_t)ii * W + w];
-      before += c_pre[(size_t)ii * W + w] + __popc(ww & below) - panel_rank(c_pre, row_nnz, ii, W, w0);
-      if (tt < t) before += (ww >> bit) & 1u;
-    }
-    order[dst0 + before] = cb;
-    ++cb;
-  }
-}
-
-// per-XCD totals -> common padded length (multiple of 4), written to out[0]
-__global__ void order_len(const int64_t* __restrict__ base, int64_t total, int NP, int NG, int64_t* __restrict__ out) {
-  int64_t mx = 0;
-  for (int x = 0; x < 8; ++x) {
-    const int64_t b0 = base[(size_t)x * NP * NG];
-    const int64_t b1 = x < 7 ? base[(size_t)(x + 1) * NP * NG] : total;
-    mx = b1 - b0 > mx ? b1 - b0 : mx;
-  }
-  out[0] = (mx + 3) & ~(int64_t)3;
-}
-
-// ----------------------------------------------------------------------------
-// numeric kernels
-// ----------------------------------------------------------------------------
-template <int MA, int NC>
-__device__ __forceinline__ void cblock_f64(const Desc& d, const Entry* __restrict__ entries, const double* __restrict__ a_data,
-                                           const double* __restrict__ b_data, double* __restrict__ c_out,
-                                           const double* __restrict__ c_in, double alpha, double beta, const LaneMap& L, int row0,
-                                           int col0) {
-  double acc[MA][NC];
-#pragma unroll
-  for (int a = 0; a < MA; ++a)
-#pragma unroll
-    for (int c = 0; c < NC; ++c) acc[a][c] = 0.0;
-  const int m = d.m, n = d.n;
-  const Entry* e = entries + d.prod_start;
-  for (int p = 0; p < d.prod_cnt; ++p) {
-    const uint64_t ao = e[p].a_off(), bo = e[p].b_off();
-    block_product_f64<MA, NC, false>(acc, a_data + ao, b_data + bo, m, n, e[p].ks(), L, row0, col0);
-  }
-  double* C = c_out + d.c_off;
-  const bool has_in = d.cin_off >= 0;
-  const double* Ci = c_in + (has_in ? d.cin_off : 0);
-#pragma unroll
-  for (int a = 0; a < MA; ++a)
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      const int row = row0 + 8 * a + L.rowd, col = col0 + 8 * c + L.coll;
-      if (row < m && col < n) {
-        double v = alpha * acc[a][c];
-        if (has_in) v += beta * Ci[row + (size_t)m * col];
-        C[row + (size_t)m * col] = v;
-      }
-    }
-}
-
-__global__ void __launch_bounds__(256) mm_numeric_f64(const Desc* __restrict__ descs, int64_t nblk, const Entry* __restrict__ entries,
-                                                      const double* __restrict__ a_data, const double* __restrict__ b_data,
-                                                      double* __restrict__ c_out, const double* __restrict__ c_in, double alpha,
-                                                      double beta, int skip_empty) {
-  const int lane = threadIdx.x & 63;
-  const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int64_t cb = __builtin_amdgcn_readfirstlane(wg * 4 + (int)(threadIdx.x >> 6));
-  if (cb >= nblk) return;
-  const Desc d = descs[cb];
-  if (skip_empty && d.prod_cnt == 0) return;
-  const LaneMap L(lane);
-  const int m = d.m, n = d.n;
-  if (m <= 32 && n <= 32) {
-    const int MA = (m + 7) >> 3, NC = (n + 7) >> 3;
-    switch (MA * 4 + NC) {
-#define DBCSR_CASE(A_, C_) \
-  case A_ * 4 + C_: cblock_f64<A_, C_>(d, entries, a_data, b_data, c_out, c_in, alpha, beta, L, 0, 0); break;
-      DBCSR_CASE(1, 1) DBCSR_CASE(1, 2) DBCSR_CASE(1, 3) DBCSR_CASE(1, 4)
-      DBCSR_CASE(2, 1) DBCSR_CASE(2, 2) DBCSR_CASE(2, 3) DBCSR_CASE(2, 4)
-      DBCSR_CASE(3, 1) DBCSR_CASE(3, 2) DBCSR_CASE(3, 3) DBCSR_CASE(3, 4)
-      DBCSR_CASE(4, 1) DBCSR_CASE(4, 2) DBCSR_CASE(4, 3) DBCSR_CASE(4, 4)
-#undef DBCSR_CASE
-      default: break;
-    }
-  } else {  // large blocks: 32 x 32 tiles, one after the other
-    for (int row0 = 0; row0 < m; row0 += 32)
-      for (int col0 = 0; col0 < n; col0 += 32) cblock_f64<4, 4>(d, entries, a_data, b_data, c_out, c_in, alpha, beta, L, row0, col0);
-  }
-}
-
-// ---- LDS-staged variant ----------------------------------------------------
-// Measured on v1 (profiles/r01_v1_direct_loads_rocprofv3_summary.txt): loading
-// MFMA fragments straight from global memory costs ~40 L1 accesses per wave
-// load (TA 86 % busy, MFMA 20 % busy).  Here each wave copies the whole A and B
-// block of a product with fully coalesced 16-byte loads into its private LDS
-// slice (no barrier: one wave, in-order LDS queue) and reads fragments with
-// ds_read_b64; the next product's blocks are already in flight in registers
-// while the current one is multiplied.
-
-template <int MA, int NC>
-__device__ __forceinline__ void cblock_f64_lds(const Desc& d, const Entry* __restrict__ entries, const double* __restrict__ a_data,
-                                               const double* __restrict__ b_data, double* __restrict__ c_out,
-                                               const double* __restrict__ c_in, double alpha, double beta, const LaneMap& L, int lane,
-                                               char* lds_a, char* lds_b, int dbg) {
-  // Staging in 1 KiB chunks (64 lanes x 16 B).  The loads are RAW BUFFER loads whose
-  // descriptor covers exactly one block: the hardware bounds check returns zeros past
-  // the block end, which (a) needs no address arithmetic or tail fix-up on the VALU
-  // (v3 profile: 284 VALU instructions per product against 54 MFMAs) and (b) zero-pads
-  // A's k dimension in LDS for free.  Chunk counts are wave-uniform.
-  constexpr int CA = 2 * MA, CB = 2 * NC;  // enough for (8 MA) x 32 and 32 x (8 NC) doubles
-  double acc[MA][NC];
-#pragma unroll
-  for (int a = 0; a < MA; ++a)
-#pragma unroll
-    for (int c = 0; c < NC; ++c) acc[a][c] = 0.0;
-  const int m = d.m, n = d.n;
-  const Entry* e = entries + d.prod_start;
-  const int cnt = d.prod_cnt;
-  u32x4 ra[CA], rb[CB];
-  const int voff = lane * 16;
-  // The product-list entries are kept two ahead in scalar registers: entry p+1 is needed when product p's operands
-  // have been copied to LDS (to start the next prefetch), so it is requested one trip earlier and its scalar-load
-  // latency never sits between the LDS copy and the MFMAs.
-  auto issue = [&](uint64_t a_off, uint64_t b_off_in, int ks) {
-    // explicit scalarisation: with the k extent known to fit 16 bits the compiler multiplies on the VALU (mul24), the buffer
-    // descriptor then sits in VGPRs and every load becomes a waterfall loop (measured: config 3 10.6 -> 12.7 ms)
-    const int abytes = __builtin_amdgcn_readfirstlane(m * ks * 8), bbytes = __builtin_amdgcn_readfirstlane(ks * n * 8);
-    const int nca = __builtin_amdgcn_readfirstlane((m * ((ks + 3) & ~3) * 8 + 1023) >> 10), ncb = (bbytes + 1023) >> 10;
-    const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)(a_data + a_off), 0, abytes, 0x00020000);
-    // dbg 128 (profiling only): fold all B blocks onto the first 1 MB of B -> L2-resident; isolates the cost of L2 misses
-    const uint64_t b_off = (dbg & 128) ? (b_off_in % (uint64_t)(131072 - 1024)) : b_off_in;
-    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)(b_data + b_off), 0, bbytes, 0x00020000);
-#pragma unroll
-    for (int c = 0; c < CA; ++c)
-      if (c < nca) ra[c] = __builtin_amdgcn_raw_buffer_load_b128(rsa, voff, c * 1024, 0);
-    // (measured: a non-temporal hint (aux = 2) on these streamed B loads costs 20-30 % -- plain loads)
-#pragma unroll
-    for (int c = 0; c < CB; ++c)
-      if (c < ncb) rb[c] = __builtin_amdgcn_raw_buffer_load_b128(rsb, voff, c * 1024, 0);
-  };
-  // dbg (ablation switches for profiling, 0 in production): 1 = no global loads, 2 = no MFMA/LDS reads, 4 = no LDS writes
-  if (dbg & 1) {
-#pragma unroll
-    for (int c = 0; c < CA; ++c) ra[c] = u32x4{0u, 0x3ff00000u, 0u, 0x3ff00000u};
-#pragma unroll
-    for (int c = 0; c < CB; ++c) rb[c] = u32x4{0u, 0x3ff00000u, 0u, 0x3ff00000u};
-  }
-  Entry e0 = cnt > 0 ? e[0] : Entry::make(0, 0, 1);            // product p (being staged / multiplied)
-  Entry e1 = cnt > 1 ? e[1] : e0;                            // product p + 1 (prefetched next)
-  if (cnt > 0 && !(dbg & 1)) issue(e0.a_off(), e0.b_off(), e0.ks());
-  for (int p = 0; p < cnt; ++p) {
-    const int ks = e0.ks();
-    if (!(dbg & 4)) {
-      const int nca = __builtin_amdgcn_readfirstlane((m * ((ks + 3) & ~3) * 8 + 1023) >> 10), ncb = __builtin_amdgcn_readfirstlane((ks * n * 8 + 1023) >> 10);
-#pragma unroll
-      for (int c = 0; c < CA; ++c)
-        if (c < nca) *reinterpret_cast<u32x4*>(lds_a + c * 1024 + voff) = ra[c];
-      DBCSR_AMD_LDS_ORDER();
-#pragma unroll
-      for (int c = 0; c < CB; ++c)
-        if (c < ncb) *reinterpret_cast<u32x4*>(lds_b + c * 1024 + voff) = rb[c];
-    }
-    if (p + 1 < cnt && !(dbg & 1)) issue(e1.a_off(), e1.b_off(), e1.ks());
-    const Entry e2 = e[p + 2 < cnt ? p + 2 : cnt - 1];      // requested now, first used one trip later
-    if (!(dbg & 2))
-      block_product_f64_lds<MA, NC>(acc, reinterpret_cast<const double*>(lds_a), reinterpret_cast<const double*>(lds_b), m, n, ks, L);
-    e0 = e1;
-    e1 = e2;
-  }
-  double* C = c_out + d.c_off;
-  const bool has_in = d.cin_off >= 0;
-  const double* Ci = c_in + (has_in ? d.cin_off : 0);
-#pragma unroll
-  for (int a = 0; a < MA; ++a)
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      const int row = 8 * a + L.rowd, col = 8 * c + L.coll;
-      if (row < m && col < n) {
-        double v = alpha * acc[a][c];
-        if (has_in) v += beta * Ci[row + (size_t)m * col];
-        C[row + (size_t)m * col] = v;  // plain store: non-temporal stores doubled WRITE_SIZE here (8-byte scattered lanes are not combined)
-      }
-    }
-}
-
-// ---- exact-size variant ------------------------------------------------------
-// Specialisation for C blocks of M x N whose products have inner dimension K, all compile-time (what the
-// reference's JIT does per (m, n, k) triple): chunk counts, LDS fragment offsets and the k loop are constants, so
-// a product costs its buffer loads, LDS copies, ds_reads with immediate offsets and MFMAs and next to nothing else
-// (the generic path: 103 VALU + 98 SALU instructions per 23^3 product besides the 54 MFMAs).  Products of the
-// block with another inner dimension (the tail block column of A) are multiplied straight from global memory.
-typedef const volatile double __attribute__((address_space(3))) lds_vd;  // volatile LDS read: never paired into ds_read2_b64
-// VAR: 0 = production (no ablation branch is compiled in), 1 = the run-time ablation switches of DBCSR_AMD_MM_DBG (profiling),
-// 2 = production with the fragment reads kept as single ds_read_b64 (the compiler pairs them into ds_read2_b64 otherwise)
-template <int M, int N, int K, int VAR>
-__device__ __forceinline__ void cblock_f64_exact(const Desc& d, const Entry first, const Entry* __restrict__ entries, const double* __restrict__ a_data,
-                                                 const double* __restrict__ b_data, double* __restrict__ c_out,
-                                                 const double* __restrict__ c_in, double alpha, double beta, const LaneMap& L, int lane,
-                                                 char* lds_a, char* lds_b, int dbg_rt, double* __restrict__ norm_out) {
-  const int dbg = VAR == 1 ? dbg_rt : 0;
-  constexpr int MA = (M + 7) / 8, NC = (N + 7) / 8, KS = (K + 3) / 4, K4 = 4 * KS;
-  constexpr int CA = (M * K4 * 8 + 1023) / 1024, CB = (K * N * 8 + 1023) / 1024;
-  double acc[MA][NC];
-#pragma unroll
-  for (int a = 0; a < MA; ++a)
-#pragma unroll
-    for (int c = 0; c < NC; ++c) acc[a][c] = 0.0;
-  const Entry* e = entries + d.prod_start;
-  const int cnt = d.prod_cnt;
-  u32x4 ra[CA], rb[CB];
-  const int voff = lane * 16;
-  // fragment addresses: constant for the whole life of the wave
-  const double* pa[MA];
-  const double* pb[NC];
-  const double* pbt[NC];  // last k step when K is not a multiple of 4: lanes past the end read element (0, col) (A's padding is zero)
-#pragma unroll
-  for (int a = 0; a < MA; ++a) {
-    int row = 8 * a + L.rowl;
-    row = row < M ? row : M - 1;
-    pa[a] = reinterpret_cast<const double*>(lds_a) + row + M * L.kq;
-  }
-#pragma unroll
-  for (int c = 0; c < NC; ++c) {
-    int col = 8 * c + L.coll;
-    col = col < N ? col : N - 1;
-    pb[c] = reinterpret_cast<const double*>(lds_b) + L.kq + K * col;
-    const int kt = 4 * (KS - 1) + L.kq;
-    pbt[c] = reinterpret_cast<const double*>(lds_b) + (kt < K ? kt : 0) + K * col;
-  }
-  auto issue = [&](uint64_t a_off, uint64_t b_off_in) {
-    if (dbg & 1) return;
-    const uint32_t fold = (dbg >> 16) ? (uint32_t)(dbg >> 16) * 65536u : 131072u;  // B window of the L2/MALL experiments, doubles
-    const uint64_t b_off = (dbg & 128) ? (b_off_in % (uint64_t)(fold - 1024u)) : b_off_in;
-    const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)(a_data + a_off), 0, M * K * 8, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)(b_data + b_off), 0, K * N * 8, 0x00020000);
-#pragma unroll
-    for (int c = 0; c < CA; ++c) ra[c] = __builtin_amdgcn_raw_buffer_load_b128(rsa, voff, c * 1024, 0);
-    // (measured on the streamed B loads: sc0 / sc1 / sc0+sc1 make no difference, nt costs +30 %)
-#pragma unroll
-    for (int c = 0; c < CB; ++c) rb[c] = __builtin_amdgcn_raw_buffer_load_b128(rsb, voff, c * 1024, 0);
-  };
-  // Products with inner dimension K run through the staged pipeline (i0 = the one being multiplied, i1 = the next
-  // candidate, whose list entry was requested one trip earlier); the others are summed afterwards.
-  int i0 = 0;
-  Entry e0 = first;  // == e[0], already here
-  while (i0 < cnt && e0.ks() != K) {
-    ++i0;
-    e0 = e[i0 < cnt ? i0 : cnt - 1];
-  }
-  int i1 = i0 + 1;
-  Entry e1 = e[i1 < cnt ? i1 : cnt - 1];
-  if (dbg & 1) {
-#pragma unroll
-    for (int c = 0; c < CA; ++c) ra[c] = u32x4{0u, 0x3ff00000u, 0u, 0x3ff00000u};
-#pragma unroll
-    for (int c = 0; c < CB; ++c) rb[c] = u32x4{0u, 0x3ff00000u, 0u, 0x3ff00000u};
-  }
-  if (i0 < cnt) issue(e0.a_off(), e0.b_off());
-  while (i0 < cnt) {
-    if (!(dbg & 4)) {
-#pragma unroll
-      for (int c = 0; c < CA; ++c) *reinterpret_cast<u32x4*>(lds_a + c * 1024 + voff) = ra[c];
-      DBCSR_AMD_LDS_ORDER();
-#pragma unroll
-      for (int c = 0; c < CB; ++c) *reinterpret_cast<u32x4*>(lds_b + c * 1024 + voff) = rb[c];
-    }
-    while (i1 < cnt && e1.ks() != K) {
-      ++i1;
-      e1 = e[i1 < cnt ? i1 : cnt - 1];
-    }
-    if (i1 < cnt) issue(e1.a_off(), e1.b_off());
-    const Entry e2 = e[i1 + 1 < cnt ? i1 + 1 : cnt - 1];
-    if (!(dbg & 2))
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      double av[MA], bv[NC];
-#pragma unroll
-      for (int a = 0; a < MA; ++a) {
-        if constexpr (VAR == 2)
-          av[a] = *(lds_vd*)(pa[a] + s * 4 * M);
-        else
-          av[a] = pa[a][s * 4 * M];
-      }
-#pragma unroll
-      for (int c = 0; c < NC; ++c) {
-        if constexpr (VAR == 2)
-          bv[c] = (s == KS - 1 && (K & 3)) ? *(lds_vd*)(pbt[c]) : *(lds_vd*)(pb[c] + 4 * s);
-        else
-          bv[c] = (s == KS - 1 && (K & 3)) ? pbt[c][0] : pb[c][4 * s];
-      }
-#pragma unroll
-      for (int a = 0; a < MA; ++a)
-#pragma unroll
-        for (int c = 0; c < NC; ++c) acc[a][c] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[a], bv[c], acc[a][c], 0, 0, 0);
-    }
-    i0 = i1;
-    e0 = e1;
-    i1 = i1 + 1;
-    e1 = e2;
-  }
-  for (int p = 0; p < cnt; ++p) {
-    const Entry ep = e[p];
-    if (ep.ks() != K) block_product_f64<MA, NC, false>(acc, a_data + ep.a_off(), b_data + ep.b_off(), M, N, ep.ks(), L);
-  }
-  const bool has_in = d.cin_off >= 0;
-  if (dbg & 8) {  // scattered 8-byte stores straight from the accumulators (the first version; kept for comparison)
-    double* C = c_out + d.c_off;
-    const double* Ci = c_in + (has_in ? d.cin_off : 0);
-#pragma unroll
-    for (int a = 0; a < MA; ++a)
-#pragma unroll
-      for (int c = 0; c < NC; ++c) {
-        const int row = 8 * a + L.rowd, col = 8 * c + L.coll;
-        if (row < M && col < N) {
-          double v = alpha * acc[a][c];
-          if (has_in) v += beta * Ci[row + (size_t)M * col];
-          C[row + (size_t)M * col] = v;
-        }
-      }
-    return;
-  }
-  // C epilogue through LDS: the block is laid out as stored (column-major, contiguous) in the wave's staging area and
-  // leaves in whole 1 KiB pieces -- 16 B per lane, full cache lines except at the two ends of the block -- with the
-  // streaming hint, so that the 8.6 GB of C that config 2 writes do not push the A block-rows out of L2 / the B panel out
-  // of the Infinity Cache.  (Non-temporal on the scattered 8-byte stores doubled WRITE_SIZE: partial lines are not combined.)
-  constexpr int CC = (M * N * 8 + 1023) / 1024;
-  double* lds_c = reinterpret_cast<double*>(lds_a);
-#pragma unroll
-  for (int a = 0; a < MA; ++a)
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      const int row = 8 * a + L.rowd, col = 8 * c + L.coll;
-      if (row < M && col < N) lds_c[row + M * col] = alpha * acc[a][c];
-    }
-  const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc((void*)(c_out + d.c_off), 0, M * N * 8, 0x00020000);
-  typedef double f64x2 __attribute__((ext_vector_type(2)));
-  if (has_in) {
-    const __amdgpu_buffer_rsrc_t rsi = __builtin_amdgcn_make_buffer_rsrc((void*)(c_in + d.cin_off), 0, M * N * 8, 0x00020000);
-    u32x4 ci[CC];
-#pragma unroll
-    for (int c = 0; c < CC; ++c) ci[c] = __builtin_amdgcn_raw_buffer_load_b128(rsi, voff, c * 1024, 0);
-#pragma unroll
-    for (int c = 0; c < CC; ++c) {
-      f64x2 v = *reinterpret_cast<const f64x2*>(lds_a + c * 1024 + voff);
-      const f64x2 w = __builtin_bit_cast(f64x2, ci[c]);
-      v[0] += beta * w[0];
-      v[1] += beta * w[1];
-      if (norm_out) *reinterpret_cast<f64x2*>(lds_a + c * 1024 + voff) = v;  // (the final values, for the norm below)
-      if (dbg & 16)
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsc, voff, c * 1024, 0);
-      else
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsc, voff, c * 1024, 2);
-    }
-  } else {
-#pragma unroll
-    for (int c = 0; c < CC; ++c) {
-      const u32x4 v = *reinterpret_cast<const u32x4*>(lds_a + c * 1024 + voff);
-      if (dbg & 16)
-        __builtin_amdgcn_raw_buffer_store_b128(v, rsc, voff, c * 1024, 0);
-      else
-        __builtin_amdgcn_raw_buffer_store_b128(v, rsc, voff, c * 1024, 2);
-    }
-  }
-  // squared Frobenius norm of the block as it was stored (the final block filter of a filtered multiply reads it instead of C):
-  // the block still sits in the wave's LDS slice
-  if (norm_out) {
-    double ss = 0.0;
-#pragma unroll
-    for (int c = 0; c < CC; ++c) {
-      const f64x2 v = *reinterpret_cast<const f64x2*>(lds_a + c * 1024 + voff);
-      const int idx = c * 128 + 2 * lane;
-      if (idx < M * N) ss += v[0] * v[0];
-      if (idx + 1 < M * N) ss += v[1] * v[1];
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) ss += __shfl_down(ss, off, 64);
-    if (lane == 0) *norm_out = ss;
-  }
-}
-
-// C blocks of exactly M x N take the exact-size path; every other block of the launch the generic one.
-template <int M, int N, int K, int VAR>
-__global__ void __launch_bounds__(256) mm_numeric_f64_hot(const Desc* __restrict__ descs, int64_t nblk, const Entry* __restrict__ entries,
-                                                          const double* __restrict__ a_data, const double* __restrict__ b_data,
-                                                          double* __restrict__ c_out, const double* __restrict__ c_in, double alpha,
-                                                          double beta, int lds_a_doubles, int lds_wave_doubles, int dbg, const int* __restrict__ order,
-                                                          const Work* __restrict__ work, double* __restrict__ norms) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63;
-  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int64_t pos = (int64_t)wg * (int)(blockDim.x >> 6) + wid;  // 1, 2 or 4 waves per workgroup (Engine::wg_waves)
-  // launch-order records (build_work): descriptor and first product in one read -- no order[] -> descs[] -> entries[] chain
-  const Work w = work[pos];
-  if (w.prod_cnt < 0) return;  // padding position
-  const Desc d = {w.c_off, w.cin_off, w.prod_start, w.prod_cnt, w.m, w.n};
-  Entry first;
-  first.a_lo = w.a_lo, first.b_lo = w.b_lo, first.w = w.w;
-  if ((dbg & 32) && d.prod_cnt == 0) return;
-  if ((dbg & 64) && d.m == M && d.n == N) return;  // the tile kernel (mm_tile.h) computed the blocks of the dominant size
-  char* lds_a = smem + (size_t)wid * lds_wave_doubles * 8;
-  char* lds_b = lds_a + (size_t)lds_a_doubles * 8;
-  const LaneMap L(lane);
-  if (d.m == M && d.n == N) {
-    cblock_f64_exact<M, N, K, VAR>(d, first, entries, a_data, b_data, c_out, c_in, alpha, beta, L, lane, lds_a, lds_b, dbg,
-                              norms ? norms + w.cb : nullptr);
-    return;
-  }
-  // the few blocks of another size (tail block row / column): straight from global memory, as one 32 x 32 tile
-  cblock_f64<4, 4>(d, entries, a_data, b_data, c_out, c_in, alpha, beta, L, 0, 0);
-}
-
-// all block dimensions of the launch are <= 8*MAXT (<= 32); lds_wave_doubles = per-wave LDS slice (A part then B part).
-// MAXT bounds the register allocation to what the largest block class present needs.
-template <int MAXT>
-__global__ void __launch_bounds__(256) mm_numeric_f64_lds(const Desc* __restrict__ descs, int64_t nblk, const Entry* __restrict__ entries,
-                                                          const double* __restrict__ a_data, const double* __restrict__ b_data,
-                                                          double* __restrict__ c_out, const double* __restrict__ c_in, double alpha,
-                                                          double beta, int lds_a_doubles, int lds_wave_doubles, int dbg, const int* __restrict__ order) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63;
-  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int64_t pos = (int64_t)wg * (int)(blockDim.x >> 6) + wid;  // gridDim.x * waves per workgroup == padded length of order[]
-  const int64_t cb = order[pos];
-  if (cb < 0 || cb >= nblk) return;
-  if ((dbg & 32) && descs[cb].prod_cnt == 0) return;  // in-place accumulation (beta = 1): untouched blocks stay as they are
-  char* lds_a = smem + (size_t)wid * lds_wave_doubles * 8;
-  char* lds_b = lds_a + (size_t)lds_a_doubles * 8;
-  const Desc d = descs[cb];
-  const LaneMap L(lane);
-  const int MA = (d.m + 7) >> 3, NC = (d.n + 7) >> 3;
-  switch (MA * 4 + NC) {
-#define DBCSR_CASE(A_, C_)                                                                                           \
-  case A_ * 4 + C_:                                                                                                  \
-    if constexpr (A_ <= MAXT && C_ <= MAXT)                                                                          \
-      cblock_f64_lds<A_, C_>(d, entries, a_data, b_data, c_out, c_in, alpha, beta, L, lane, lds_a, lds_b, dbg);          \
-    break;
-    DBCSR_CASE(1, 1) DBCSR_CASE(1, 2) DBCSR_CASE(1, 3) DBCSR_CASE(1, 4)
-    DBCSR_CASE(2, 1) DBCSR_CASE(2, 2) DBCSR_CASE(2, 3) DBCSR_CASE(2, 4)
-    DBCSR_CASE(3, 1) DBCSR_CASE(3, 2) DBCSR_CASE(3, 3) DBCSR_CASE(3, 4)
-    DBCSR_CASE(4, 1) DBCSR_CASE(4, 2) DBCSR_CASE(4, 3) DBCSR_CASE(4, 4)
-#undef DBCSR_CASE
-    default: break;
-  }
-}
-
-
-// ---- pipelined variant: a wave walks a RANGE of C blocks --------------------------
-// v4 measurements: with one C block per wave, every wave pays the dependent chain
-// order -> descriptor -> entry -> operand loads -> LDS before its first MFMA (about 5 us);
-// at 14 products per block that is ~10 % of a wave's life, at 1-4 products per block
-// (configs 3 and 4) it dominates.  Here a wave owns G consecutive positions of order[] and
-// the product pipeline runs ACROSS C-block boundaries: while the last product of block b is
-// multiplied, the first product of block b+1 is already in flight, and the descriptor of
-// block b+2 has been requested.
-struct PipeCtx {
-  const Desc* __restrict__ descs;
-  const Entry* __restrict__ entries;
-  const double* __restrict__ a_data;
-  const double* __restrict__ b_data;
-  double* __restrict__ c_out;
-  const double* __restrict__ c_in;
-  double alpha, beta;
-  char* lds_a;
-  char* lds_b;
-  int lane, voff;
-};
-
-__device__ __forceinline__ int64_t uniform64(int64_t v) {
-  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
-  return (int64_t)(((uint64_t)hi << 32) | lo);
-}
-
-// descriptor held in scalar registers
-__device__ __forceinline__ Desc load_desc_uniform(const Desc* __restrict__ descs, int cb) {
-  const Desc t = descs[cb];
-  Desc d;
-  d.c_off = uniform64(t.c_off);
-  d.cin_off = uniform64(t.cin_off);
-  d.prod_start = uniform64(t.prod_start);
-  d.prod_cnt = __builtin_amdgcn_readfirstlane(t.prod_cnt);
-  const int mn = __builtin_amdgcn_readfirstlane(((int)(uint16_t)t.m) | (((int)(uint16_t)t.n) << 16));
-  d.m = (int16_t)(mn & 0xffff);
-  d.n = (int16_t)(mn >> 16);
-  return d;
-}
-
-// prefetch product `pidx` (index into entries) of a C block of size m x n into the staging registers
-template <int CMAX>
-__device__ __forceinline__ void pipe_issue(const PipeCtx& X, int64_t pidx, int m, int n, u32x4 (&ra)[CMAX], u32x4 (&rb)[CMAX]) {
-  const Entry e = X.entries[pidx];
-  Entry u;  // wave-uniform copy
-  u.a_lo = __builtin_amdgcn_readfirstlane(e.a_lo);
-  u.b_lo = __builtin_amdgcn_readfirstlane(e.b_lo);
-  u.w = __builtin_amdgcn_readfirstlane(e.w);
-  const uint64_t ao = u.a_off(), bo = u.b_off();
-  const int ks = u.ks();
-  const int abytes = __builtin_amdgcn_readfirstlane(m * ks * 8), bbytes = __builtin_amdgcn_readfirstlane(ks * n * 8);  // scalar on purpose, see cblock_f64_lds
-  const int nca = __builtin_amdgcn_readfirstlane((m * ((ks + 3) & ~3) * 8 + 1023) >> 10), ncb = (bbytes + 1023) >> 10;
-  const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)(X.a_data + ao), 0, abytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)(X.b_data + bo), 0, bbytes, 0x00020000);
-#pragma unroll
-  for (int c = 0; c < CMAX; ++c)
-    if (c < nca) ra[c] = __builtin_amdgcn_raw_buffer_load_b128(rsa, X.voff, c * 1024, 0);
-#pragma unroll
-  for (int c = 0; c < CMAX; ++c)
-    if (c < ncb) rb[c] = __builtin_amdgcn_raw_buffer_load_b128(rsb, X.voff, c * 1024, 0);
-}
-
-// multiply the staged product into the accumulators of the current block.  acc is the launch-wide
-// [MAXT][MAXT] array; class (MA, NC) uses a corner of it.
-template <int MA, int NC, int MAXT>
-__device__ __forceinline__ void pipe_compute(const PipeCtx& X, int m, int n, int ks, double (&acc)[MAXT][MAXT], const LaneMap& L) {
-  double t[MA][NC];
-#pragma unroll
-  for (int a = 0; a < MA; ++a)
-#pragma unroll
-    for (int c = 0; c < NC; ++c) t[a][c] = acc[a][c];
-  block_product_f64_lds<MA, NC>(t, reinterpret_cast<const double*>(X.lds_a), reinterpret_cast<const double*>(X.lds_b), m, n, ks, L);
-#pragma unroll
-  for (int a = 0; a < MA; ++a)
-#pragma unroll
-    for (int c = 0; c < NC; ++c) acc[a][c] = t[a][c];
-}
-
-// write a finished block (any class: rows/columns outside the block are masked) and clear the accumulators
-template <int MAXT>
-__device__ __forceinline__ void pipe_flush(const PipeCtx& X, const Desc& d, double (&acc)[MAXT][MAXT], const LaneMap& L) {
-  const int m = d.m, n = d.n;
-  double* C = X.c_out + d.c_off;
-  const bool has_in = d.cin_off >= 0;
-  const double* Ci = X.c_in + (has_in ? d.cin_off : 0);
-#pragma unroll
-  for (int a = 0; a < MAXT; ++a)
-#pragma unroll
-    for (int c = 0; c < MAXT; ++c) {
-      const int row = 8 * a + L.rowd, col = 8 * c + L.coll;
-      if (row < m && col < n) {
-        double v = X.alpha * acc[a][c];
-        if (has_in) v += X.beta * Ci[row + (size_t)m * col];
-        C[row + (size_t)m * col] = v;
-      }
-      acc[a][c] = 0.0;
-    }
-}
-
-template <int MAXT>
-__global__ void __launch_bounds__(256) mm_numeric_f64_pipe(const Desc* __restrict__ descs, int64_t nblk, const Entry* __restrict__ entries,
-                                                           const double* __restrict__ a_data, const double* __restrict__ b_data,
-                                                           double* __restrict__ c_out, const double* __restrict__ c_in, double alpha,
-                                                           double beta, int lds_a_doubles, int lds_wave_doubles, int skip_empty,
-                                                           const int* __restrict__ order, int64_t npos, int G) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int CMAX = 2 * MAXT;
-  const int lane = threadIdx.x & 63;
-  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  int64_t pos = ((int64_t)wg * 4 + wid) * G;
-  const int64_t pos_end = min(pos + G, npos);
-  if (pos >= npos) return;
-  PipeCtx X;
-  X.descs = descs; X.entries = entries; X.a_data = a_data; X.b_data = b_data; X.c_out = c_out; X.c_in = c_in;
-  X.alpha = alpha; X.beta = beta;
-  X.lds_a = smem + (size_t)wid * lds_wave_doubles * 8;
-  X.lds_b = X.lds_a + (size_t)lds_a_doubles * 8;
-  X.lane = lane; X.voff = lane * 16;
-  const LaneMap L(lane);
-  // Next C block of this wave's range that has products.  Blocks without products are finished on the spot
-  // (C = beta*C_in or 0), or left untouched when accumulating in place (skip_empty).
-  auto next_block = [&](Desc& d) -> bool {
-    while (pos < pos_end) {
-      const int cb = __builtin_amdgcn_readfirstlane(order[pos]);
-      ++pos;
-      if (cb < 0 || cb >= nblk) continue;
-      d = load_desc_uniform(descs, cb);
-      if (d.prod_cnt > 0) return true;
-      if (!skip_empty) {
-        double* C = c_out + d.c_off;
-        const int ne = (int)d.m * (int)d.n;
-        if (d.cin_off >= 0) {
-          const double* Ci = c_in + d.cin_off;
-          for (int e = lane; e < ne; e += 64) C[e] = beta * Ci[e];
-        } else {
-          for (int e = lane; e < ne; e += 64) C[e] = 0.0;
-        }
-      }
-    }
-    return false;
-  };
-  u32x4 ra[CMAX], rb[CMAX];
-  double acc[MAXT][MAXT];
-#pragma unroll
-  for (int a = 0; a < MAXT; ++a)
-#pragma unroll
-    for (int c = 0; c < MAXT; ++c) acc[a][c] = 0.0;
-  Desc cur, nxt, done;
-  if (!next_block(cur)) return;
-  bool have_nxt = next_block(nxt);
-  bool pending = false;  // `done` is finished and still sits in acc, waiting to be written
-  // Flat product loop.  p = -1: nothing staged yet (the first trip only issues the first prefetch), so there is
-  // exactly ONE prefetch site and ONE LDS-write site in the kernel (one set of staging registers).
-  // Order inside a trip: [wait for the prefetched operands, copy them to LDS] [write out the block finished in
-  // the previous trip] [prefetch] [multiply].  The finished block's stores are issued BEFORE the next prefetch,
-  // so the in-order vmcnt wait of the following trip never has to drain stores that were issued after loads.
-  int p = -1, ks = 0;
-  for (;;) {
-    if (p >= 0) {
-      ks = __builtin_amdgcn_readfirstlane(entries[cur.prod_start + p].ks());
-      const int nca = __builtin_amdgcn_readfirstlane((cur.m * ((ks + 3) & ~3) * 8 + 1023) >> 10), ncb = __builtin_amdgcn_readfirstlane((ks * cur.n * 8 + 1023) >> 10);
-#pragma unroll
-      for (int c = 0; c < CMAX; ++c)
-        if (c < nca) *reinterpret_cast<u32x4*>(X.lds_a + c * 1024 + X.voff) = ra[c];
-      DBCSR_AMD_LDS_ORDER();
-#pragma unroll
-      for (int c = 0; c < CMAX; ++c)
-        if (c < ncb) *reinterpret_cast<u32x4*>(X.lds_b + c * 1024 + X.voff) = rb[c];
-    }
-    if (pending) {
-      pipe_flush<MAXT>(X, done, acc, L);
-      pending = false;
-    }
-    const bool more = p + 1 < cur.prod_cnt;
-    if (more || have_nxt) pipe_issue<CMAX>(X, more ? cur.prod_start + p + 1 : nxt.prod_start, more ? cur.m : nxt.m, more ? cur.n : nxt.n, ra, rb);
-    if (p >= 0) {
-      const int MA = (cur.m + 7) >> 3, NC = (cur.n + 7) >> 3;
-      switch (MA * 4 + NC) {
-#define DBCSR_CASE(A_, C_)                                                                               \
-  case A_ * 4 + C_:                                                                                      \
-    if constexpr (A_ <= MAXT && C_ <= MAXT) pipe_compute<A_, C_, MAXT>(X, cur.m, cur.n, ks, acc, L);     \
-    break;
-        DBCSR_CASE(1, 1) DBCSR_CASE(1, 2) DBCSR_CASE(1, 3) DBCSR_CASE(1, 4)
-        DBCSR_CASE(2, 1) DBCSR_CASE(2, 2) DBCSR_CASE(2, 3) DBCSR_CASE(2, 4)
-        DBCSR_CASE(3, 1) DBCSR_CASE(3, 2) DBCSR_CASE(3, 3) DBCSR_CASE(3, 4)
-        DBCSR_CASE(4, 1) DBCSR_CASE(4, 2) DBCSR_CASE(4, 3) DBCSR_CASE(4, 4)
-#undef DBCSR_CASE
-        default: break;
-      }
-      if (!more) {  // block complete: it is written at the start of the next trip (or after the loop)
-        done = cur;
-        pending = true;
-        if (!have_nxt) break;
-        cur = nxt;
-        have_nxt = next_block(nxt);
-        p = 0;
-        continue;
-      }
-    }
-    ++p;
-  }
-  if (pending) pipe_flush<MAXT>(X, done, acc, L);
-}
-
-// max and (negated) min of an int array (block sizes): out[0] = max v, out[1] = max -v
-__global__ void __launch_bounds__(256) max_of(const int* __restrict__ v, int n, int* __restrict__ out) {
-  int mx = 0, mn = -0x7fffffff;
-  for (int i = threadIdx.x; i < n; i += 256) {
-    mx = max(mx, v[i]);
-    mn = max(mn, -v[i]);
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    mx = max(mx, __shfl_down(mx, off, 64));
-    mn = max(mn, __shfl_down(mn, off, 64));
-  }
-  if ((threadIdx.x & 63) == 0) {
-    atomicMax(out, mx);
-    atomicMax(out + 1, mn);
-  }
-}
-
-// most frequent value among the entries of v that lie in 1..32: out[0] = value (0: none), out[1] = how often
-__global__ void __launch_bounds__(256) mode_of(const int* __restrict__ v, int n, int* __restrict__ out) {
-  __shared__ int h[33];
-  if (threadIdx.x < 33) h[threadIdx.x] = 0;
-  __syncthreads();
-  for (int i = threadIdx.x; i < n; i += 256) {
-    const int s = v[i];
-    if (s >= 1 && s <= 32) atomicAdd(&h[s], 1);
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int best = 0, cnt = 0;
-    for (int s = 1; s <= 32; ++s)
-      if (h[s] > cnt) {
-        cnt = h[s];
-        best = s;
-      }
-    out[0] = best;
-    out[1] = cnt;
-  }
-}
-
-// ---- fp64, C blocks of at most 4 x 4 (BASELINE config 1: 4 x 4 x 4 blocks) -------------------------------------------
-// v_mfma_f64_4x4x4_4b_f64 multiplies FOUR independent 4x4x4 block triples at once (lane bits 2-3 select the triple).  With
-// one wave per C block three quarters of every instruction are padding and a wave lives for ten products; here a wave
-// owns four C blocks, one per MFMA sub-block, each walking its own product list, and every lane fetches exactly the A and
-// B element it feeds (no LDS, no staging): per block product 2 element loads per lane and one MFMA per 4 of k.
-// Sub-block b of lane l: b = (l >> 2) & 3; operands A[i = l & 3][k = l >> 4], B[k = l >> 4][j = l & 3]; result C[i = l >> 4][j = l & 3].
-__global__ void __launch_bounds__(256) mm_numeric_f64_tiny(const Desc* __restrict__ descs, int64_t nblk, const Entry* __restrict__ entries,
-                                                           const double* __restrict__ a_data, const double* __restrict__ b_data,
-                                                           double* __restrict__ c_out, const double* __restrict__ c_in, double alpha,
-                                                           double beta, int skip_empty, const int* __restrict__ order) {
-  const int lane = threadIdx.x & 63;
-  const int wid = threadIdx.x >> 6;
-  const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int sub = (lane >> 2) & 3, x = lane & 3, kq = lane >> 4;
-  const int64_t pos = ((int64_t)wg * 4 + wid) * 4 + sub;  // gridDim.x * 16 == padded length of order[]
-  const int cb = order[pos];
-  const bool live = cb >= 0 && cb < nblk;
-  Desc d;
-  d.prod_cnt = 0;
-  d.m = d.n = 0;
-  d.c_off = d.cin_off = d.prod_start = 0;
-  if (live) d = descs[cb];
-  const int m = d.m, n = d.n;
-  const Entry* e = entries + d.prod_start;
-  const int cnt = live ? d.prod_cnt : 0;
-  double acc = 0.0;
-  Entry cur = Entry::make(0, 0, 0);
-  if (cnt > 0) cur = e[0];
-  for (int p = 0; __any(p < cnt); ++p) {
-    const bool on = p < cnt;
-    Entry nxt = cur;
-    if (p + 1 < cnt) nxt = e[p + 1];  // requested before this product's elements: one entry ahead
-    const int ks = on ? cur.ks() : 0;
-    const double* A = a_data + cur.a_off();
-    const double* B = b_data + cur.b_off();
-    for (int kb = 0; __any(kb < ks); kb += 4) {
-      const int k = kb + kq;
-      const bool kv = k < ks;
-      const double av = (kv && x < m) ? A[x + m * k] : 0.0;
-      const double bv = (kv && x < n) ? B[k + ks * x] : 0.0;
-      acc = __builtin_amdgcn_mfma_f64_4x4x4f64(av, bv, acc, 0, 0, 0);
-    }
-    cur = nxt;
-  }
-  if (!live || (skip_empty && cnt == 0)) return;
-  const int i = kq, j = x;
-  if (i < m && j < n) {
-    double v = alpha * acc;
-    if (d.cin_off >= 0) v += beta * c_in[d.cin_off + i + m * j];
-    c_out[d.c_off + i + m * j] = v;
-  }
-}
-
-// ---- fp32, LDS-staged (blocks up to 32 x 32; BASELINE config 5) -----------------------------------------
-// One v_mfma_f32_32x32x2_f32 covers the whole C block for 2 k.  A (m x k, column-major) is copied to LDS as
-// is: its fragment (lane = row, two k per instruction) reads 32 consecutive floats.  B is stored k x n with k
-// contiguous, but its fragment wants n across lanes at a fixed k -- 32 lanes 128 B apart would all hit one LDS
-// bank -- so B is written to LDS TRANSPOSED with a row pitch of 33 floats (Bt[j + 33 kk]); the staging write
-// computes (kk, j) per element with a multiply-shift division by the runtime k.
-constexpr int F32_CH = 4;            // 1 KiB chunks: 4 x 256 floats >= 32 x 32
-constexpr int F32_LDN = 33;          // pitch of the transposed B image
-constexpr int F32_A_FLOATS = 1024 + 64, F32_BT_FLOATS = F32_LDN * 32 + 31;
-constexpr int F32_WAVE_FLOATS = F32_A_FLOATS + ((F32_BT_FLOATS + 3) & ~3);
-
-__device__ __forceinline__ void cblock_f32_lds(const Desc& d, const Entry* __restrict__ entries, const float* __restrict__ a_data,
-                                               const float* __restrict__ b_data, float* __restrict__ c_out,
-                                               const float* __restrict__ c_in, float alpha, float beta, int lane, float* lds_a,
-                                               float* lds_bt) {
-  constexpr int CH = F32_CH, LDN = F32_LDN;
-  const int m = d.m, n = d.n, cnt = d.prod_cnt;
-  const Entry* e = entries + d.prod_start;
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-  u32x4 ra[CH], rb[CH];
-  const int voff = lane * 16;
-  auto issue = [&](int p) {
-    const int ks = e[p].ks();
-    const int abytes = __builtin_amdgcn_readfirstlane(m * ks * 4), bbytes = __builtin_amdgcn_readfirstlane(ks * n * 4);  // scalar on purpose, see cblock_f64_lds
-    const int nca = __builtin_amdgcn_readfirstlane((m * (ks + 1) * 4 + 1023) >> 10), ncb = (bbytes + 1023) >> 10;  // A: one zero column of k padding
-    const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)(a_data + e[p].a_off()), 0, abytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)(b_data + e[p].b_off()), 0, bbytes, 0x00020000);
-#pragma unroll
-    for (int c = 0; c < CH; ++c)
-      if (c < nca) ra[c] = __builtin_amdgcn_raw_buffer_load_b128(rsa, voff, c * 1024, 0);
-#pragma unroll
-    for (int c = 0; c < CH; ++c)
-      if (c < ncb) rb[c] = __builtin_amdgcn_raw_buffer_load_b128(rsb, voff, c * 1024, 0);
-  };
-  if (cnt > 0) issue(0);
-  const int i = lane & 31, kh = lane >> 5;
-  const int arow = i < m ? i : m - 1, bcol = i < n ? i : n - 1;
-  for (int p = 0; p < cnt; ++p) {
-    const int ks = e[p].ks();
-    const int kn = ks * n;
-    const int nca = __builtin_amdgcn_readfirstlane((m * (ks + 1) * 4 + 1023) >> 10), ncb = __builtin_amdgcn_readfirstlane((kn * 4 + 1023) >> 10);
-    const unsigned inv = (65536u + (unsigned)ks - 1u) / (unsigned)ks;  // j = (e * inv) >> 16 == e / ks for e < 2048, ks <= 32
-#pragma unroll
-    for (int c = 0; c < CH; ++c)
-      if (c < nca) *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(lds_a) + c * 1024 + voff) = ra[c];
-#pragma unroll
-    for (int c = 0; c < CH; ++c)
-      if (c < ncb) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const unsigned el = (unsigned)((c * 64 + lane) * 4 + t);
-          const unsigned j = (el * inv) >> 16, kk = el - j * (unsigned)ks;
-          if ((int)el < kn) lds_bt[j + LDN * kk] = __uint_as_float(rb[c][t]);
-        }
-      }
-    if (p + 1 < cnt) issue(p + 1);
-    // multiply: lane (i, kh) feeds A[i][2s + kh] and B[2s + kh][i]; the odd-k tail reads A's zero padding column
-    const int nsteps = (ks + 1) >> 1;
-    int aoff = arow + m * kh;
-    for (int s2 = 0; s2 < nsteps; ++s2) {
-      const int kk = 2 * s2 + kh;
-      const float av = lds_a[aoff];
-      const float bv = lds_bt[bcol + LDN * (kk < ks ? kk : ks - 1)];
-      aoff += 2 * m;
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
-    }
-  }
-  float* C = c_out + d.c_off;
-  const bool has_in = d.cin_off >= 0;
-  const float* Ci = c_in + (has_in ? d.cin_off : 0);
-  const int col = lane & 31;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    if (row < m && col < n) {
-      float v = alpha * acc[r];
-      if (has_in) v += beta * Ci[row + (size_t)m * col];
-      C[row + (size_t)m * col] = v;
-    }
-  }
-}
-
-// Exact-size fp32 variant (see cblock_f64_exact): with M, N, K known at compile time the transposed LDS image of B needs no
-// per-element division (the generic kernel spends 208 VALU + 140 SALU instructions per 32^3 product next to 16 MFMAs,
-// MFMA pipe 42 % busy): the LDS address of every staged element is a per-wave constant.
-template <int M, int N, int K>
-__device__ __forceinline__ void cblock_f32_exact(const Desc& d, const Entry* __restrict__ entries, const float* __restrict__ a_data,
-                                                 const float* __restrict__ b_data, float* __restrict__ c_out,
-                                                 const float* __restrict__ c_in, float alpha, float beta, int lane, float* lds_a,
-                                                 float* lds_bt) {
-  constexpr int LDN = F32_LDN;
-  constexpr int KS2 = (K + 1) / 2, KP = 2 * KS2;                       // k steps of 2; A is zero-padded to KP columns
-  constexpr int CA = (M * KP * 4 + 1023) / 1024, CB = (K * N * 4 + 1023) / 1024;
-  constexpr int DUMMY = F32_BT_FLOATS;                                 // LDS slot that swallows the staging lanes past the block end
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-  const Entry* e = entries + d.prod_start;
-  const int cnt = d.prod_cnt;
-  u32x4 ra[CA], rb[CB];
-  const int voff = lane * 16;
-  int baddr[CB][4];  // where element t of chunk c of this lane goes in the transposed image: constants of the wave
-#pragma unroll
-  for (int c = 0; c < CB; ++c)
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int el = (c * 64 + lane) * 4 + t;
-      const int j = el / K, kk = el - j * K;
-      baddr[c][t] = el < K * N ? j + LDN * kk : DUMMY;
-    }
-  const int i = lane & 31, kh = lane >> 5;
-  const float* pa = lds_a + (i < M ? i : M - 1) + M * kh;
-  const float* pb = lds_bt + (i < N ? i : N - 1) + LDN * kh;
-  const float* pbt = lds_bt + (i < N ? i : N - 1) + LDN * ((K & 1) && kh ? K - 1 : 2 * (KS2 - 1) + kh);  // last step of an odd K
-  auto issue = [&](uint64_t a_off, uint64_t b_off) {
-    const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)(a_data + a_off), 0, M * K * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)(b_data + b_off), 0, K * N * 4, 0x00020000);
-#pragma unroll
-    for (int c = 0; c < CA; ++c) ra[c] = __builtin_amdgcn_raw_buffer_load_b128(rsa, voff, c * 1024, 0);
-#pragma unroll
-    for (int c = 0; c < CB; ++c) rb[c] = __builtin_amdgcn_raw_buffer_load_b128(rsb, voff, c * 1024, 0);
-  };
-  int i0 = 0;
-  Entry e0 = e[0];
-  while (i0 < cnt && e0.ks() != K) {
-    ++i0;
-    e0 = e[i0 < cnt ? i0 : cnt - 1];
-  }
-  int i1 = i0 + 1;
-  Entry e1 = e[i1 < cnt ? i1 : cnt - 1];
-  if (i0 < cnt) issue(e0.a_off(), e0.b_off());
-  while (i0 < cnt) {
-#pragma unroll
-    for (int c = 0; c < CA; ++c) *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(lds_a) + c * 1024 + voff) = ra[c];
-#pragma unroll
-    for (int c = 0; c < CB; ++c)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) lds_bt[baddr[c][t]] = __uint_as_float(rb[c][t]);
-    while (i1 < cnt && e1.ks() != K) {
-      ++i1;
-      e1 = e[i1 < cnt ? i1 : cnt - 1];
-    }
-    if (i1 < cnt) issue(e1.a_off(), e1.b_off());
-    const Entry e2 = e[i1 + 1 < cnt ? i1 + 1 : cnt - 1];
-#pragma unroll
-    for (int s2 = 0; s2 < KS2; ++s2) {
-      const float av = pa[s2 * 2 * M];
-      const float bv = (s2 == KS2 - 1) ? pbt[0] : pb[s2 * 2 * LDN];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
-    }
-    i0 = i1;
-    e0 = e1;
-    i1 = i1 + 1;
-    e1 = e2;
-  }
-  for (int p = 0; p < cnt; ++p) {
-    const Entry ep = e[p];
-    if (ep.ks() != K) block_product_f32<false>(acc, a_data + ep.a_off(), b_data + ep.b_off(), M, N, ep.ks(), lane);
-  }
-  float* C = c_out + d.c_off;
-  const bool has_in = d.cin_off >= 0;
-  const float* Ci = c_in + (has_in ? d.cin_off : 0);
-  const int col = lane & 31;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    if (row < M && col < N) {
-      float v = alpha * acc[r];
-      if (has_in) v += beta * Ci[row + (size_t)M * col];
-      C[row + (size_t)M * col] = v;
-    }
-  }
-}
-
-static inline size_t f32_lds_bytes(int wg_waves) { return ((size_t)wg_waves * F32_WAVE_FLOATS + 4) * sizeof(float); }
-#define DBCSR_F32_KERNEL_HEAD                                                                          \
-  extern __shared__ __attribute__((aligned(16))) char smem_raw_[]; /* f32_lds_bytes(waves per workgroup) */ \
-  float* smem = reinterpret_cast<float*>(smem_raw_);                                                   \
-  const int lane = threadIdx.x & 63;                                                                   \
-  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));                             \
-  const int wg = xcd_remap(blockIdx.x, gridDim.x);                                                     \
-  const int64_t pos = (int64_t)wg * (int)(blockDim.x >> 6) + wid;                                      \
-  const int64_t cb = order[pos];                                                                       \
-  if (cb < 0 || cb >= nblk) return;                                                                    \
-  const Desc d = descs[cb];                                                                            \
-  if (skip_empty && d.prod_cnt == 0) return;                                                           \
-  float* lds_a = smem + (size_t)wid * F32_WAVE_FLOATS;                                                 \
-  float* lds_bt = lds_a + F32_A_FLOATS;
-
-__global__ void __launch_bounds__(256) mm_numeric_f32_lds(const Desc* __restrict__ descs, int64_t nblk, const Entry* __restrict__ entries,
-                                                          const float* __restrict__ a_data, const float* __restrict__ b_data,
-                                                          float* __restrict__ c_out, const float* __restrict__ c_in, float alpha,
-                                                          float beta, int skip_empty, const int* __restrict__ order) {
-  DBCSR_F32_KERNEL_HEAD
-  cblock_f32_lds(d, entries, a_data, b_data, c_out, c_in, alpha, beta, lane, lds_a, lds_bt);
-}
-
-template <int M, int N, int K>
-__global__ void __launch_bounds__(256) mm_numeric_f32_hot(const Desc* __restrict__ descs, int64_t nblk, const Entry* __restrict__ entries,
-                                                          const float* __restrict__ a_data, const float* __restrict__ b_data,
-                                                          float* __restrict__ c_out, const float* __restrict__ c_in, float alpha,
-                                                          float beta, int skip_empty, const int* __restrict__ order) {
-  DBCSR_F32_KERNEL_HEAD
-  if (d.m == M && d.n == N)
-    cblock_f32_exact<M, N, K>(d, entries, a_data, b_data, c_out, c_in, alpha, beta, lane, lds_a, lds_bt);
-  else
-    cblock_f32_lds(d, entries, a_data, b_data, c_out, c_in, alpha, beta, lane, lds_a, lds_bt);
-}
-
-__global__ void __launch_bounds__(256) mm_numeric_f32(const Desc* __restrict__ descs, int64_t nblk, const Entry* __restrict__ entries,
-                                                      const float* __restrict__ a_data, const float* __restrict__ b_data,
-                                                      float* __restrict__ c_out, const float* __restrict__ c_in, float alpha,
-                                                      float beta, int skip_empty) {
-  const int lane = threadIdx.x & 63;
-  const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int64_t cb = __builtin_amdgcn_readfirstlane(wg * 4 + (int)(threadIdx.x >> 6));
-  if (cb >= nblk) return;
-  const Desc d = descs[cb];
-  if (skip_empty && d.prod_cnt == 0) return;
-  const int m = d.m, n = d.n;
-  const Entry* e = entries + d.prod_start;
-  const bool has_in = d.cin_off >= 0;
-  for (int row0 = 0; row0 < m; row0 += 32)
-    for (int col0 = 0; col0 < n; col0 += 32) {
-      f32x16 acc;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-      for (int p = 0; p < d.prod_cnt; ++p)
-        block_product_f32<false>(acc, a_data + e[p].a_off(), b_data + e[p].b_off(), m, n, e[p].ks(), lane, row0, col0);
-      float* C = c_out + d.c_off;
-      const float* Ci = c_in + (has_in ? d.cin_off : 0);
-      const int col = col0 + (lane & 31);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row < m && col < n) {
-          float v = alpha * acc[r];
-          if (has_in) v += beta * Ci[row + (size_t)m * col];
-          C[row + (size_t)m * col] = v;
-        }
-      }
-    }
-}
-
-// ----------------------------------------------------------------------------
-// auxiliary kernels: checksum, random fill, transpose
-// ----------------------------------------------------------------------------
-template <typename T>
-__global__ void __launch_bounds__(256) checksum_blocks(const int* __restrict__ row_p, const int* __restrict__ col_i,
-                                                       const int64_t* __restrict__ blk_p, const T* __restrict__ data,
-                                                       const int* __restrict__ rs, const int* __restrict__ cs,
-                                                       const int64_t* __restrict__ roff, const int64_t* __restrict__ coff, int nbr,
-                                                       double* __restrict__ row_sums) {
-  // one wavefront per block row; fixed summation order -> reproducible
-  const int lane = threadIdx.x & 63;
-  const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (row >= nbr) return;
-  const int m = rs[row];
-  double s2 = 0.0, sp = 0.0;
-  for (int b = row_p[row]; b < row_p[row + 1]; ++b) {
-    const int c = col_i[b];
-    const int n = cs[c];
-    const T* d = data + blk_p[b];
-    for (int e = lane; e < m * n; e += 64) {
-      const double x = (double)d[e];
-      const int r = e % m, cc = e / m;
-      s2 += x * x;
-      sp += x * log(fabs((double)(roff[row] + r + 1) * (double)(coff[c] + cc + 1)));
-    }
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    s2 += __shfl_down(s2, off, 64);
-    sp += __shfl_down(sp, off, 64);
-  }
-  if (lane == 0) {
-    row_sums[2 * row] = s2;
-    row_sums[2 * row + 1] = sp;
-  }
-}
-
-__global__ void __launch_bounds__(256) checksum_final(const double* __restrict__ row_sums, int nbr, double* __restrict__ out2) {
-  __shared__ double r2[256], rp[256];
-  double s2 = 0.0, sp = 0.0;
-  for (int i = threadIdx.x; i < nbr; i += 256) {
-    s2 += row_sums[2 * i];
-    sp += row_sums[2 * i + 1];
-  }
-  r2[threadIdx.x] = s2;
-  rp[threadIdx.x] = sp;
-  __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
-    if ((int)threadIdx.x < off) {
-      r2[threadIdx.x] += r2[threadIdx.x + off];
-      rp[threadIdx.x] += rp[threadIdx.x + off];
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    out2[0] = r2[0];
-    out2[1] = rp[0];
-  }
-}
-
-// LAPACK xLARUV stream: x_i = seed * a^i mod 2^48 (a = 33952834046453); see
-// oracle/dbcsr_oracle.c for the statement of the published algorithm.
-__device__ __forceinline__ uint64_t larnv_block_seed(int irow, int nrow, int icol, int ival) {
-  // set_larnv_seed, src/utils/dbcsr_blas_operations.F:29-52 (irow/icol 1-based)
-  long long ivm = ((long long)ival) % 65536;
-  if (ivm < 0) ivm += 65536;
-  long long map = (((long long)irow - 1 + (long long)icol * (long long)nrow) * (1 + ivm)) * 2 + 1;
-  const uint64_t s4 = (uint64_t)(map % 4096);
-  map /= 4096;
-  const uint64_t s3 = (uint64_t)((map ^ 3541) % 4096);
-  map /= 4096;
-  const uint64_t s2 = (uint64_t)((map ^ 1153) % 4096);
-  map /= 4096;
-  const uint64_t s1 = (uint64_t)((map ^ 2029) % 4096);
-  return (s1 << 36) | (s2 << 24) | (s3 << 12) | s4;
-}
-
-__device__ __forceinline__ uint64_t pow48(uint64_t base, uint64_t e) {
-  const uint64_t mask = (1ull << 48) - 1;
-  uint64_t r = 1;
-  base &= mask;
-  while (e) {
-    if (e & 1) r = (r * base) & mask;
-    base = (base * base) & mask;
-    e >>= 1;
-  }
-  return r;
-}
-
-__global__ void __launch_bounds__(256) fill_random_f64(const int* __restrict__ row_p, const int* __restrict__ col_i,
-                                                       const int64_t* __restrict__ blk_p, double* __restrict__ data,
-                                                       const int* __restrict__ rs, const int* __restrict__ cs, int nbr, int nbc,
-                                                       int counter, const int* __restrict__ row_gid, const int* __restrict__ col_gid,
-                                                       int nrow_global) {
-  // one wavefront per block row, lanes over the elements of each block
-  const int lane = threadIdx.x & 63;
-  const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (row >= nbr) return;
-  (void)nbc;
-  const uint64_t mask = (1ull << 48) - 1, A = 33952834046453ull;
-  const uint64_t a64 = pow48(A, 64);
-  for (int b = row_p[row]; b < row_p[row + 1]; ++b) {
-    const int c = col_i[b];
-    const int ne = rs[row] * cs[c];
-    const uint64_t seed = larnv_block_seed((row_gid ? row_gid[row] : row) + 1, nrow_global, (col_gid ? col_gid[c] : c) + 1, counter);
-    uint64_t x = (seed * pow48(A, (uint64_t)lane + 1)) & mask;
-    double* d = data + blk_p[b];
-    for (int e = lane; e < ne; e += 64) {
-      d[e] = (double)x * (1.0 / 281474976710656.0);
-      x = (x * a64) & mask;
-    }
-  }
-}
-
-__global__ void __launch_bounds__(256) fill_random_f32(const int* __restrict__ row_p, const int* __restrict__ col_i,
-                                                       const int64_t* __restrict__ blk_p, float* __restrict__ data,
-                                                       const int* __restrict__ rs, const int* __restrict__ cs, int nbr, int nbc,
-                                                       int counter, const int* __restrict__ row_gid, const int* __restrict__ col_gid,
-                                                       int nrow_global) {
-  // slarnv draws in chunks of 64 and, inside a chunk, a value that rounds to 1.0f
-  // bumps the chunk's base seed (LAPACK slaruv) -- so one thread walks one block.
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  (void)nbc;
-  // thread per block: find its row by binary search in row_p
-  const int64_t nblks = row_p[nbr];
-  if (t >= nblks) return;
-  int lo = 0, hi = nbr;
-  while (hi - lo > 1) {
-    const int mid = (lo + hi) >> 1;
-    if (row_p[mid] <= t) lo = mid; else hi = mid;
-  }
-  const int r = lo, c = col_i[t];
-  const int ne = rs[r] * cs[c];
-  const uint64_t mask = (1ull << 48) - 1, A = 33952834046453ull;
-  uint64_t seed = larnv_block_seed((row_gid ? row_gid[r] : r) + 1, nrow_global, (col_gid ? col_gid[c] : c) + 1, counter);
-  float* d = data + blk_p[t];
-  const float rr = 1.0f / 4096.0f;
-  for (int done = 0; done < ne; done += 64) {
-    const int il = (ne - done) < 64 ? (ne - done) : 64;
-    // limbs of the chunk's base seed (may exceed 4095 after a bump)
-    long long i1 = (long long)((seed >> 36) & 4095), i2 = (long long)((seed >> 24) & 4095), i3 = (long long)((seed >> 12) & 4095),
-              i4 = (long long)(seed & 4095);
-    uint64_t apow = 1, last = 0;
-    for (int i = 0; i < il; ++i) {
-      apow = (apow * A) & mask;
-      for (;;) {
-        const uint64_t full = ((uint64_t)i1 << 36) + ((uint64_t)i2 << 24) + ((uint64_t)i3 << 12) + (uint64_t)i4;
-        const uint64_t p = (full * apow) & mask;
-        const float v = rr * ((float)((p >> 36) & 4095) + rr * ((float)((p >> 24) & 4095) + rr * ((float)((p >> 12) & 4095) + rr * (float)(p & 4095))));
-        if (v == 1.0f) {
-          i1 += 2; i2 += 2; i3 += 2; i4 += 2;
-          continue;
-        }
-        d[done + i] = v;
-        last = p;
-        break;
-      }
-    }
-    seed = last;
-  }
-}
-
-// transpose: dst block (c, r) <- src block (r, c)^T
-template <typename T>
-__global__ void __launch_bounds__(256)
-transpose_fill(const int* __restrict__ s_row_p, const int* __restrict__ s_col_i, const int64_t* __restrict__ s_blk_p,
-               const T* __restrict__ s_data, const int* __restrict__ s_rs, const int* __restrict__ s_cs, const uint32_t* __restrict__ t_bm,
-               const int* __restrict__ t_pre, const int* __restrict__ t_row_p, const int64_t* __restrict__ t_blk_p_ws, int s_nbr, int Wt,
-               int* __restrict__ t_col_i, int64_t* __restrict__ t_blk_p, T* __restrict__ t_data) {
-  // one wavefront per source block row
-  const int lane = threadIdx.x & 63;
-  const int r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (r >= s_nbr) return;
-  const int m = s_rs[r];
-  for (int b = s_row_p[r]; b < s_row_p[r + 1]; ++b) {
-    const int c = s_col_i[b];
-    const int n = s_cs[c];
-    // position of (c, r) in the transposed index
-    const uint32_t wv = t_bm[(size_t)c * Wt + (r >> 5)];
-    const int tb = t_row_p[c] + t_pre[(size_t)c * Wt + (r >> 5)] + __popc(wv & ((1u << (r & 31)) - 1u));
-    const int64_t toff = t_blk_p_ws[tb];
-    if (lane == 0) {
-      t_col_i[tb] = r;
-      t_blk_p[tb] = toff;
-    }
-    const T* src = s_data + s_blk_p[b];
-    T* dst = t_data + toff;
-    for (int e = lane; e < m * n; e += 64) {
-      const int i = e % m, j = e / m;  // src(i, j) -> dst(j, i), dst is n x m
-      dst[j + (size_t)n * i] = src[e];
-    }
-  }
-}
-
-__global__ void __launch_bounds__(256) transpose_mark(const int* __restrict__ s_row_p, const int* __restrict__ s_col_i, int s_nbr, int Wt,
-                                                      uint32_t* __restrict__ t_bm) {
-  const int lane = threadIdx.x & 63;
-  const int r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (r >= s_nbr) return;
-  for (int b = s_row_p[r] + lane; b < s_row_p[r + 1]; b += 64) atomicOr(&t_bm[(size_t)s_col_i[b] * Wt + (r >> 5)], 1u << (r & 31));
-}
-
-// thread per (row c of the transposed matrix, word w): block sizes in index order
-__global__ void __launch_bounds__(256) transpose_sizes(const uint32_t* __restrict__ t_bm, const int* __restrict__ t_pre,
-                                                       const int* __restrict__ t_row_p, const int* __restrict__ s_rs,
-                                                       const int* __restrict__ s_cs, int t_nbr, int Wt, int* __restrict__ blk_nze) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (int64_t)t_nbr * Wt) return;
-  const int c = (int)(t / Wt), w = (int)(t % Wt);
-  uint32_t v = t_bm[t];
-  int tb = t_row_p[c] + t_pre[t];
-  while (v) {
-    const int bit = __ffs(v) - 1;
-    v &= v - 1;
-    blk_nze[tb++] = s_cs[c] * s_rs[32 * w + bit];
-  }
-}
-
-
-// ---- desymmetrize (dbcsr_desymmetrize_deep, what make_images does to a symmetric operand: src/mm/dbcsr_mm_cannon.F:284,
-// 351-379): a symmetric / antisymmetric matrix stores one triangle; the full matrix has block (c, r) = +-block (r, c)^T too
-// mode 0: desymmetrize (a block and its twin); mode 1: stored triangle -> canonical (checkerboard) form of a matrix with symmetry
-// (dbcsr_make_index_canonical: block (r, c), r != c, moves to (c, r) when checker_tr says its twin is the stored one,
-// src/dist/dbcsr_dist_operations.F:65-75 on the 1-based coordinates); mode 2: canonical form -> stored triangle (row <= col)
-__device__ __forceinline__ bool twin_moves(int mode, int r, int c) {
-  if (mode == 1) return r != c && ((((r + c) & 1) == 1) == (c >= r));
-  return r > c;  // mode 2
-}
-
-__global__ void __launch_bounds__(256) desym_mark(const int* __restrict__ s_row_p, const int* __restrict__ s_col_i, int nbr, int W, int mode,
-                                                  uint32_t* __restrict__ bm) {
-  const int lane = threadIdx.x & 63;
-  const int r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (r >= nbr) return;
-  for (int b = s_row_p[r] + lane; b < s_row_p[r + 1]; b += 64) {
-    const int c = s_col_i[b];
-    const bool stay = mode == 0 || !twin_moves(mode, r, c), go = mode == 0 || twin_moves(mode, r, c);
-    if (stay) atomicOr(&bm[(size_t)r * W + (c >> 5)], 1u << (c & 31));
-    if (go) atomicOr(&bm[(size_t)c * W + (r >> 5)], 1u << (r & 31));
-  }
-}
-
-template <typename T>
-__global__ void __launch_bounds__(256)
-desym_fill(const int* __restrict__ s_row_p, const int* __restrict__ s_col_i, const int64_t* __restrict__ s_blk_p, const T* __restrict__ s_data,
-           const int* __restrict__ sizes, const uint32_t* __restrict__ bm, const int* __restrict__ pre, const int* __restrict__ d_row_p,
-           const int64_t* __restrict__ d_blk_p_ws, int nbr, int W, T sign, int mode, int* __restrict__ d_col_i, int64_t* __restrict__ d_blk_p,
-           T* __restrict__ d_data) {
-  const int lane = threadIdx.x & 63;
-  const int r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (r >= nbr) return;
-  const int m = sizes[r];
-  auto slot = [&](int row, int col) {
-    const uint32_t wv = bm[(size_t)row * W + (col >> 5)];
-    return d_row_p[row] + pre[(size_t)row * W + (col >> 5)] + __popc(wv & ((1u << (col & 31)) - 1u));
-  };
-  for (int b = s_row_p[r]; b < s_row_p[r + 1]; ++b) {
-    const int c = s_col_i[b];
-    const int n = sizes[c];
-    const T* src = s_data + s_blk_p[b];
-    const bool stay = mode == 0 || !twin_moves(mode, r, c), go = mode == 0 ? c != r : twin_moves(mode, r, c);
-    if (stay) {
-      const int t0 = slot(r, c);
-      if (lane == 0) {
-        d_col_i[t0] = c;
-        d_blk_p[t0] = d_blk_p_ws[t0];
-      }
-      T* d0 = d_data + d_blk_p_ws[t0];
-      for (int e = lane; e < m * n; e += 64) d0[e] = src[e];
-    }
-    if (go) {
-      const int t1 = slot(c, r);
-      if (lane == 0) {
-        d_col_i[t1] = r;
-        d_blk_p[t1] = d_blk_p_ws[t1];
-      }
-      T* d1 = d_data + d_blk_p_ws[t1];
-      for (int e = lane; e < m * n; e += 64) {
-        const int i = e % m, j = e / m;  // src(i, j) -> dst(j, i), dst is n x m
-        d1[j + (size_t)n * i] = sign * src[e];
-      }
-    }
-  }
-}
-
-// ---- block filter (dbcsr_mm_multrec.F:694-748 multrec_filtering / dbcsr_filter): drop blocks with ||blk||^2 < eps^2
-__global__ void __launch_bounds__(256) filter_flags(const double* __restrict__ norms64, int64_t nblks, const int* __restrict__ row_p,
-                                                    const int* __restrict__ col_i, const int* __restrict__ rs, const int* __restrict__ cs,
-                                                    int nbr, double eps2, int* __restrict__ keep, int* __restrict__ blk_nze,
-                                                    int* __restrict__ row_keep) {
-  // one wavefront per block row
-  const int lane = threadIdx.x & 63;
-  const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (row >= nbr) return;
-  int cnt = 0;
-  for (int b = row_p[row] + lane; b < row_p[row + 1]; b += 64) {
-    const int k = norms64[b] >= eps2 ? 1 : 0;
-    keep[b] = k;
-    blk_nze[b] = k ? rs[row] * cs[col_i[b]] : 0;
-    cnt += k;
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
-  if (lane == 0) row_keep[row] = cnt;
-  (void)nblks;
-}
-
-template <typename T>
-__global__ void __launch_bounds__(256) filter_compact(const int* __restrict__ row_p, const int* __restrict__ col_i,
-                                                      const int64_t* __restrict__ blk_p, const T* __restrict__ data,
-                                                      const int* __restrict__ rs, const int* __restrict__ cs, int nbr, int S,
-                                                      const int* __restrict__ keep, const int64_t* __restrict__ newidx,
-                                                      const int64_t* __restrict__ newoff, int* __restrict__ d_col_i,
-                                                      int64_t* __restrict__ d_blk_p, T* __restrict__ d_data) {
-  const int lane = threadIdx.x & 63;
-  const int64_t wv = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int row = (int)(wv / S), sub = (int)(wv % S);
-  if (row >= nbr) return;
-  const int m = rs[row];
-  for (int b = row_p[row] + sub; b < row_p[row + 1]; b += S) {
-    if (!keep[b]) continue;
-    const int64_t t = newidx[b], off = newoff[b];
-    if (lane == 0) {
-      d_col_i[t] = col_i[b];
-      d_blk_p[t] = off;
-    }
-    const int ne = m * cs[col_i[b]];
-    const T* src = data + blk_p[b];
-    T* dst = d_data + off;
-    for (int e = lane; e < ne; e += 64) dst[e] = src[e];
-  }
-}
-
-// ---- submatrix limits (dbcsr_crop_matrix, src/ops/dbcsr_operations.F:1652-1833; dbcsr_scale with limits) ---------
-struct Window {
-  int r0, r1, c0, c1;  // inclusive 0-based element bounds
-};
-
-// one wavefront per block row: a block is kept when it intersects the window
-__global__ void __launch_bounds__(256) crop_flags(const int* __restrict__ row_p, const int* __restrict__ col_i, const int* __restrict__ rs,
-                                                  const int* __restrict__ cs, const int64_t* __restrict__ roff,
-                                                  const int64_t* __restrict__ coff, int nbr, Window w, int* __restrict__ keep,
-                                                  int* __restrict__ blk_nze, int* __restrict__ row_keep) {
-  const int lane = threadIdx.x & 63;
-  const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (row >= nbr) return;
-  const int m = rs[row];
-  const bool row_in = roff[row] + m - 1 >= w.r0 && roff[row] <= w.r1;
-  int cnt = 0;
-  for (int b = row_p[row] + lane; b < row_p[row + 1]; b += 64) {
-    const int c = col_i[b], n = cs[c];
-    const int k = (row_in && coff[c] + n - 1 >= w.c0 && coff[c] <= w.c1) ? 1 : 0;
-    keep[b] = k;
-    blk_nze[b] = k ? m * n : 0;
-    cnt += k;
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
-  if (lane == 0) row_keep[row] = cnt;
-}
-
-// compaction of the kept blocks; elements outside the window become zero
-template <typename T>
-__global__ void __launch_bounds__(256) crop_compact(const int* __restrict__ row_p, const int* __restrict__ col_i,
-                                                    const int64_t* __restrict__ blk_p, const T* __restrict__ data,
-                                                    const int* __restrict__ rs, const int* __restrict__ cs,
-                                                    const int64_t* __restrict__ roff, const int64_t* __restrict__ coff, int nbr, Window w,
-                                                    const int* __restrict__ keep, const int64_t* __restrict__ newidx,
-                                                    const int64_t* __restrict__ newoff, int* __restrict__ d_col_i,
-                                                    int64_t* __restrict__ d_blk_p, T* __restrict__ d_data) {
-  const int lane = threadIdx.x & 63;
-  const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (row >= nbr) return;
-  const int m = rs[row];
-  const int64_t r_base = roff[row];
-  for (int b = row_p[row]; b < row_p[row + 1]; ++b) {
-    if (!keep[b]) continue;
-    const int64_t t = newidx[b], off = newoff[b];
-    const int c = col_i[b];
-    if (lane == 0) {
-      d_col_i[t] = c;
-      d_blk_p[t] = off;
-    }
-    const int ne = m * cs[c];
-    const int64_t c_base = coff[c];
-    const T* src = data + blk_p[b];
-    T* dst = d_data + off;
-    for (int e = lane; e < ne; e += 64) {
-      const int64_t gr = r_base + e % m, gc = c_base + e / m;
-      dst[e] = (gr >= w.r0 && gr <= w.r1 && gc >= w.c0 && gc <= w.c1) ? src[e] : T(0);
-    }
-  }
-}
-
-// in place: x *= beta for the elements inside the window
-template <typename T>
-__global__ void __launch_bounds__(256) scale_window(const int* __restrict__ row_p, const int* __restrict__ col_i,
-                                                    const int64_t* __restrict__ blk_p, T* __restrict__ data, const int* __restrict__ rs,
-                                                    const int* __restrict__ cs, const int64_t* __restrict__ roff,
-                                                    const int64_t* __restrict__ coff, int nbr, Window w, T beta) {
-  const int lane = threadIdx.x & 63;
-  const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (row >= nbr) return;
-  const int m = rs[row];
-  const int64_t r_base = roff[row];
-  if (r_base + m - 1 < w.r0 || r_base > w.r1) return;
-  for (int b = row_p[row]; b < row_p[row + 1]; ++b) {
-    const int c = col_i[b], n = cs[c];
-    const int64_t c_base = coff[c];
-    if (c_base + n - 1 < w.c0 || c_base > w.c1) continue;
-    T* blk = data + blk_p[b];
-    for (int e = lane; e < m * n; e += 64) {
-      const int64_t gr = r_base + e % m, gc = c_base + e / m;
-      if (gr >= w.r0 && gr <= w.r1 && gc >= w.c0 && gc <= w.c1) blk[e] *= beta;
-    }
-  }
-}
-
-
-// ----------------------------------------------------------------------------
-// (m, n) classes of C blocks (mixed block sizes): order[] in one segment per class
-//
-// The reference sorts block products into homogeneous stacks by the three most common sizes of each dimension
-// (map_most_common, src/dist/dbcsr_dist_util.F:753-812; stack_map in dbcsr_mm_csr.F:497-525) and runs each stack on the
-// kernel compiled for its (m, n, k).  Here a C block is the unit of work, so C blocks are bucketed by (m, n): class
-// c = 3 * rank(m) + rank(n) for the three most common row and column block sizes (ranks 0..2), class 9 = everything else.
-// order[] becomes ten segments, each laid out like the single list of the other kernels (eight XCD streams padded to a
-// common length, column panels, row i on XCD i mod 8), and each segment is one launch of the kernel for its class.
-// ----------------------------------------------------------------------------
-constexpr int kNumClasses = 10;
-
-__global__ void __launch_bounds__(256) size_hist(const int* __restrict__ sizes, int n, int* __restrict__ hist /* 33 */) {
-  // per-workgroup histogram in LDS first: with a single block size every global atomic would hit the same address
-  // (5699 serialised atomics = 66 us on config 4)
-  __shared__ int h[33];
-  if (threadIdx.x < 33) h[threadIdx.x] = 0;
-  __syncthreads();
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) {
-    const int s = sizes[i];
-    atomicAdd(&h[(s >= 1 && s <= 32) ? s : 0], 1);
-  }
-  __syncthreads();
-  if (threadIdx.x < 33 && h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
-}
-
-__global__ void __launch_bounds__(256) class_ids(const int* __restrict__ sizes, int n, int s0, int s1, int s2, unsigned char* __restrict__ cls) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int s = sizes[i];
-  cls[i] = (unsigned char)(s == s0 ? 0 : (s == s1 ? 1 : (s == s2 ? 2 : 3)));
-}
-
-// ncls_bm[q * W + w]: bit j of word w set iff column 32 w + j has class q (q = 0..3)
-__global__ void __launch_bounds__(256) class_col_bitmaps(const unsigned char* __restrict__ ncls, int nbc, int W, uint32_t* __restrict__ bm) {
-  const int w = blockIdx.x * blockDim.x + threadIdx.x;
-  if (w >= W) return;
-  uint32_t m[4] = {0u, 0u, 0u, 0u};
-  for (int b = 0; b < 32; ++b) {
-    const int j = 32 * w + b;
-    if (j < nbc) m[ncls[j]] |= 1u << b;
-  }
-  for (int q = 0; q < 4; ++q) bm[(size_t)q * W + w] = m[q];
-}
-
-// columns of row i (class rc) that belong to class `cls`, as a mask on bitmap word w
-__device__ __forceinline__ uint32_t class_mask(int cls, int rc, const uint32_t* __restrict__ ncls_bm, int W, int w) {
-  if (cls < 9) return rc == cls / 3 ? ncls_bm[(size_t)(cls % 3) * W + w] : 0u;
-  return rc == 3 ? 0xffffffffu : ncls_bm[(size_t)3 * W + w];
-}
-
-// key = ((cls * 8 + x) * NP + p) * R + g : the C blocks of class cls in row i = 8 g + x inside column panel p
-__global__ void __launch_bounds__(256) order_count_cls(const uint32_t* __restrict__ c_bm, const unsigned char* __restrict__ rowcls,
-                                                       const uint32_t* __restrict__ ncls_bm, int nbr, int W, int PW, int NP, int R,
-                                                       int* __restrict__ cnt) {
-  const int key = blockIdx.x * blockDim.x + threadIdx.x;
-  if (key >= kNumClasses * 8 * NP * R) return;
-  const int g = key % R, p = (key / R) % NP, x = (key / (R * NP)) % 8, cls = key / (R * NP * 8);
-  const int i = 8 * g + x;
-  int c = 0;
-  if (i < nbr) {
-    const int rc = rowcls[i];
-    const int w1 = min(W, (p + 1) * PW);
-    for (int w = p * PW; w < w1; ++w) c += __popc(c_bm[(size_t)i * W + w] & class_mask(cls, rc, ncls_bm, W, w));
-  }
-  cnt[key] = c;
-}
-
-// per class: common padded length of its eight XCD streams (multiple of 4) and the offset of its segment in order[]
-__global__ void order_len_cls(const int64_t* __restrict__ base, int64_t total, int NP, int R, int64_t* __restrict__ lens /* 10 lens, 10 offsets, total */) {
-  int64_t off = 0;
-  for (int cls = 0; cls < kNumClasses; ++cls) {
-    int64_t mx = 0;
-    for (int x = 0; x < 8; ++x) {
-      const size_t k0 = ((size_t)cls * 8 + x) * NP * R, k1 = k0 + (size_t)NP * R;
-      const int64_t b1 = (cls == kNumClasses - 1 && x == 7) ? total : base[k1];
-      mx = b1 - base[k0] > mx ? b1 - base[k0] : mx;
-    }
-    const int64_t len = (mx + 31) & ~(int64_t)31;  // multiple of 4 waves x up to 8 blocks per wave
-    lens[cls] = len;
-    lens[kNumClasses + cls] = off;
-    off += 8 * len;
-  }
-  lens[2 * kNumClasses] = off;
-}
-
-// thread per (row i, bitmap word w): position of each C block inside the stream of its class and XCD
-__global__ void __launch_bounds__(256) order_fill_cls(const uint32_t* __restrict__ c_bm, const int* __restrict__ c_pre,
-                                                      const int* __restrict__ c_row_p, const unsigned char* __restrict__ rowcls,
-                                                      const uint32_t* __restrict__ ncls_bm, const int64_t* __restrict__ base,
-                                                      const int64_t* __restrict__ lens, int nbr, int W, int PW, int NP, int R,
-                                                      int* __restrict__ order) {
-  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (tid >= (int64_t)nbr * W) return;
-  const int i = (int)(tid / W), w = (int)(tid % W);
-  uint32_t v = c_bm[tid];
-  if (!v) return;
-  const int x = i & 7, g = i >> 3, p = w / PW, rc = rowcls[i];
-  // blocks of each column class that precede word w inside the panel (class 9 of a row whose own size is unranked: all of them)
-  int before[4] = {0, 0, 0, 0};
-  for (int ww = p * PW; ww < w; ++ww) {
-    const uint32_t cw = c_bm[(size_t)i * W + ww];
-    if (rc == 3)
-      before[3] += __popc(cw);
-    else
-      for (int q = 0; q < 4; ++q) before[q] += __popc(cw & ncls_bm[(size_t)q * W + ww]);
-  }
-  int cb = c_row_p[i] + c_pre[tid];
-  while (v) {
-    const int bit = __ffs(v) - 1;
-    v &= v - 1;
-    int q = 3;
-    if (rc != 3)
-      for (int qq = 0; qq < 3; ++qq)
-        if ((ncls_bm[(size_t)qq * W + w] >> bit) & 1u) q = qq;
-    const int cls = (rc < 3 && q < 3) ? rc * 3 + q : 9;
-    const size_t key = (((size_t)cls * 8 + x) * NP + p) * R + g;
-    const size_t key0 = ((size_t)cls * 8 + x) * NP * R;
-    const int64_t pos = lens[kNumClasses + cls] + (int64_t)x * lens[cls] + (base[key] - base[key0]) + before[q];
-    order[pos] = cb;
-    ++before[q];
-    ++cb;
-  }
-}
-
-// ---- per-(m, n, k) statistics (dbcsr_mm_sched.F:392-461): histogram over the product lists, open addressing ------------
-constexpr int kStatSlots = 8192;  // power of two
-// launch-order work records (mm_types.h Work): one thread per position of order[]
-__global__ void __launch_bounds__(256) build_work(const int* __restrict__ order, int64_t npos, const Desc* __restrict__ descs, int64_t nblk,
-                                                  const Entry* __restrict__ entries, Work* __restrict__ work) {
-  const int64_t pos = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (pos >= npos) return;
-  const int cb = order[pos];
-  Work w;
-  w.c_off = 0, w.cin_off = -1, w.prod_start = 0, w.prod_cnt = -1, w.m = 0, w.n = 0, w.a_lo = 0, w.b_lo = 0, w.w = 0, w.cb = cb;
-  if (cb >= 0 && cb < nblk) {
-    const Desc d = descs[cb];
-    w.c_off = d.c_off, w.cin_off = d.cin_off, w.prod_start = d.prod_start, w.prod_cnt = d.prod_cnt, w.m = d.m, w.n = d.n;
-    if (d.prod_cnt > 0) {
-      const Entry e = entries[d.prod_start];
-      w.a_lo = e.a_lo, w.b_lo = e.b_lo, w.w = e.w;
-    }
-  }
-  work[pos] = w;
-}
-
-__global__ void __launch_bounds__(256) mnk_histogram(const Desc* __restrict__ descs, int64_t nblk, const Entry* __restrict__ entries,
-                                                     unsigned long long* __restrict__ keys, unsigned long long* __restrict__ counts,
-                                                     int* __restrict__ overflow) {
-  const int64_t cb = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (cb >= nblk) return;
-  const Desc d = descs[cb];
-  const Entry* e = entries + d.prod_start;
-  unsigned long long run_key = 0, run_cnt = 0;
-  auto flush = [&]() {
-    if (!run_cnt) return;
-    unsigned h = (unsigned)((run_key * 0x9E3779B97F4A7C15ull) >> 40) & (kStatSlots - 1);
-    for (int probe = 0; probe < kStatSlots; ++probe) {
-      const unsigned long long prev = atomicCAS(&keys[h], 0ull, run_key);
-      if (prev == 0ull || prev == run_key) {
-        atomicAdd(&counts[h], run_cnt);
-        return;
-      }
-      h = (h + 1) & (kStatSlots - 1);
-    }
-    *overflow = 1;
-  };
-  for (int p = 0; p < d.prod_cnt; ++p) {
-    // key: m | n << 16 | k << 32, plus bit 63 so that no key is 0
-    const unsigned long long key = (unsigned long long)(uint16_t)d.m | ((unsigned long long)(uint16_t)d.n << 16) |
-                                   ((unsigned long long)(unsigned)e[p].ks() << 32) | (1ull << 63);
-    if (key != run_key) {
-      flush();
-      run_key = key;
-      run_cnt = 0;
-    }
-    ++run_cnt;
-  }
-  flush();
-}
-}  // namespace dbcsr_amd
+#include "mm_workspace.h"
+#include "mm_symbolic.h"
+#include "mm_numeric_f64.h"
+#include "mm_numeric_f32.h"
+#include "mm_aux.h"
 #include "mm_dma.h"
 #include "mm_tile_index.h"
 namespace dbcsr_amd {
@@ -2543,7 +233,7 @@ struct Engine {
   int dbg = 0;      // DBCSR_AMD_MM_DBG: ablation switches of the LDS kernel (profiling only; the exact-size kernel honours them in its VAR = 1 build)
   // XCD-wide C tiles in registers (mm_tile.h): DBCSR_AMD_MM_TILE = 0 never, 1 automatic, 2 whenever the sizes allow;
   // DBCSR_AMD_MM_TILE_WINDOW = k window of the team (inner blocks; 0: no throttle); DBCSR_AMD_MM_TILE_RDV = 1: unpaired fragment reads
-  int use_tile = 0, tile_window = 256, tile_rdv = 0, tile_pub = 1, tile_prefetch = 0;  // DBCSR_AMD_MM_TILE_PUB: progress stores written through (0) / left in L2 (1)
+  int use_tile = 0, tile_window = 256, tile_rdv = 0, tile_pub = 1, tile_prefetch = 0, tile_knobs = 0;  // DBCSR_AMD_MM_TILE_PUB: progress stores written through (0) / left in L2 (1)
   int hot_cnt_m = 0, hot_cnt_k = 0, hot_cnt_n = 0;  // block rows / inner blocks / block columns of the dominant size
   DevBuf<uint32_t> a_bm, bt_bm, tile_prog;
   DevBuf<int> a_pre, tile_rows, tile_cols, tile_cnt, tile_flags;
@@ -2740,6 +430,7 @@ static int run_tile_f64(Engine* E, hipStream_t st, const dbcsr_amd_bcsr* a, cons
   P.window = E->tile_window;
   P.pub_policy = E->tile_pub;
   P.prefetch = E->tile_prefetch;
+  P.knobs = E->tile_knobs;
   ACC_CHECK(hipEventRecord(E->ev[1], st));  // the timed numeric launch starts here (the index work above counts as fill time)
   if (tile_launch(S_, S_, S_, E->tile_rdv, (unsigned)(8 * cu_per_xcd), st, P)) return -1;
   if (tile_launch_remainder(S_, S_, st, G, E->tdescs.p, E->tentries.p, P.a_data, P.b_data, P.c_out, alpha)) return -1;
@@ -2789,6 +480,7 @@ int dbcsr_amd_mm_create(void** handle) {
   if (const char* k = getenv("DBCSR_AMD_MM_TILE_RDV")) E->tile_rdv = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_TILE_PUB")) E->tile_pub = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_TILE_PREFETCH")) E->tile_prefetch = atoi(k);
+  if (const char* k = getenv("DBCSR_AMD_MM_TILE_KNOBS")) E->tile_knobs = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_HOT")) E->use_hot = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_TINY")) E->use_tiny = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_LDS_PAD")) E->lds_pad = atoi(k);
@@ -3414,7 +1106,7 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
 int dbcsr_amd_mm_init_c(void* handle, libsmm_acc_data_t datatype, double beta, const dbcsr_amd_bcsr* c_in, dbcsr_amd_bcsr* c_out,
                         void* stream) {
   Engine* E = static_cast<Engine*>(handle);
-  if (E) plan_invalidate(E);  // this call uses (or changes what feeds) the engine's work areas: the next multiply runs its own symbolic phase
+  if (E) E->plan_numeric = false;  // the descriptors are rewritten below: a numeric phase that follows fills its lists again (the plan itself stands)
   if (!E || !E->valid || !c_in || !c_out) {
     fprintf(stderr, "dbcsr_amd_mm_init_c: no valid symbolic phase for this handle\n");
     return -1;

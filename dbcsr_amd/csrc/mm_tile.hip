@@ -177,7 +177,9 @@ __global__ void __launch_bounds__(512) mm_numeric_f64_tile(TileArgs P) {
   // config 2, every one a partial-line write) took longer than the multiply itself.  A wave republishes only when its need has
   // moved on by a quantum (an eighth of the window): what it publishes is a LOWER bound of what it still needs, so publishing
   // late is always safe, and the team's view of it lags by less than the quantum.
-  const unsigned quantum = window > 8 ? (unsigned)window >> 3 : 1u;
+  const int qshift = P.knobs & 7 ? (P.knobs & 7) : 3;             // knobs bits 0-2: publish quantum = window >> qshift (default 3)
+  const bool use_prio = (P.knobs >> 3) & 1;                       // bit 3: issue priority by distance from the team's minimum
+  const unsigned quantum = (window >> qshift) > 0 ? (unsigned)(window >> qshift) : 1u;
   unsigned published = 0;
   unsigned pf_sink = 0;             // destination of the L2 prefetch loads (see the product loop)
   const int pf_off = lane * 128;    // one dword per 128-byte line
@@ -194,6 +196,17 @@ __global__ void __launch_bounds__(512) mm_numeric_f64_tile(TileArgs P) {
     if (window <= 0) return;
     if (g <= seen_min + (unsigned)window) {  // inside the window already: no traffic at all, except the rationed progress report
       if (g >= published + quantum) publish(g);
+      if (use_prio) {
+        // the two waves of a SIMD share its MFMA pipe: the one further behind in the team's sweep gets the pipe first, the one
+        // near the front of the window (it will have to wait there anyway) yields -- spread reduced without anybody idling
+        const unsigned lead = g - seen_min;   // (seen_min is a stale lower bound of the minimum: lead is an upper bound)
+        if (lead * 4 < (unsigned)window)
+          __builtin_amdgcn_s_setprio(3);
+        else if (lead * 4 > 3u * (unsigned)window)
+          __builtin_amdgcn_s_setprio(0);
+        else
+          __builtin_amdgcn_s_setprio(1);
+      }
       return;
     }
     publish(g);
@@ -214,7 +227,10 @@ __global__ void __launch_bounds__(512) mm_numeric_f64_tile(TileArgs P) {
         publish(kTileDone);
         break;
       }
-      __builtin_amdgcn_s_sleep(2);
+      if ((P.knobs >> 4) & 1)
+        __builtin_amdgcn_s_sleep(1);
+      else
+        __builtin_amdgcn_s_sleep(2);
     }
   };
   double acc[kTileSlots][3][3];

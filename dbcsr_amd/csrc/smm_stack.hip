@@ -13,6 +13,8 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <map>
+#include <mutex>
 
 #include "../../include/dbcsr_acc_libsmm.h"
 #include "common.h"
@@ -359,6 +361,80 @@ int process_stack_f32(const int* dev_stack, int nstack, const float* a, const fl
   return dbcsr_amd::check(hipGetLastError(), "smm_stack_f32 launch", __FILE__, __LINE__);
 }
 
+// ---- inhomogeneous stacks ------------------------------------------------------------------------------------------------
+// A stack whose entries have different (m, n, k) -- the products with the tail blocks, or a fourth block size: everything the
+// host's three most common sizes per dimension do not cover (dbcsr_mm_csr.F:236-248) -- is refused by the reference's library
+// (libsmm_acc.cpp:324-339 returns -1: the host multiplies it on the CPU, and aborts in G2G mode, dbcsr_mm_accdrv.F:534).  Here
+// it runs on the device: the sizes are in the host's own 7-integer records (m, n, k, a, b, c, c_blk; dbcsr_mm_types.F:24-37),
+// which are copied to the device for the call; one wavefront per entry, C tiles of 32 x 32, fp64 atomics into C.
+__global__ void __launch_bounds__(256) smm_stack_f64_mixed(const int* __restrict__ params, int nstack, const double* __restrict__ a_data,
+                                                           const double* __restrict__ b_data, double* __restrict__ c_data, int max_dim) {
+  const int lane = threadIdx.x & 63;
+  const int s = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+  if (s >= nstack) return;
+  const int* p = params + 7 * (size_t)s;
+  const int m = __builtin_amdgcn_readfirstlane(p[0]), n = __builtin_amdgcn_readfirstlane(p[1]), k = __builtin_amdgcn_readfirstlane(p[2]);
+  const int ao = __builtin_amdgcn_readfirstlane(p[3]), bo = __builtin_amdgcn_readfirstlane(p[4]), co = __builtin_amdgcn_readfirstlane(p[5]);
+  if (m <= 0 || n <= 0 || k <= 0) return;
+  const bool bt = k <= max_dim && n <= max_dim;  // the host transposed this B block (libsmm_acc_transpose) iff both of its dims are small
+  const LaneMap L(lane);
+  const double* A = a_data + (ao - 1);
+  const double* B = b_data + (bo - 1);
+  double* C = c_data + (co - 1);
+  for (int row0 = 0; row0 < m; row0 += 32)
+    for (int col0 = 0; col0 < n; col0 += 32) {
+      double acc[4][4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[a][c] = 0.0;
+      if (bt)
+        block_product_f64<4, 4, true>(acc, A, B, m, n, k, L, row0, col0);
+      else
+        block_product_f64<4, 4, false>(acc, A, B, m, n, k, L, row0, col0);
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int row = row0 + 8 * a + L.rowd, col = col0 + 8 * c + L.coll;
+          if (row < m && col < n) unsafeAtomicAdd(C + row + (size_t)m * col, acc[a][c]);
+        }
+    }
+}
+
+// device copy of the host records, one buffer per stream (calls on one stream are ordered; the host calls from several OpenMP
+// threads with their own streams)
+struct MixedScratch {
+  std::mutex mu;
+  std::map<hipStream_t, std::pair<int*, size_t>> buf;  // stream -> (device buffer, capacity in ints)
+  int* get(hipStream_t st, size_t nints) {
+    std::lock_guard<std::mutex> lk(mu);
+    auto& e = buf[st];
+    if (e.second < nints) {
+      if (e.first) (void)hipFree(e.first);  // (hipFree waits for the device: the old buffer is no longer in use)
+      e.first = nullptr;
+      e.second = 0;
+      const size_t want = nints + nints / 4 + 1024;
+      if (hipMalloc(reinterpret_cast<void**>(&e.first), want * sizeof(int)) != hipSuccess) return nullptr;
+      e.second = want;
+    }
+    return e.first;
+  }
+};
+static MixedScratch g_mixed;
+
+int process_stack_f64_mixed(const int* host_params, int nstack, const double* a, const double* b, double* c, int max_dim, hipStream_t st) {
+  if (nstack <= 0) return 0;
+  if (!host_params) return -1;
+  int* dev = g_mixed.get(st, (size_t)7 * nstack);
+  if (!dev) return -1;
+  // (the records live in ordinary host memory that the host reuses after this call: a copy from pageable memory has read its
+  // source when the call returns)
+  ACC_CHECK(hipMemcpyAsync(dev, host_params, sizeof(int) * 7 * (size_t)nstack, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(smm_stack_f64_mixed, dim3((nstack + 3) / 4), dim3(256), 0, st, dev, nstack, a, b, c, max_dim);
+  return dbcsr_amd::check(hipGetLastError(), "smm_stack_f64_mixed launch", __FILE__, __LINE__);
+}
+
 }  // namespace dbcsr_amd
 
 using namespace dbcsr_amd;
@@ -403,9 +479,13 @@ int libsmm_acc_transpose(const int* dev_trs_stack, int offset, int stack_size, v
 int libsmm_acc_process(const int* host_param_stack, const int* dev_param_stack, int stack_size, libsmm_acc_data_t datatype,
                        const void* dev_a_data, const void* dev_b_data, void* dev_c_data, int m_max, int n_max, int k_max,
                        int max_kernel_dim, c_dbcsr_acc_bool_t def_mnk, void* stack_stream, void* c_stream) {
-  (void)host_param_stack;
   (void)c_stream;
-  if (def_mnk != 1) return -1;  // inhomogeneous stack: host path
+  if (def_mnk != 1) {
+    // inhomogeneous stack: on the device from the host's own records for fp64 (see smm_stack_f64_mixed), host path otherwise
+    if (datatype != dbcsr_type_real_8 || !host_param_stack || getenv("DBCSR_AMD_SMM_MIXED_ON_HOST")) return -1;
+    return process_stack_f64_mixed(host_param_stack, stack_size, static_cast<const double*>(dev_a_data), static_cast<const double*>(dev_b_data),
+                                   static_cast<double*>(dev_c_data), max_kernel_dim, stream_of(stack_stream));
+  }
   if (datatype == dbcsr_type_real_8) {
     // B was transposed by libsmm_acc_transpose iff its own dims (k x n) are both <= max_kernel_dim
     const bool bt = (k_max <= max_kernel_dim && n_max <= max_kernel_dim);

@@ -186,3 +186,20 @@ def test_reference_unittests_through_resident_engine(prog, tmp_path):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     check_unittest_output(r.stdout, prog)
     assert r.stdout.count("dbcsr_amd_resident:") > 10, "hardly any multiply took the device-resident path"
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(HOST_RES, "dbcsr_resident_loop")), reason="patched reference host not built (tools/build_dbcsr_host.py resident)")
+@pytest.mark.parametrize("args", [("2316", "0.8", "23", "5"), ("3000", "0.7", "13", "3"), ("1500", "0.5", "32", "4")], ids=["23", "13", "32"])
+def test_fortran_host_keeps_matrices_on_the_device(args, tmp_path):
+    """tests/fortran/dbcsr_resident_loop.F90: a Fortran host that uploads A, B, C once (dbcsr_amd_dev_create), multiplies nrep times in
+    HBM (dbcsr_amd_dev_multiply: C <- beta C + alpha A B, C's pattern changes after the first step, the plan is reused afterwards) and
+    downloads C once, against the same loop through the library's own dbcsr_multiply: same checksums (1e-10), and no PCIe traffic per
+    multiply -- the per-multiply time of the resident loop must be far below the build's own dbcsr_multiply."""
+    r = subprocess.run([os.path.join(HOST_RES, "dbcsr_resident_loop"), *args, "1"], cwd=tmp_path, env=dict(ENV, DBCSR_AMD_RESIDENT="0"),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    d = re.search(r"relative difference\s+([0-9.E+-]+)", r.stdout)
+    assert d and float(d.group(1)) <= 1e-10, r.stdout[-2000:]
+    t_dev = float(re.search(r"per multiply \[s\]\s+([0-9.]+)", r.stdout).group(1))
+    t_ref = float(re.search(r"dbcsr_multiply of this build, per multiply \[s\]\s+([0-9.]+)", r.stdout).group(1))
+    assert t_dev < t_ref, r.stdout[-2000:]

@@ -94,13 +94,60 @@ def test_fp32_stack_odd_sizes(m, n, k):
     assert float(np.max(np.abs(c - c_ref))) <= 2e-5 * float(np.max(np.abs(c_ref)))
 
 
+def test_inhomogeneous_stack_runs_on_the_device():
+    """A stack with different (m, n, k) per entry (def_mnk = 0): the reference's library refuses it (libsmm_acc.cpp:324-339 returns
+    -1, the host multiplies it on the CPU and aborts in G2G mode); here it is read from the host's own 7-integer records (unsorted,
+    ordinary host memory) and run on the device.  B blocks with both dims <= max_kernel_dim arrive transposed, the others as stored."""
+    rng = np.random.default_rng(11)
+    lib = L.load_library()
+    st = StreamHandle()
+    sizes = [4, 13, 23, 32, 7, 45, 90]
+    nstack, max_dim = 700, 80
+    # data areas: blocks of random sizes back to back
+    ent, a_parts, b_parts, c_off, c_sizes = [], [], [], [], []
+    a_len = b_len = 0
+    c_blocks = [(int(rng.choice(sizes)), int(rng.choice(sizes))) for _ in range(40)]
+    c_pos = np.concatenate([[0], np.cumsum([m * n for m, n in c_blocks])])
+    for _ in range(nstack):
+        ci = int(rng.integers(0, len(c_blocks)))
+        m, n = c_blocks[ci]
+        k = int(rng.choice(sizes))
+        A = rng.random((m, k))
+        B = rng.random((k, n))
+        a_parts.append(A.flatten(order="F"))
+        bt = k <= max_dim and n <= max_dim
+        b_parts.append((B.T if bt else B).flatten(order="F"))   # what libsmm_acc_transpose leaves behind: n x k column-major
+        ent.append((m, n, k, a_len + 1, b_len + 1, int(c_pos[ci]) + 1, ci + 1, A, B))
+        a_len += m * k
+        b_len += k * n
+    a = np.concatenate(a_parts)
+    b = np.concatenate(b_parts)
+    c0 = rng.random(int(c_pos[-1]))
+    c_ref = c0.copy()
+    for (m, n, k, ao, bo, co, ci, A, B) in ent:
+        blk = c_ref[co - 1:co - 1 + m * n].reshape((m, n), order="F")
+        blk += A @ B
+    host = np.ascontiguousarray(np.array([e[:7] for e in ent], np.int32))   # 7 x nstack, column-major == rows of 7
+    ta, tb, tc = torch.as_tensor(a).cuda(), torch.as_tensor(b).cuda(), torch.as_tensor(c0.copy()).cuda()
+    dummy = torch.zeros(3 * nstack, dtype=torch.int32, device="cuda")
+    rc = lib.libsmm_acc_process(host.ctypes.data, dummy.data_ptr(), nstack, L.dbcsr_type_real_8, ta.data_ptr(), tb.data_ptr(), tc.data_ptr(),
+                                max(sizes), max(sizes), max(sizes), max_dim, 0, st.ptr, st.ptr)
+    assert rc == 0
+    host[:] = -12345   # the host reuses its records right after the call
+    torch.cuda.synchronize()
+    assert rel_err(tc.cpu().numpy(), c_ref) <= 1e-10
+
+
 def test_return_codes():
     lib = L.load_library()
     st = StreamHandle()
     z = torch.zeros(64, dtype=torch.float64, device="cuda")
     s = torch.ones(3, dtype=torch.int32, device="cuda")
-    # inhomogeneous stack -> -1, complex -> -10 : "run this stack on the CPU", never abort
+    # inhomogeneous stack without the host's records (or not fp64) -> -1, complex -> -10 : "run this stack on the CPU", never abort
     assert lib.libsmm_acc_process(None, s.data_ptr(), 1, L.dbcsr_type_real_8, z.data_ptr(), z.data_ptr(), z.data_ptr(), 4, 4, 4, 80, 0,
+                                  st.ptr, st.ptr) == -1
+    h = np.array([4, 4, 4, 1, 1, 1, 1], np.int32)
+    assert lib.libsmm_acc_process(h.ctypes.data, s.data_ptr(), 1, L.dbcsr_type_real_4, z.data_ptr(), z.data_ptr(), z.data_ptr(), 4, 4, 4, 80, 0,
                                   st.ptr, st.ptr) == -1
     assert lib.libsmm_acc_process(None, s.data_ptr(), 1, L.dbcsr_type_complex_8, z.data_ptr(), z.data_ptr(), z.data_ptr(), 2, 2, 2, 80,
                                   1, st.ptr, st.ptr) == -10

@@ -155,6 +155,12 @@ def build_variant(variant, scratch, exp, files, jobs, reuse=False):
     dump_obj = os.path.join(bdir, "dbcsr_ref_dump.o")
     subprocess.check_call([FC] + flags + ["-c", dump_src, "-o", dump_obj])
     subprocess.check_call([FC, dump_obj] + lib_objs + link + ["-o", os.path.join(outdir, "dbcsr_ref_dump")])
+    if variant == "resident":
+        # a host that keeps its matrices on the device across multiplies (dbcsr_amd_dev_* of the glue module)
+        loop_src = os.path.join(ROOT, "tests", "fortran", "dbcsr_resident_loop.F90")
+        loop_obj = os.path.join(bdir, "dbcsr_resident_loop.o")
+        subprocess.check_call([FC] + flags + ["-c", loop_src, "-o", loop_obj])
+        subprocess.check_call([FC, loop_obj] + lib_objs + link + ["-o", os.path.join(outdir, "dbcsr_resident_loop")])
     print("built", outdir, sorted(os.listdir(outdir)))
 
 

@@ -138,7 +138,7 @@ def run_case(c, exe=DUMP, env=None, with_stdout=False):
         e.update(env or {})
         r = subprocess.run([exe, nml, out], cwd=td, env=e, capture_output=True, text=True, timeout=600)
         if r.returncode != 0 or not os.path.exists(out):
-            raise RuntimeError("dbcsr_ref_dump failed on %s:\n%s\n%s" % (c["name"], r.stdout[-2000:], r.stderr[-2000:]))
+            raise RuntimeError("dbcsr_ref_dump failed on %s (return code %d):\n%s\n%s" % (c["name"], r.returncode, r.stdout[-2000:], r.stderr[-2000:]))
         return (parse_dump(out), r.stdout) if with_stdout else parse_dump(out)
 
 

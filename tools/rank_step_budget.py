@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Step budget of ONE rank of an N-GPU run, measured on one GPU (development tool).
+
+For N in 1, 2, 4, 8 the block patterns of BASELINE config 2 (or --workload) are cut as dbcsr_amd.cannon does for an N-rank
+grid, and the local multiply of rank 0 -- its full A row panel times its full B column panel into its C tile, the "gather"
+schedule's one multiply per step -- is run alone on the GPU with synthetic values.  Reported per multiply: wall time of the call
+sequence (symbolic + numeric as the driver issues them, then a device synchronisation), the block-product kernel's own time
+(HIP events), and their difference = everything a rank spends per step outside the kernel (plan comparison and its one
+synchronisation, kernel launches, Python, allocation of the result) -- the fixed cost that bounds strong scaling.
+   python tools/rank_step_budget.py [--workload NAME] [--plan 0|1]"""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+
+
+def main():
+    p = argparse.ArgumentParser()
+    p.add_argument("--workload", default="config2_32768_23x23_fill10_fp64")
+    p.add_argument("--ranks", default="1,2,4,8")
+    p.add_argument("--steps", type=int, default=10)
+    a = p.parse_args()
+    import bench
+    from dbcsr_amd import cannon
+    from dbcsr_amd.multiply import MultiplyEngine
+    M, N, K, fill, mix, dt = bench.WORKLOADS[a.workload]
+    dtype = torch.float64 if dt == "f64" else torch.float32
+    print("# workload %s; plan reuse %s" % (a.workload, os.environ.get("DBCSR_AMD_MM_PLAN", "1")))
+    print("# ranks grid  C_blocks  products   GFLOP   wall_ms  kernel_ms  fill_ms  non_kernel_ms  kernel")
+    for n in [int(x) for x in a.ranks.split(",")]:
+        eng = MultiplyEngine()
+        g = cannon.Grid(n, 0)
+        plan = cannon.CannonMultiply(M, N, K, (1 - fill,) * 3, mix, dtype=dtype, engine=eng, grid=g)
+        # images owned by other ranks: synthetic values in place (what would have arrived over xGMI)
+        for buf in (plan._a_all, plan._b_all):
+            buf.uniform_(0.0, 1.0)
+        torch.cuda.synchronize()
+
+        def step():
+            row_p, counts = eng.symbolic(plan.A_panel, plan.B_panel, plan.C_in, retain_sparsity=False)
+            out = eng.numeric_after_symbolic(1.0, plan.A_panel, plan.B_panel, 1.0, plan.C_in, row_p, counts, dtype)
+            return out, counts
+
+        for _ in range(3):
+            out, counts = step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            out, counts = step()
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / a.steps * 1e3
+        ks, fs = [], []
+        for _ in range(3):
+            out, counts = step()
+            f, k = eng.last_timing()
+            ks.append(k)
+            fs.append(f)
+        km, fm = sum(ks) / len(ks), sum(fs) / len(fs)
+        print("%7d %dx%d %9d %9d %8.1f %9.3f %9.3f %8.3f %12.3f   %s" % (n, g.nprows, g.npcols, counts.c_nblks, counts.nproducts, counts.flop / 1e9, wall, km,
+                                                                       fm, wall - km, eng.last_kernel()))
+        del plan, eng, out
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()
