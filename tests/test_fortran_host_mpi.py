@@ -1,0 +1,72 @@
+"""The UNCHANGED reference as a real multi-rank MPI program (tools/build_dbcsr_host.py cpu_mpi / acc_mpi: -D__parallel, the image's
+MPICH through a module `mpi` made of MPICH's own mpif.h, launched with mpiexec):
+  * CPU build, 2 / 4 ranks, the reference's golden .perf inputs (the driver checks its checksums itself): pins what a multi-rank
+    run of the reference computes -- and that the MPI build of this repository's tooling is a faithful one;
+  * (-m gpu) the same library linked against libdbcsr_acc_amd.so, 2 / 4 / 8 ranks SHARING the one GPU of the box (device = rank
+    mod ndevices, src/core/dbcsr_lib.F:231-236): the reference's own Fortran Cannon loop -- make_m2s, MPI isend / irecv of the
+    panels, one OpenMP team per rank driving the acc ABI -- on this back end, against the same golden checksums.
+The binaries are built in the build container (oracle/_ref/host_cpu_mpi, host_acc_mpi: git-ignored, they travel with the snapshot)."""
+import json
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+from tests.test_gpu_fortran_host import write_perf
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "perf_golden.json")))
+MPIEXEC = shutil.which("mpiexec") or "/opt/conda/bin/mpiexec"
+ENV = dict(os.environ, MKL_THREADING_LAYER="SEQUENTIAL", OMP_NUM_THREADS="2")
+CASES = sorted(k for k, v in GOLD.items() if v["check"] == "T" and v["data_type"] == 3)
+
+
+def run_perf(host, name, nranks, tmp_path, env):
+    exe = os.path.join(ROOT, "oracle", "_ref", host, "dbcsr_perf")
+    if not (os.path.exists(exe) and os.path.exists(MPIEXEC)):
+        pytest.skip("%s or mpiexec not available" % host)
+    c = dict(GOLD[name])
+    c["npcols"] = 0   # let MPI_Dims_create choose the grid (the golden checksums do not depend on it)
+    write_perf(c, tmp_path / "case.perf")
+    r = subprocess.run([MPIEXEC, "-n", str(nranks), exe, str(tmp_path / "case.perf")], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert re.search(r"numnodes\s+%d\b" % nranks, r.stdout), r.stdout[:2000]
+    m = re.search(r"checksum\(C_out\)\s*=\s*([0-9.E+-]+)", r.stdout)
+    mp = re.search(r"checksum\(C_out\) POS\s*=\s*([0-9.E+-]+)", r.stdout)
+    assert m and mp, r.stdout[-3000:]
+    assert abs(float(m.group(1)) / c["checksum"] - 1.0) <= c["threshold"]
+    assert abs(float(mp.group(1)) / c["checksum_pos"] - 1.0) <= c["threshold"]
+    return r.stdout
+
+
+@pytest.mark.parametrize("nranks", [2, 4])
+@pytest.mark.parametrize("name", ["test_square_sparse.perf", "test_rect1_sparse.perf", "test_rect2_dense.perf"])
+def test_reference_mpi_build_reproduces_golden_checksums_on_cpu(name, nranks, tmp_path):
+    run_perf("host_cpu_mpi", name, nranks, tmp_path, ENV)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nranks", [2, 4, 8])
+@pytest.mark.parametrize("name", CASES)
+def test_reference_mpi_host_on_acc_backend_shared_gpu(name, nranks, tmp_path):
+    if nranks == 8 and name not in ("test_square_sparse.perf", "test_square_dense.perf", "test_rect1_sparse.perf"):
+        pytest.skip("eight ranks on the three cases with enough blocks per rank")
+    out = run_perf("host_acc_mpi", name, nranks, tmp_path, ENV)
+    c = GOLD[name]
+    acc = re.search(r"flops total\s+\S+\s+([0-9.]+)%\s+([0-9.]+)%\s+([0-9.]+)%", out)
+    assert acc, out[-3000:]
+    if max(c["bs_m"][1::2] + c["bs_n"][1::2] + c["bs_k"][1::2]) <= 80:
+        assert float(acc.group(3)) > 50.0, "less than half of the flops went through libsmm_acc_process:\n" + out[-3000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nranks", [2, 4])
+def test_reference_mpi_unittest_on_acc_backend(nranks, tmp_path):
+    exe = os.path.join(ROOT, "oracle", "_ref", "host_acc_mpi", "dbcsr_unittest3")
+    if not (os.path.exists(exe) and os.path.exists(MPIEXEC)):
+        pytest.skip("host_acc_mpi or mpiexec not available")
+    r = subprocess.run([MPIEXEC, "-n", str(nranks), exe], cwd=tmp_path, env=ENV, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " FAILED !" not in r.stdout.upper() and r.stdout.upper().count("PASSED !") > 0, r.stdout[-3000:]

@@ -116,8 +116,19 @@ def build_variant(variant, scratch, exp, files, jobs, reuse=False):
     os.makedirs(bdir, exist_ok=True)
     flags = ["-cpp", "-O2", "-fopenmp", "-D__MKL", "-D__NO_STATM_ACCESS", "-J", bdir, "-I", bdir,
              "-I", os.path.join(exp, "src"), "-I", os.path.join(exp, "src", "base")]
-    if variant in ("acc", "resident"):
+    base = variant[:-4] if variant.endswith("_mpi") else variant
+    if base in ("acc", "resident"):
         flags += ["-D__DBCSR_ACC"]
+    if variant.endswith("_mpi"):
+        # a REAL multi-rank build: -D__parallel switches the reference's MPI layer (src/mpi/dbcsr_mpiwrap.F) from its serial stubs to
+        # MPI calls.  It says USE mpi; the image's mpi.mod was written by gfortran and amdflang cannot read it, but the image's
+        # MPICH also ships the compiler-independent Fortran 77 interface (mpif.h: constants, COMMON blocks, external routines
+        # with the f77 calling convention of libmpifort): a module `mpi` that just INCLUDEs it is compiled first.
+        flags += ["-D__parallel", "-I", "/opt/conda/include"]
+        mod_src = os.path.join(bdir, "mpi_from_mpif_h.F90")
+        with open(mod_src, "w") as fh:
+            fh.write("MODULE mpi\n   IMPLICIT NONE\n   INCLUDE 'mpif.h'\nEND MODULE mpi\n")
+        subprocess.check_call([FC] + flags + ["-c", mod_src, "-o", os.path.join(bdir, "mpi_from_mpif_h.o")])
     lib_files = [f for f in files if os.sep + "src" + os.sep in f]
     test_files = [f for f in files if os.sep + "tests" + os.sep in f]
 
@@ -145,7 +156,9 @@ def build_variant(variant, scratch, exp, files, jobs, reuse=False):
     os.makedirs(outdir, exist_ok=True)
     lib_objs = [objs[f] for f in lib_files]
     link = ["-fopenmp", "-L/opt/conda/lib", "-lmkl_rt", "-Wl,-rpath,/opt/conda/lib"]
-    if variant in ("acc", "resident"):
+    if variant.endswith("_mpi"):
+        link = [os.path.join(bdir, "mpi_from_mpif_h.o")] + link + ["-lmpifort", "-lmpi"]
+    if base in ("acc", "resident"):
         link += ["-L" + os.path.join(ROOT, "dbcsr_amd"), "-ldbcsr_acc_amd", "-Wl,-rpath,$ORIGIN/../../../dbcsr_amd"]
     for prog, srcs in TEST_PROGRAMS.items():
         pobjs = [objs[f] for f in test_files if os.path.basename(f)[:-4] + ".F" in srcs]
@@ -155,7 +168,7 @@ def build_variant(variant, scratch, exp, files, jobs, reuse=False):
     dump_obj = os.path.join(bdir, "dbcsr_ref_dump.o")
     subprocess.check_call([FC] + flags + ["-c", dump_src, "-o", dump_obj])
     subprocess.check_call([FC, dump_obj] + lib_objs + link + ["-o", os.path.join(outdir, "dbcsr_ref_dump")])
-    if variant == "resident":
+    if base == "resident":
         # a host that keeps its matrices on the device across multiplies (dbcsr_amd_dev_* of the glue module)
         loop_src = os.path.join(ROOT, "tests", "fortran", "dbcsr_resident_loop.F90")
         loop_obj = os.path.join(bdir, "dbcsr_resident_loop.o")
@@ -166,8 +179,9 @@ def build_variant(variant, scratch, exp, files, jobs, reuse=False):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("variant", nargs="?", default="both", choices=["cpu", "acc", "both", "resident"],
-                    help="resident = acc + the call-site patch (dbcsr_multiply -> device-resident engine), output oracle/_ref/host_resident")
+    ap.add_argument("variant", nargs="?", default="both", choices=["cpu", "acc", "both", "resident", "cpu_mpi", "acc_mpi"],
+                    help="resident = acc + the call-site patch (dbcsr_multiply -> device-resident engine), output oracle/_ref/host_resident; "
+                         "cpu_mpi / acc_mpi = the same library as a real multi-rank MPI build (MPICH of the image, mpiexec)")
     ap.add_argument("--scratch", default="/tmp/dbcsr_host")
     ap.add_argument("--jobs", type=int, default=16)
     ap.add_argument("--patch", action="append", default=[])
