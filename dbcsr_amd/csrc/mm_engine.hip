@@ -216,7 +216,8 @@ struct Engine {
   int use_tiny = 1;                     // DBCSR_AMD_MM_TINY=0: no packed kernel for blocks of at most 4 x 4
   int use_hot = 1;                      // DBCSR_AMD_MM_HOT=0: never use the exact-size kernels
   int lds_pad = 0;                      // DBCSR_AMD_MM_LDS_PAD: extra LDS bytes per workgroup (occupancy experiments)
-  int64_t panel_bytes = 160ll << 20;  // DBCSR_AMD_MM_PANEL_MB: target size of a B column panel
+  int64_t panel_bytes = 256ll << 20;  // DBCSR_AMD_MM_PANEL_MB: target size of a B column panel (config 2, round 3: 160 / 200 / 256 / 320 / 400 MB ->
+                                      // 18.97 / 18.76 / 18.63 / 18.95 / 19.04 ms, profiles/r03_panel_wgwaves_sweep.txt)
   int row_group = 0;                 // DBCSR_AMD_MM_ROW_GROUP: rows walked together per XCD (0 = automatic)
   DevBuf<unsigned long long> dev_scalars, stat_table;
   int64_t* host_scalars = nullptr;  // pinned: [0]=c_nblks [1]=c_nze [2]=nproducts [3]=flop

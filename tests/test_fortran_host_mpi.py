@@ -70,3 +70,33 @@ def test_reference_mpi_unittest_on_acc_backend(nranks, tmp_path):
     r = subprocess.run([MPIEXEC, "-n", str(nranks), exe], cwd=tmp_path, env=ENV, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " FAILED !" not in r.stdout.upper() and r.stdout.upper().count("PASSED !") > 0, r.stdout[-3000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nranks", [2, 4])
+@pytest.mark.parametrize("name", ["test_square_sparse.perf", "test_square_dense.perf", "test_rect1_sparse.perf", "test_rect1_dense.perf", "test_H2O.perf"])
+def test_resident_engine_under_a_multi_rank_fortran_host(name, nranks, tmp_path):
+    """dbcsr_amd/fortran/dbcsr_amd_resident.F, multi_rank_multiply: the patched reference host on several MPI ranks -- each rank
+    gathers the row panel of A over its process row and the column panel of B over its process column (MPI), multiplies them on
+    the device into its part of C and puts that part back.  The driver's golden checksums must come out, and every rank must have
+    taken the device path."""
+    if GOLD[name]["check"] != "T":
+        pytest.skip("no golden checksum in this input")
+    out = run_perf("host_resident_mpi", name, nranks, tmp_path, dict(ENV, DBCSR_AMD_RESIDENT="1v"))
+    ranks = set(int(m) for m in re.findall(r"dbcsr_amd_resident: rank\s+(\d+) of", out))
+    assert ranks == set(range(nranks)), "not every rank multiplied on the device:\n" + out[-2500:]
+    mm = re.search(r"matmuls total\s+(\d+)", out)
+    assert mm and int(mm.group(1)) == 0, out[-3000:]   # no parameter stack was built anywhere
+
+
+@pytest.mark.gpu
+def test_resident_multi_rank_falls_through_together(tmp_path):
+    """the reference's multiply unit tests (limits, symmetries, transposes, types) on two ranks of the patched host: whatever the
+    multi-rank device path does not take must fall through to the reference path on ALL ranks together (a rank alone in a
+    collective would hang), and every case must still pass"""
+    exe = os.path.join(ROOT, "oracle", "_ref", "host_resident_mpi", "dbcsr_unittest3")
+    if not (os.path.exists(exe) and os.path.exists(MPIEXEC)):
+        pytest.skip("host_resident_mpi or mpiexec not available")
+    r = subprocess.run([MPIEXEC, "-n", "2", exe], cwd=tmp_path, env=dict(ENV, DBCSR_AMD_RESIDENT="1"), capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " FAILED !" not in r.stdout.upper() and r.stdout.upper().count("PASSED !") > 0, r.stdout[-3000:]

@@ -179,7 +179,7 @@ def build_variant(variant, scratch, exp, files, jobs, reuse=False):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("variant", nargs="?", default="both", choices=["cpu", "acc", "both", "resident", "cpu_mpi", "acc_mpi"],
+    ap.add_argument("variant", nargs="?", default="both", choices=["cpu", "acc", "both", "resident", "cpu_mpi", "acc_mpi", "resident_mpi"],
                     help="resident = acc + the call-site patch (dbcsr_multiply -> device-resident engine), output oracle/_ref/host_resident; "
                          "cpu_mpi / acc_mpi = the same library as a real multi-rank MPI build (MPICH of the image, mpiexec)")
     ap.add_argument("--scratch", default="/tmp/dbcsr_host")
@@ -190,7 +190,7 @@ def main():
     if not os.path.isdir(REF):
         raise SystemExit("the reference is not mounted here: nothing to build (the GPU box uses the prebuilt oracle/_ref)")
     os.makedirs(a.scratch, exist_ok=True)
-    if a.variant == "resident" and not a.patch:
+    if a.variant.startswith("resident") and not a.patch:
         a.patch = [os.path.join(ROOT, "dbcsr_amd", "fortran", "dbcsr_mm_call_site.patch")]
     if a.reuse and os.path.isdir(os.path.join(a.scratch, "expanded")):
         exp = os.path.join(a.scratch, "expanded")
@@ -198,7 +198,7 @@ def main():
         glue_dst = os.path.join(exp, "src", "mm", "dbcsr_amd_resident.F90")
         if os.path.exists(glue_dst):   # this repository's own module may have changed since: refresh it and what uses it
             shutil.copy(os.path.join(ROOT, "dbcsr_amd", "fortran", "dbcsr_amd_resident.F"), glue_dst)
-            o = os.path.join(a.scratch, "build_resident", "dbcsr_amd_resident.o")
+            o = os.path.join(a.scratch, "build_" + a.variant, "dbcsr_amd_resident.o")
             if os.path.exists(o):
                 os.remove(o)
     else:
