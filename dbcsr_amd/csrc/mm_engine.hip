@@ -237,6 +237,7 @@ struct Engine {
   int use_tile = 0, tile_window = 256, tile_rdv = 0, tile_pub = 1, tile_prefetch = 0, tile_knobs = 0;  // DBCSR_AMD_MM_TILE_PUB: progress stores written through (0) / left in L2 (1)
   int hot_cnt_m = 0, hot_cnt_k = 0, hot_cnt_n = 0;  // block rows / inner blocks / block columns of the dominant size
   DevBuf<uint32_t> a_bm, bt_bm, tile_prog;
+  DevBuf<unsigned long long> tile_times;
   DevBuf<int> a_pre, tile_rows, tile_cols, tile_cnt, tile_flags;
   DevBuf<int64_t> tile_start;
   DevBuf<TileDesc> tdescs;
@@ -261,6 +262,11 @@ struct Engine {
   int use_classes = 1;
   int class_g = 1;  // DBCSR_AMD_MM_CLASS_G: C blocks per wave in the class kernels (1, 2, 4, 8)
   bool cls_mode = false;
+  // DBCSR_AMD_MM_CLASS_STREAMS: the class launches of one multiply touch disjoint C blocks; with n > 1 they are spread over n streams
+  // (the caller's + n - 1 of the engine's, forked / joined with events) so that the tail of one launch overlaps the body of the next
+  int class_streams = 1;
+  hipStream_t side_stream[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t fork_ev = nullptr, join_ev[3] = {nullptr, nullptr, nullptr};
   int cls_m[3] = {0, 0, 0}, cls_n[3] = {0, 0, 0}, cls_k[3] = {0, 0, 0};
   int64_t cls_len[kNumClasses] = {0}, cls_off[kNumClasses] = {0};
   DevBuf<int> cls_hist;
@@ -432,6 +438,12 @@ static int run_tile_f64(Engine* E, hipStream_t st, const dbcsr_amd_bcsr* a, cons
   P.pub_policy = E->tile_pub;
   P.prefetch = E->tile_prefetch;
   P.knobs = E->tile_knobs;
+  P.times = nullptr;
+  if (E->tile_knobs & 32) {
+    if (E->tile_times.ensure(8)) return -1;
+    ACC_CHECK(hipMemsetAsync(E->tile_times.p, 0, 8 * sizeof(unsigned long long), st));
+    P.times = E->tile_times.p;
+  }
   ACC_CHECK(hipEventRecord(E->ev[1], st));  // the timed numeric launch starts here (the index work above counts as fill time)
   if (tile_launch(S_, S_, S_, E->tile_rdv, (unsigned)(8 * cu_per_xcd), st, P)) return -1;
   if (tile_launch_remainder(S_, S_, st, G, E->tdescs.p, E->tentries.p, P.a_data, P.b_data, P.c_out, alpha)) return -1;
@@ -489,6 +501,7 @@ int dbcsr_amd_mm_create(void** handle) {
     E->force_word_kernels = strcmp(k, "word") == 0;
     E->force_symbolic = strcmp(k, "word") == 0 ? 1 : (strcmp(k, "grid") == 0 ? 2 : (strcmp(k, "rows") == 0 ? 3 : 0));
   }
+  if (const char* k = getenv("DBCSR_AMD_MM_CLASS_STREAMS")) E->class_streams = std::min(4, std::max(1, atoi(k)));
   if (const char* k = getenv("DBCSR_AMD_MM_PANEL_MB")) E->panel_bytes = (int64_t)atoll(k) << 20;
   if (const char* k = getenv("DBCSR_AMD_MM_ROW_GROUP")) E->row_group = atoi(k);
   for (int i = 0; i < 3; ++i) {
@@ -532,6 +545,11 @@ int dbcsr_amd_mm_destroy(void* handle) {
   E->cls_hist.release(); E->cls_row.release(); E->cls_col.release(); E->cls_col_bm.release(); E->cls_lens.release();
   for (int i = 0; i < 3; ++i)
     if (E->ev[i]) (void)hipEventDestroy(E->ev[i]);
+  for (int i = 0; i < 3; ++i) {
+    if (E->side_stream[i]) (void)hipStreamDestroy(E->side_stream[i]);
+    if (E->join_ev[i]) (void)hipEventDestroy(E->join_ev[i]);
+  }
+  if (E->fork_ev) (void)hipEventDestroy(E->fork_ev);
   delete E;
   return 0;
 }
@@ -923,8 +941,26 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
       const int g_maxt = (std::max(E->max_m, E->max_n) + 7) / 8;
       const int dbgv = E->dbg | (skip_empty ? 32 : 0);
       int njit = 0, ngen = 0, jit_mask = 0;
+      const hipStream_t st_main = st;
+      int nside = 0, nlaunch = 0;
+      if (E->class_streams > 1) {
+        nside = E->class_streams - 1;
+        if (!E->fork_ev) ACC_CHECK(hipEventCreateWithFlags(&E->fork_ev, hipEventDisableTiming));
+        ACC_CHECK(hipEventRecord(E->fork_ev, st_main));
+        for (int i = 0; i < nside; ++i) {
+          if (!E->side_stream[i]) {
+            ACC_CHECK(hipStreamCreateWithFlags(&E->side_stream[i], hipStreamNonBlocking));
+            ACC_CHECK(hipEventCreateWithFlags(&E->join_ev[i], hipEventDisableTiming));
+          }
+          ACC_CHECK(hipStreamWaitEvent(E->side_stream[i], E->fork_ev, 0));
+        }
+      }
       for (int c = 0; c < kNumClasses; ++c) {
         if (E->cls_len[c] == 0) continue;
+        {
+          const int slot = nlaunch++ % (nside + 1);
+          st = slot == 0 ? st_main : E->side_stream[slot - 1];
+        }
         const int* ord = E->order.p + E->cls_off[c];
         const unsigned nwg_c = (unsigned)(8 * E->cls_len[c] / 4);
         ClassKernel ck;
@@ -962,6 +998,11 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
 #undef DBCSR_LAUNCH_G
           ++ngen;
         }
+      }
+      st = st_main;
+      for (int i = 0; i < nside; ++i) {
+        ACC_CHECK(hipEventRecord(E->join_ev[i], E->side_stream[i]));
+        ACC_CHECK(hipStreamWaitEvent(st_main, E->join_ev[i], 0));
       }
       if (epi_norms) {  // the blocks the generic kernel handled did not leave their norm
         ClassSet cs;
@@ -1504,6 +1545,13 @@ int dbcsr_amd_mm_tile_stats(void* handle, int* waves_gave_up, int* list_mismatch
   ACC_CHECK(hipMemcpy(h, E->tile_flags.p, sizeof h, hipMemcpyDeviceToHost));
   if (waves_gave_up) *waves_gave_up = h[0];
   if (list_mismatches) *list_mismatches = h[1];
+  if ((E->tile_knobs & 32) && E->tile_times.p) {
+    unsigned long long t[8];
+    ACC_CHECK(hipMemcpy(t, E->tile_times.p, sizeof t, hipMemcpyDeviceToHost));
+    const double w = t[5] ? (double)t[5] : 1.0;
+    fprintf(stderr, "dbcsr_amd tile kernel, mean per wave [ms]: total %.3f = window waits %.3f + operand waits %.3f + multiplies %.3f + epilogues %.3f + rest %.3f (%llu waves)\n",
+            t[0] / w * 1e-5, t[1] / w * 1e-5, t[2] / w * 1e-5, t[3] / w * 1e-5, t[4] / w * 1e-5, ((double)t[0] - t[1] - t[2] - t[3] - t[4]) / w * 1e-5, t[5]);
+  }
   if (getenv("DBCSR_AMD_MM_TILE_VERBOSE"))
     fprintf(stderr, "dbcsr_amd tile kernel: %d waves gave up, %lld reads of the team counters, %lld products waited for the window (of %lld)\n", h[0],
             16ll * h[2], 16ll * h[3], (long long)E->nproducts);

@@ -70,6 +70,7 @@ struct TileArgs {
   int window;      // W, in inner blocks; <= 0: no throttle
   int pub_policy;  // progress stores: 0 = written through (device scope), 1 = left in the XCD's L2
   int prefetch;    // 1: the blocks of the product after the next one are pulled into L2 ahead of their DMA
+  unsigned long long* times;  // [6] sums over the waves (knob bit 5): total, window waits, operand waits, multiplies, epilogues [10 ns], waves
   int knobs;       // tuning switches of the team protocol (mm_tile.hip): bits 0-2 publish quantum shift, 3 issue priority, 4 short sleep
 };
 

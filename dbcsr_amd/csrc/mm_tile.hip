@@ -42,6 +42,11 @@ __device__ __forceinline__ unsigned tile_wave_min(unsigned v) {
   return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+__device__ __forceinline__ int64_t tile_uniform64(int64_t v) {
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
+  return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
 template <int M, int N, int K, int RDV>
 struct TileKernel {
   static constexpr int MA = (M + 7) / 8, NC = (N + 7) / 8, KS = (K + 3) / 4;
@@ -184,6 +189,10 @@ __global__ void __launch_bounds__(512) mm_numeric_f64_tile(TileArgs P) {
   unsigned pf_sink = 0;             // destination of the L2 prefetch loads (see the product loop)
   const int pf_off = lane * 128;    // one dword per 128-byte line
   unsigned n_polls = 0, n_blocked = 0;  // diagnostics: reads of the team's counters / products that had to wait for the window
+  // knob bit 5: where a wave's time goes (s_memrealtime ticks of 10 ns): window waits, waits for operands, multiplies, epilogues
+  const bool timing = (P.knobs >> 5) & 1;
+  unsigned long long t_admit = 0, t_wait = 0, t_mul = 0, t_epi = 0, t_all = 0;
+  const unsigned long long t_begin = timing ? __builtin_amdgcn_s_memrealtime() : 0ull;
   auto publish = [&](unsigned g) {
     published = g;
     if (P.pub_policy == 0)
@@ -244,7 +253,7 @@ __global__ void __launch_bounds__(512) mm_numeric_f64_tile(TileArgs P) {
     }
     const TileDesc* td = P.tdescs + ((int64_t)tr * G.nTC + tc);
     const int n = __builtin_amdgcn_readfirstlane(td->n_main);
-    const int64_t ls = td->list_start;
+    const int64_t ls = tile_uniform64(td->list_start);
     const TileEntry* e = P.entries + ls;
 #pragma unroll
     for (int sl = 0; sl < kTileSlots; ++sl)
@@ -252,18 +261,14 @@ __global__ void __launch_bounds__(512) mm_numeric_f64_tile(TileArgs P) {
       for (int a = 0; a < 3; ++a)
 #pragma unroll
         for (int c = 0; c < 3; ++c) acc[sl][a][c] = 0.0;
-    // The list is read with vector loads (lane l holds entry base + l) and handed out with v_readlane: no scalar-load latency
-    // between two products, and no SMEM in flight next to the fragment reads
-    int ebase = 0;
-    u32x4 ev = {0u, 0u, 0u, 0u};
+    // The list is read in WINDOWS of 64 entries with one vector load (lane l holds entry base + l) and handed out with v_readlane:
+    // no scalar load next to the fragment reads (SMEM returns out of order: one in flight turns every lgkmcnt wait of the
+    // multiply into lgkmcnt(0) -- measured: 22.4 -> 27.2 ms), and no vector load INSIDE the loop over a window's products (the
+    // compiler would have to place s_waitcnt vmcnt(0) where a refill branch joins, i.e. before every product, and that wait also
+    // covers the LDS-DMA pieces in flight).  Windows overlap by one entry: product p needs entry p + 1 to request its operands.
     const __amdgpu_buffer_rsrc_t rs_list = __builtin_amdgcn_make_buffer_rsrc((void*)e, 0, n * 16, 0x00020000);
-    auto load_window = [&](int base) {
-      ebase = base;
-      ev = __builtin_amdgcn_raw_buffer_load_b128(rs_list, voff, base * 16, 0);  // entries base .. base + 63 (zeros past the end)
-    };
-    auto entry_at = [&](int i) {  // i wave-uniform, ebase <= i < n
-      if (i - ebase >= 64) load_window(i);
-      const int j = __builtin_amdgcn_readfirstlane(i - ebase);
+    u32x4 ev = {0u, 0u, 0u, 0u};
+    auto entry_of = [&](int j) {  // entry base + j of the current window, j wave-uniform
       TileEntry en;
       en.a_lo = (uint32_t)__builtin_amdgcn_readlane((int)ev[0], j);
       en.b_lo = (uint32_t)__builtin_amdgcn_readlane((int)ev[1], j);
@@ -277,63 +282,93 @@ __global__ void __launch_bounds__(512) mm_numeric_f64_tile(TileArgs P) {
       dma_block<TK::ABYTES>(P.a_data + ao, lds, voff);
       dma_block<TK::BBYTES>(P.b_data + bo, lds + TK::SA, voff);
     };
-    load_window(0);
     TileEntry cur = {0u, 0u, 0u, 0u}, nxt = {0u, 0u, 0u, 0u};
-    if (n > 0) {
-      cur = entry_at(0);
-      admit((unsigned)(s * G.kspan) + cur.k);
-      issue(cur, 0);
-    }
-    for (int p = 0; p < n; ++p) {
-      const bool more = p + 1 < n;
-      if (more) {
-        nxt = entry_at(p + 1);
-        admit((unsigned)(s * G.kspan) + nxt.k);
-        issue(nxt, (p + 1) & 1);
-        if (P.prefetch && p + 2 < n) {
-          // pull the blocks of product p + 2 into this XCD's L2 ahead of their DMA (one dword per 128-byte line, lanes past the
-          // block are dropped by the descriptor's bounds check; the loaded values are never used): the ring holds one product in
-          // flight per wave, which covers an L2 hit but not a trip over the fabric
-          const TileEntry pf = entry_at(p + 2);
-          const uint64_t ao = (uint64_t)pf.a_lo | ((uint64_t)((pf.w >> 16) & 0xffu) << 32), bo = (uint64_t)pf.b_lo | ((uint64_t)(pf.w >> 24) << 32);
-          const dma_rsrc_t ra = dma_make_rsrc(P.a_data + ao, (unsigned)TK::ABYTES), rb = dma_make_rsrc(P.b_data + bo, (unsigned)TK::BBYTES);
-          // (inline asm: the compiler must never wait for these loads; they all land in ONE register that nothing else may use,
-          // kept alive until the wave's last wait)
-          asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, 0 offen sc1\n\tbuffer_load_dword %0, %1, %3, 0 offen sc1"
-                       : "+v"(pf_sink)
-                       : "v"(pf_off), "s"(ra), "s"(rb)
-                       : "memory");
-          dma_wait<TK::PIECES + 2>();
-        } else {
-          dma_wait<TK::PIECES>();  // the pieces of product p have landed (loads return in order; a pending store only makes this wait longer)
-        }
-      } else {
-        dma_wait<0>();
+    for (int base = 0; base < n; base += 63) {
+      ev = __builtin_amdgcn_raw_buffer_load_b128(rs_list, voff, base * 16, 0);  // entries base .. base + 63 (zeros past the end)
+      const int jn = n - base < 63 ? n - base : 63;
+      if (base == 0) {
+        cur = entry_of(0);
+        admit((unsigned)(s * G.kspan) + cur.k);
+        issue(cur, 0);
       }
-      const double* sl = reinterpret_cast<const double*>(ring + (p & 1) * TK::SLOT);
-      const double *pa = sl + la, *pb = sl + lb;
-      // one multiply body per accumulator set (the set is a compile-time choice: registers cannot be indexed)
-      switch (cur.w & 15u) {
+      for (int j = 0; j < jn; ++j) {
+        const int p = base + j;
+        const bool more = p + 1 < n;
+        unsigned long long t0 = timing ? __builtin_amdgcn_s_memrealtime() : 0ull;
+        if (more) {
+          nxt = entry_of(j + 1);
+          admit((unsigned)(s * G.kspan) + nxt.k);
+          if (timing) {
+            const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+            t_admit += t1 - t0;
+            t0 = t1;
+          }
+          issue(nxt, (p + 1) & 1);
+          if (P.prefetch && j + 2 < 64 && p + 2 < n) {
+            // pull the blocks of product p + 2 into this XCD's L2 ahead of their DMA (one dword per 128-byte line, lanes past the
+            // block are dropped by the descriptor's bounds check; the loaded values are never used): the ring holds one product
+            // in flight per wave, which covers an L2 hit but not a trip over the fabric
+            const TileEntry pf = entry_of(j + 2);
+            const uint64_t ao = (uint64_t)pf.a_lo | ((uint64_t)((pf.w >> 16) & 0xffu) << 32), bo = (uint64_t)pf.b_lo | ((uint64_t)(pf.w >> 24) << 32);
+            const dma_rsrc_t ra = dma_make_rsrc(P.a_data + ao, (unsigned)TK::ABYTES), rb = dma_make_rsrc(P.b_data + bo, (unsigned)TK::BBYTES);
+            // (inline asm: the compiler must never wait for these loads; they all land in ONE register that nothing else may use,
+            // kept alive until the wave's last wait)
+            asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, 0 offen sc1\n\tbuffer_load_dword %0, %1, %3, 0 offen sc1"
+                         : "+v"(pf_sink)
+                         : "v"(pf_off), "s"(ra), "s"(rb)
+                         : "memory");
+            dma_wait<TK::PIECES + 2>();
+          } else {
+            dma_wait<TK::PIECES>();  // the pieces of product p have landed (loads return in order; a pending store only makes this wait longer)
+          }
+        } else {
+          dma_wait<0>();
+        }
+        if (timing) {
+          const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+          t_wait += t1 - t0;
+          t0 = t1;
+        }
+        const double* sl = reinterpret_cast<const double*>(ring + (p & 1) * TK::SLOT);
+        const double *pa = sl + la, *pb = sl + lb;
+        // one multiply body per accumulator set (the set is a compile-time choice: registers cannot be indexed)
+        switch (cur.w & 15u) {
 #define DBCSR_TILE_CASE(S_) \
   case S_: tile_multiply<M, N, K, RDV>(acc[S_], pa, pb, ktail_dead); break;
-        DBCSR_TILE_CASE(0) DBCSR_TILE_CASE(1) DBCSR_TILE_CASE(2) DBCSR_TILE_CASE(3) DBCSR_TILE_CASE(4)
-        DBCSR_TILE_CASE(5) DBCSR_TILE_CASE(6) DBCSR_TILE_CASE(7)
+          DBCSR_TILE_CASE(0) DBCSR_TILE_CASE(1) DBCSR_TILE_CASE(2) DBCSR_TILE_CASE(3) DBCSR_TILE_CASE(4)
+          DBCSR_TILE_CASE(5) DBCSR_TILE_CASE(6) DBCSR_TILE_CASE(7)
 #undef DBCSR_TILE_CASE
-        default: tile_multiply<M, N, K, RDV>(acc[8], pa, pb, ktail_dead); break;
+          default: tile_multiply<M, N, K, RDV>(acc[8], pa, pb, ktail_dead); break;
+        }
+        if (timing) t_mul += __builtin_amdgcn_s_memrealtime() - t0;
+        cur = nxt;
       }
-      cur = nxt;
     }
+    const unsigned long long t_e0 = timing ? __builtin_amdgcn_s_memrealtime() : 0ull;
     // the wave needs nothing below the next super-tile any more: do not hold the team back during the epilogue
     if (window > 0) publish((unsigned)((s + 1) * G.kspan));
 #pragma unroll
     for (int sl2 = 0; sl2 < kTileSlots; ++sl2) {
-      const int64_t c_off = td->c_off[sl2];
-      if (c_off >= 0) tile_store_block<M, N>(acc[sl2], ring, c_off, td->cin_off[sl2], P.c_out, P.c_in, P.alpha, P.beta, L, voff);
+      // (wave-uniform by construction; said explicitly so that the buffer descriptors made from them stay in scalar registers)
+      const int64_t c_off = tile_uniform64(td->c_off[sl2]), cin_off = tile_uniform64(td->cin_off[sl2]);
+      if (c_off >= 0) tile_store_block<M, N>(acc[sl2], ring, c_off, cin_off, P.c_out, P.c_in, P.alpha, P.beta, L, voff);
     }
+    if (timing) t_epi += __builtin_amdgcn_s_memrealtime() - t_e0;
   }
   if (q < 256) publish(kTileDone);
   dma_wait<0>();
   asm volatile("" ::"v"(pf_sink));
+  if (timing && P.times) {
+    t_all = __builtin_amdgcn_s_memrealtime() - t_begin;
+    if (lane == 0) {
+      atomicAdd(P.times + 0, t_all);
+      atomicAdd(P.times + 1, t_admit);
+      atomicAdd(P.times + 2, t_wait);
+      atomicAdd(P.times + 3, t_mul);
+      atomicAdd(P.times + 4, t_epi);
+      atomicAdd(P.times + 5, 1ull);
+    }
+  }
   if (P.window > 0) {
     atomicAdd(P.flags + 2, lane == 0 ? (int)(n_polls >> 4) : 0);   // (in units of 16: the sum over 2048 waves stays in range)
     atomicAdd(P.flags + 3, lane == 0 ? (int)(n_blocked >> 4) : 0);

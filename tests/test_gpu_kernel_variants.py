@@ -69,11 +69,14 @@ VARIANTS = [
     ({"DBCSR_AMD_MM_WORK": "0"}, H2O, "mm_numeric_f64_hot<23,23,23>"),
     ({"DBCSR_AMD_MM_WORK": "0", "DBCSR_AMD_MM_CLASSES": "2"}, CONFIG3_37, "mm_numeric_f64_class[9 jit + 1 generic"),
     ({"DBCSR_AMD_MM_WORK": "0", "DBCSR_AMD_MM_CLASSES": "2"}, MIXED, "mm_numeric_f64_class["),
+    # the class launches of one multiply spread over several streams
+    ({"DBCSR_AMD_MM_CLASS_STREAMS": "3", "DBCSR_AMD_MM_CLASSES": "2"}, CONFIG3_37, "mm_numeric_f64_class[9 jit + 1 generic"),
+    ({"DBCSR_AMD_MM_CLASS_STREAMS": "4", "DBCSR_AMD_MM_CLASSES": "2"}, MIXED, "mm_numeric_f64_class["),
 ]
 
 
 def run_case(monkeypatch, env, case, dtype, tol, expect, alpha=0.7, beta=1.3, retain=False, in_place_twice=False):
-    for k in ("DBCSR_AMD_MM_KERNEL", "DBCSR_AMD_MM_HOT", "DBCSR_AMD_MM_TINY", "DBCSR_AMD_MM_PIPE_G", "DBCSR_AMD_MM_SYMBOLIC", "DBCSR_AMD_MM_CLASSES", "DBCSR_AMD_MM_CLASS_G", "DBCSR_AMD_MM_WORK", "DBCSR_AMD_MM_WG_WAVES"):
+    for k in ("DBCSR_AMD_MM_KERNEL", "DBCSR_AMD_MM_HOT", "DBCSR_AMD_MM_TINY", "DBCSR_AMD_MM_PIPE_G", "DBCSR_AMD_MM_SYMBOLIC", "DBCSR_AMD_MM_CLASSES", "DBCSR_AMD_MM_CLASS_G", "DBCSR_AMD_MM_WORK", "DBCSR_AMD_MM_WG_WAVES", "DBCSR_AMD_MM_CLASS_STREAMS"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
