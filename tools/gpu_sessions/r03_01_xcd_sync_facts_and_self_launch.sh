@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, GPU session 1: XCD sync facts, exact-size kernel with unpaired fragment reads, bench.py --gpus 2 from a bare shell
-cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}"
 O=gpurun_out/r03_s01; mkdir -p $O
 ( cd tools/ubench && timeout 120 ./ubench_xcd_sync ) > $O/ubench_xcd_sync.txt 2>&1
 for rep in 1 2; do

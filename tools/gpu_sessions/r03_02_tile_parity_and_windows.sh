@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, GPU session 2: tile kernel parity, then config 2 with the tile kernel at several team windows
-cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}"
 O=gpurun_out/r03_s02; mkdir -p $O
 timeout 900 python -m pytest tests/test_gpu_tile_kernel.py -x -q -m gpu > $O/pytest_tile.txt 2>&1
 tail -25 $O/pytest_tile.txt

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, GPU session 3: tile kernel with rationed progress stores; plan reuse
-cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}"
 O=gpurun_out/r03_s03; mkdir -p $O
 timeout 900 python -m pytest tests/test_gpu_tile_kernel.py tests/test_gpu_plan_reuse.py -q -m gpu > $O/pytest.txt 2>&1
 tail -15 $O/pytest.txt

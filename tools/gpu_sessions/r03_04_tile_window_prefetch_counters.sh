@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, GPU session 4: tile kernel -- window, L2 prefetch, wait statistics, counters
-cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}"
 O=gpurun_out/r03_s04; mkdir -p $O
 timeout 900 python -m pytest tests/test_gpu_tile_kernel.py -q -m gpu > $O/pytest.txt 2>&1
 tail -5 $O/pytest.txt

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, GPU session 5: whole GPU suite, per-rank step budget, bench --gpus 2/4 on the one GPU (gloo)
-cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}"
 O=gpurun_out/r03_s05; mkdir -p $O
 timeout 1500 python -m pytest tests -q -m gpu -x > $O/pytest_gpu.txt 2>&1
 tail -12 $O/pytest_gpu.txt

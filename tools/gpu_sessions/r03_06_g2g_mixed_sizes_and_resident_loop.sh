@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, GPU session 6: G2G failure of the unchanged host on mixed block sizes; resident Fortran loop
-cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}"
 O=gpurun_out/r03_s06; mkdir -p $O
 python - <<'PY' > $O/g2g_debug.txt 2>&1
 import os, sys, subprocess, tempfile

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, GPU session 7: inhomogeneous stacks on the device (unchanged host incl. G2G), resident Fortran loop
-cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}"
 O=gpurun_out/r03_s07; mkdir -p $O
 timeout 1500 python -m pytest tests/test_gpu_libsmm.py tests/test_gpu_fortran_host.py tests/test_gpu_acc_spec.py -q -m gpu > $O/pytest.txt 2>&1
 tail -15 $O/pytest.txt

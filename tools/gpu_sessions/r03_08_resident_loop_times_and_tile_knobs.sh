@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, GPU session 8: resident Fortran loop per-multiply times; tile kernel protocol knobs
-cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}"
 O=gpurun_out/r03_s08; mkdir -p $O
 ( cd /tmp && OMP_NUM_THREADS=8 MKL_THREADING_LAYER=SEQUENTIAL timeout 900 $GRAFT_REPO_ROOT/oracle/_ref/host_resident/dbcsr_resident_loop 32768 0.9 23 10 0 2>&1 | grep "resident_loop" ) > $O/resident_loop_config2.txt 2>&1
 cat $O/resident_loop_config2.txt

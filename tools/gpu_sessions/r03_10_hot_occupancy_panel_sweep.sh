@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, GPU session 10: occupancy / panel sweeps of the exact-size kernel on config 2 (does a lower occupancy cut the A re-fetches?)
-cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}"
 O=gpurun_out/r03_s10; mkdir -p $O
 show() { python - "$1" <<'PY'
 import json,sys

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, GPU session 12: the resident engine under a multi-rank Fortran host; configs 3 / 4 with the 256 MB panel default
-cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}"
 O=gpurun_out/r03_s12; mkdir -p $O
 timeout 1800 python -m pytest tests/test_fortran_host_mpi.py -q -m gpu -k "resident" > $O/pytest_resident_mpi.txt 2>&1
 tail -25 $O/pytest_resident_mpi.txt

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, GPU session 13: where a wave of the tile kernel spends its time (config 2), by window
-cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}"
 O=gpurun_out/r03_s13; mkdir -p $O
 cat > /tmp/tile_stats.py <<'PY'
 import os, sys, torch

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, GPU session 14: tile kernel after the scalar entry loads / uniform epilogue: parity, time breakdown, timing
-cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}"
 O=gpurun_out/r03_s14; mkdir -p $O
 timeout 900 python -m pytest tests/test_gpu_tile_kernel.py tests/test_gpu_plan_reuse.py -q -m gpu > $O/pytest.txt 2>&1; tail -4 $O/pytest.txt
 cat > /tmp/tile_stats.py <<'PY'

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, GPU session 15: bench.py --gpus 8 from a bare shell on the one-GPU box (gloo, ranks share the device): the whole N > 1 flow
-cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}"
 O=gpurun_out/r03_s15; mkdir -p $O
 for n in 8 4; do
   SECONDS=0; timeout 1500 python bench.py --gpus $n --steps 3 --warmup 1 --workload mid_16384_23x23_fill10_fp64 --cpu-seconds 3 > $O/bench_gpus$n.json 2> $O/bench_gpus$n.err

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, GPU session 16: C write pattern by itself (config 4), class launches of config 3 on several streams
-cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}"
 O=gpurun_out/r03_s16; mkdir -p $O
 timeout 300 tools/ubench/ubench_c_write > $O/ubench_c_write.txt 2>&1; cat $O/ubench_c_write.txt
 timeout 600 python -m pytest tests/test_gpu_kernel_variants.py -q -m gpu -x -k "CLASS_STREAMS or fp64_variant_matches" > $O/pytest_classes.txt 2>&1; tail -3 $O/pytest_classes.txt
