@@ -174,7 +174,9 @@ __device__ __forceinline__ void cblock_f64_lds(const Desc& d, const Entry* __res
 // block with another inner dimension (the tail block column of A) are multiplied straight from global memory.
 typedef const volatile double __attribute__((address_space(3))) lds_vd;  // volatile LDS read: never paired into ds_read2_b64
 // VAR: 0 = production (no ablation branch is compiled in), 1 = the run-time ablation switches of DBCSR_AMD_MM_DBG (profiling),
-// 2 = production with the fragment reads kept as single ds_read_b64 (the compiler pairs them into ds_read2_b64 otherwise)
+// 2 = production with the fragment reads kept as single ds_read_b64 (the compiler pairs them into ds_read2_b64 otherwise),
+// 3 / 4 = production + every product also touches one dword per cache line of the one / two A blocks stored before its own (the block
+// row's neighbours): an A block is then referenced two / three times as often, against its eviction by the B stream
 template <int M, int N, int K, int VAR>
 __device__ __forceinline__ void cblock_f64_exact(const Desc& d, const Entry first, const Entry* __restrict__ entries, const double* __restrict__ a_data,
                                                  const double* __restrict__ b_data, double* __restrict__ c_out,
@@ -192,6 +194,7 @@ __device__ __forceinline__ void cblock_f64_exact(const Desc& d, const Entry firs
   const int cnt = d.prod_cnt;
   u32x4 ra[CA], rb[CB];
   const int voff = lane * 16;
+  unsigned touch = 0;  // VAR 3 / 4: the dwords of the keep-alive loads, folded so that each is waited for one product later
   // fragment addresses: constant for the whole life of the wave
   const double* pa[MA];
   const double* pb[NC];
@@ -221,6 +224,14 @@ __device__ __forceinline__ void cblock_f64_exact(const Desc& d, const Entry firs
     // (measured on the streamed B loads: sc0 / sc1 / sc0+sc1 make no difference, nt costs +30 %)
 #pragma unroll
     for (int c = 0; c < CB; ++c) rb[c] = __builtin_amdgcn_raw_buffer_load_b128(rsb, voff, c * 1024, 0);
+    if constexpr (VAR == 3 || VAR == 4) {
+      constexpr uint64_t BLK = (uint64_t)M * K;
+      constexpr int NB = VAR == 3 ? 1 : 2;
+      const uint64_t back = a_off >= NB * BLK ? NB * BLK : 0;  // (wave-uniform; the first blocks of A touch themselves)
+      const __amdgpu_buffer_rsrc_t rst = __builtin_amdgcn_make_buffer_rsrc((void*)(a_data + a_off - back), 0, (int)(NB * BLK * 8), 0x00020000);
+      touch ^= (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rst, lane * 128, 0, 0);
+      if constexpr (NB * BLK * 8 > 64 * 128) touch ^= (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rst, lane * 128, 64 * 128, 0);
+    }
   };
   // Products with inner dimension K run through the staged pipeline (i0 = the one being multiplied, i1 = the next
   // candidate, whose list entry was requested one trip earlier); the others are summed afterwards.
@@ -285,6 +296,7 @@ __device__ __forceinline__ void cblock_f64_exact(const Desc& d, const Entry firs
     const Entry ep = e[p];
     if (ep.ks() != K) block_product_f64<MA, NC, false>(acc, a_data + ep.a_off(), b_data + ep.b_off(), M, N, ep.ks(), L);
   }
+  if constexpr (VAR == 3 || VAR == 4) asm volatile("" ::"v"(touch));  // the keep-alive loads are loads the compiler must keep
   const bool has_in = d.cin_off >= 0;
   if (dbg & 8) {  // scattered 8-byte stores straight from the accumulators (the first version; kept for comparison)
     double* C = c_out + d.c_off;

@@ -26,6 +26,12 @@ BIG = (300, 270, 280, 0.5, 0.5, 0.5, [1, 45, 1, 13], [1, 67, 1, 5], [1, 40, 1, 2
 # (environment, case, expected kernel-name prefix)
 VARIANTS = [
     ({}, H2O, "mm_numeric_f64_hot<23,23,23>"),
+    # experiment variants of the exact-size kernel: run-time ablation switches (1, all off), unpaired fragment reads (2), touches of the
+    # neighbouring A blocks (3, 4)
+    ({"DBCSR_AMD_MM_HOT_VARIANT": "1"}, H2O, "mm_numeric_f64_hot<23,23,23>"),
+    ({"DBCSR_AMD_MM_HOT_VARIANT": "2"}, H2O, "mm_numeric_f64_hot<23,23,23>"),
+    ({"DBCSR_AMD_MM_HOT_VARIANT": "3"}, H2O, "mm_numeric_f64_hot<23,23,23>"),
+    ({"DBCSR_AMD_MM_HOT_VARIANT": "4"}, H2O, "mm_numeric_f64_hot<23,23,23>"),
     ({"DBCSR_AMD_MM_HOT": "0", "DBCSR_AMD_MM_KERNEL": "lds1"}, H2O, "mm_numeric_f64_lds<3>"),
     ({"DBCSR_AMD_MM_KERNEL": "pipe"}, H2O, "mm_numeric_f64_pipe<3>"),
     ({"DBCSR_AMD_MM_KERNEL": "dma2"}, H2O, "mm_numeric_f64_dma<23,23,23,2>"),
@@ -76,7 +82,7 @@ VARIANTS = [
 
 
 def run_case(monkeypatch, env, case, dtype, tol, expect, alpha=0.7, beta=1.3, retain=False, in_place_twice=False):
-    for k in ("DBCSR_AMD_MM_KERNEL", "DBCSR_AMD_MM_HOT", "DBCSR_AMD_MM_TINY", "DBCSR_AMD_MM_PIPE_G", "DBCSR_AMD_MM_SYMBOLIC", "DBCSR_AMD_MM_CLASSES", "DBCSR_AMD_MM_CLASS_G", "DBCSR_AMD_MM_WORK", "DBCSR_AMD_MM_WG_WAVES", "DBCSR_AMD_MM_CLASS_STREAMS"):
+    for k in ("DBCSR_AMD_MM_KERNEL", "DBCSR_AMD_MM_HOT", "DBCSR_AMD_MM_TINY", "DBCSR_AMD_MM_PIPE_G", "DBCSR_AMD_MM_SYMBOLIC", "DBCSR_AMD_MM_CLASSES", "DBCSR_AMD_MM_CLASS_G", "DBCSR_AMD_MM_WORK", "DBCSR_AMD_MM_WG_WAVES", "DBCSR_AMD_MM_CLASS_STREAMS", "DBCSR_AMD_MM_HOT_VARIANT"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
