@@ -69,3 +69,7 @@ def test_no_scratch_and_exact_kernels_keep_their_occupancy(tmp_path):
     too_big = {n: v for n, v in hot64.items() if v > (128 if size_of(n) <= 24 else 184)}
     assert not too_big, too_big
     assert all(v <= 96 for v in hot32.values()), hot32
+    # the tile kernels (mm_tile.hip, two waves per SIMD): 81 accumulators per lane and everything else in 256 registers, no scratch
+    # (what -mllvm -structurizecfg-skip-uniform-regions is there for, see the Makefile)
+    tile = {pretty[n]: k["vgpr_count"] for n, k in ks.items() if "mm_numeric_f64_tile<" in pretty[n]}
+    assert tile and all(v <= 256 for v in tile.values()), tile
