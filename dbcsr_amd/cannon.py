@@ -279,13 +279,16 @@ class CannonMultiply:
     (process column c, images v = r mod nprows)."""
 
     def __init__(self, M=0, N=0, K=0, sparsities=(0, 0, 0), mix=(1, 1), dtype=torch.float64, engine=None, device=None, grid=None,
-                 mix_n=None, mix_k=None, mode="gather", local_first=True, matrices=None, transport="torch", distributed=None):
+                 mix_n=None, mix_k=None, mode="gather", local_first=True, matrices=None, transport="torch", distributed=None,
+                 col_chunks=4, share_comm_with=None):
         # transport: "torch" = torch.distributed point-to-point (RCCL under the nccl backend, gloo on CPU);
         #            "native" = the C-ABI exchange of include/dbcsr_amd_comm.h (RCCL group on a dedicated HIP stream);
         #            "auto"   = native when it can be set up (GPU tensors, more than one rank), else torch
         self.comm = None
         self.transport = "torch"
-        if transport in ("native", "auto") and dist.is_initialized() and dist.get_world_size() > 1 and torch.cuda.is_available():
+        if share_comm_with is not None:   # a second plan of the same job (another grid / schedule): the first one's communicator
+            self.comm, self.transport = share_comm_with.comm, share_comm_with.transport
+        elif transport in ("native", "auto") and dist.is_initialized() and dist.get_world_size() > 1 and torch.cuda.is_available():
             import sys
             err = None
             try:
@@ -322,7 +325,10 @@ class CannonMultiply:
         self._owned = None
         world = dist.get_world_size() if dist.is_initialized() else 1
         rank = dist.get_rank() if dist.is_initialized() else 0
-        self.grid = grid or Grid(world, rank)
+        # mode "colpipe": world x 1 grid -- every rank keeps its block rows of A and of C and needs ALL of B, which then travels over
+        # all links at once, in column chunks that are multiplied as they arrive (see _multiply_colpipe)
+        self.grid = grid or (Grid(world, rank, nprows=world, npcols=1) if mode == "colpipe" else Grid(world, rank))
+        self._col_chunks = max(1, int(col_chunks)) if mode == "colpipe" else 0
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.dtype = dtype
         if engine is None:
@@ -378,6 +384,11 @@ class CannonMultiply:
         self.counters = {"C": c0 + 1, "A": c0 + 2, "B": c0 + 3}
         self.nbr_g, self.nbk_g, self.nbc_g = len(sm), len(sk), len(sn)
         r, c = g.myprow, g.mypcol
+        self._cbounds = None
+        if self._col_chunks:
+            ncl = len(P.cols_of[c])
+            nch = max(1, min(self._col_chunks, ncl))
+            self._cbounds = np.round(np.linspace(0, ncl, nch + 1)).astype(np.int64)
         t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt).to(self.device)
         self._rs = t(sm[P.rows_of[r]], torch.int32)
         self._cs = t(sn[P.cols_of[c]], torch.int32)
@@ -398,7 +409,7 @@ class CannonMultiply:
                                        self._ks[v], sm, sk, self._row_gid, self._k_gid[v], self.nbr_g, fill=own_a)
             own_b = g.b_owner(v, c) == g.rank
             self.B_img[v] = self._make("B", P.k_dist, v, P.col_dist, c, P.k_local, P.col_local, len(P.ks_of[v]), self._ks[v],
-                                       self._cs, sk, sn, self._k_gid[v], self._col_gid, self.nbk_g, fill=own_b)
+                                       self._cs, sk, sn, self._k_gid[v], self._col_gid, self.nbk_g, fill=own_b, chunk_bounds=self._cbounds)
         # full-panel patterns (no data) for the one-off symbolic product that fixes C's structure
         all_k_local = np.arange(len(sk), dtype=np.int32)
         self.A_panel = self._make("A", P.row_dist, r, np.zeros(len(sk), np.int32), 0, P.row_local, all_k_local, len(P.rows_of[r]),
@@ -428,6 +439,14 @@ class CannonMultiply:
         self._sub = {}
         for name, S in (("S1", self._S1), ("S2", self._S2)):
             self._sub[name] = (self._sub_panel("A", S), self._sub_panel("B", S)) if S and g.world > 1 else None
+        # colpipe: B's column panel and C_in cut into column chunks (same buffers, chunk-local column numbering)
+        self._Bc = self._Cc = None
+        self._merged = None
+        self.colpipe_copies = 0
+        if self._cbounds is not None:
+            nch = len(self._cbounds) - 1
+            self._Bc = [self._col_sub(self.B_panel, int(self._cbounds[q]), int(self._cbounds[q + 1])) for q in range(nch)]
+            self._Cc = [self._col_sub(self.C_in, int(self._cbounds[q]), int(self._cbounds[q + 1])) for q in range(nch)]
         # double-buffered receive space for A and B panels
         amax = max([m.data_numel for v, m in self.A_img.items() if g.a_owner(r, v) != g.rank] + [0])
         bmax = max([m.data_numel for v, m in self.B_img.items() if g.b_owner(v, c) != g.rank] + [0])
@@ -465,14 +484,31 @@ class CannonMultiply:
             return "self-test exchange delivered wrong data"
         return None
 
-    def _make(self, which, rdist, rsel, cdist, csel, rloc, cloc, nrows_local, rs_t, cs_t, rsizes, csizes, rgid, cgid, nrow_global, fill):
+    def _make(self, which, rdist, rsel, cdist, csel, rloc, cloc, nrows_local, rs_t, cs_t, rsizes, csizes, rgid, cgid, nrow_global, fill,
+              chunk_bounds=None):
         rows, cols = self.pat[which]
         keep = (rdist[rows] == rsel) & (cdist[cols] == csel)
         row_p, col_i, blk_p, nze = _sub_index(rows, cols, keep, rloc, cloc, nrows_local, rsizes, csizes)
+        chunk_off = order = None
+        if chunk_bounds is not None:
+            # data laid out column chunk by column chunk (inside a chunk: by (row, col) as before), so that the blocks of one chunk
+            # are one contiguous piece of the image -- what travels per step of the colpipe schedule
+            sizes = np.diff(np.append(blk_p, nze))
+            chunk = np.searchsorted(chunk_bounds, col_i, side="right") - 1
+            order = np.argsort(chunk, kind="stable")
+            starts = np.zeros(len(order), np.int64)
+            if len(order):
+                starts[1:] = np.cumsum(sizes[order])[:-1]
+            blk_p = np.empty_like(blk_p)
+            blk_p[order] = starts
+            per_chunk = np.bincount(chunk, weights=sizes, minlength=len(chunk_bounds) - 1).astype(np.int64) if len(order) else \
+                np.zeros(len(chunk_bounds) - 1, np.int64)
+            chunk_off = np.concatenate([[0], np.cumsum(per_chunk)])
         t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt).to(self.device)
         data = torch.empty(nze if fill else 0, dtype=self.dtype, device=self.device)
         M = DbcsrMatrix(rs_t, cs_t, t(row_p, torch.int32), t(col_i, torch.int32), t(blk_p, torch.int64), data, which)
         M.data_numel = nze
+        M.chunk_off = chunk_off
         if fill and nze:
             if self._owned is not None:  # the blocks this rank received in make_images (sorted by global (row, col))
                 orow, ocol, ooff, odat = self._owned[which]
@@ -481,12 +517,16 @@ class CannonMultiply:
                 kkey = rows[keep].astype(np.int64) * ncol_t + cols[keep]
                 pos = np.searchsorted(okey, kkey)
                 assert len(okey) and np.array_equal(okey[pos], kkey), "image block missing after redistribution"
+                if order is not None:
+                    pos = pos[order]   # (the blocks in the order they are stored)
                 M.data.copy_(gather_blocks(odat, ooff[pos], ooff[pos + 1] - ooff[pos]).to(self.device))
             elif self._host is not None:  # cut the kept blocks out of the replicated global matrix
                 h = self._host[which]
                 hb, hd = np.asarray(h.blk_p, np.int64), np.asarray(h.data)
                 sizes = rsizes[rows[keep]].astype(np.int64) * csizes[cols[keep]].astype(np.int64)
                 src = hb[np.nonzero(keep)[0]]
+                if order is not None:
+                    src, sizes = src[order], sizes[order]
                 M.data.copy_(torch.as_tensor(np.concatenate([hd[o:o + n] for o, n in zip(src, sizes)])).to(self.device))
             else:
                 self.eng.fill_random_dist(M, self.counters[which], rgid, cgid, nrow_global)
@@ -526,6 +566,127 @@ class CannonMultiply:
         M = DbcsrMatrix(full.row_blk_size, full.col_blk_size, t(np.cumsum(nrow_p), torch.int32), t(col_i[keep], torch.int32),
                         t(blk_p[keep], torch.int64), full.data, which)
         return M
+
+    def _col_sub(self, full, lo, hi):
+        """`full` restricted to its block columns lo .. hi - 1, numbered from 0: same data buffer, fewer blocks."""
+        rs, cs, row_p, col_i, blk_p, _ = DbcsrMatrix(full.row_blk_size, full.col_blk_size, full.row_p, full.col_i, full.blk_p,
+                                                     full.row_p[:0]).to_host()
+        rows = np.repeat(np.arange(len(rs), dtype=np.int64), np.diff(row_p))
+        keep = (col_i >= lo) & (col_i < hi)
+        nrow_p = np.zeros(len(rs) + 1, np.int64)
+        np.add.at(nrow_p, rows[keep] + 1, 1)
+        t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt).to(self.device)
+        return DbcsrMatrix(full.row_blk_size, full.col_blk_size[lo:hi], t(np.cumsum(nrow_p), torch.int32), t(col_i[keep] - lo, torch.int32),
+                           t(blk_p[keep], torch.int64), full.data, full.name)
+
+    def _exchange(self, sends, recvs):
+        """Posts one batch of (tensor, peer) sends and receives on the transport in use; returns (work handles, staged host copies)."""
+        g = self.grid
+        if not sends and not recvs:
+            return [], []
+        if self.comm is not None:  # native transport: ONE RCCL group on the communication stream
+            return [_EventWork(self.comm.exchange(sends, recvs))], []
+        ops, staged = [], []
+        host = g.world > 1 and self.device.type == "cuda" and dist.get_backend() != "nccl"  # debug transport
+        if host:
+            torch.cuda.synchronize()
+        for t, peer in sends:
+            if host:
+                t = t.cpu()
+                staged.append(t)
+            ops.append(dist.P2POp(dist.isend, t, peer))
+        for t, peer in recvs:
+            if host:
+                h = torch.empty(t.numel(), dtype=t.dtype)
+                staged.append((h, t))
+                ops.append(dist.P2POp(dist.irecv, h, peer))
+            else:
+                ops.append(dist.P2POp(dist.irecv, t, peer))
+        return dist.batch_isend_irecv(ops), staged
+
+    @staticmethod
+    def _arrived(works, staged):
+        for w in works:
+            w.wait()
+        for item in staged:
+            if isinstance(item, tuple):
+                item[1].copy_(item[0])
+
+    def _multiply_colpipe(self, alpha, beta):
+        """world x 1 grid.  A's block rows are local; B's column panel is ALL of B, one k-image per rank.  It travels in column chunks
+        -- chunk q of every image, from its owner to everybody, one batch per chunk, all batches posted at once and carried out in
+        order -- and chunk q of C (disjoint block columns: every C block is written once) is multiplied as soon as chunk q of B is
+        complete, while chunk q + 1 is on the links.  Exposed transfer: one chunk of one image per link instead of a whole image;
+        the k-sliced tick schedule overlaps as much but reads and writes C once per tick."""
+        g, r, c = self.grid, self.grid.myprow, self.grid.mypcol
+        nch = len(self._cbounds) - 1
+        posted = []
+        for q in range(nch):
+            sends, recvs = [], []
+            for v in range(g.nvirt):
+                if q == 0:  # (grids with more than one process column: the A images this rank misses come with the first chunk)
+                    na, a_own = self.A_img[v].data_numel, g.a_owner(r, v)
+                    if na and a_own == g.rank:
+                        sends += [(self.A_img[v].data, g.rank_of(r, pc)) for pc in range(g.npcols) if pc != c]
+                    elif na:
+                        recvs.append((self._a_all[self._a_base[v]:self._a_base[v] + na], a_own))
+                img, b_own = self.B_img[v], g.b_owner(v, c)
+                lo, hi = int(img.chunk_off[q]), int(img.chunk_off[q + 1])
+                if hi > lo:
+                    if b_own == g.rank:
+                        sends += [(img.data[lo:hi], g.rank_of(pr, c)) for pr in range(g.nprows) if pr != r]
+                    else:
+                        recvs.append((self._b_all[self._b_base[v] + lo:self._b_base[v] + hi], b_own))
+            posted.append(self._exchange(sends, recvs))
+        engines = [self._engine(None if q == 0 else ("col", q)) for q in range(nch)]
+        # C's structure per chunk needs the (replicated) index only: the symbolic phases run while the first chunk travels
+        sym = [engines[q].symbolic(self.A_panel, self._Bc[q], self._Cc[q], retain_sparsity=False) for q in range(nch)]
+        mg = self._merged
+        out_all = torch.empty(mg["nze"], dtype=self.dtype, device=self.device) if mg is not None else None
+        parts, flop, nprod = [], 0, 0
+        for q in range(nch):
+            self._arrived(*posted[q])
+            row_p, cnt = sym[q]
+            eng = self.last_engine = engines[q]
+            kw = {}
+            if out_all is not None and getattr(eng, "accepts_out_data", False):
+                kw["out_data"] = out_all[mg["off"][q]:mg["off"][q] + cnt.c_nze]
+            parts.append(eng.numeric_after_symbolic(alpha, self.A_panel, self._Bc[q], beta, self._Cc[q], row_p, cnt, self.dtype, **kw))
+            flop += cnt.flop
+            nprod += cnt.nproducts
+            self.last_tick_flop = cnt.flop
+        counts = sym[0][1]
+        counts.flop, counts.nproducts = flop, nprod
+        counts.c_nblks, counts.c_nze = sum(int(x[1].c_nblks) for x in sym), sum(int(x[1].c_nze) for x in sym)
+        return self._merge_chunks(parts, out_all), counts
+
+    def _merge_chunks(self, parts, out_all):
+        """The column chunks of C as ONE matrix of the local tile.  The patterns of a plan never change, so the merged index is made
+        once; from the second multiply on the chunks were written straight into their slices of one buffer (no copy)."""
+        if self._merged is None:
+            rows_l, cols_l, off_l, chunk_l, base = [], [], [], [], 0
+            offs = []
+            for q, Cq in enumerate(parts):
+                rs, cs, row_p, col_i, blk_p, _ = DbcsrMatrix(Cq.row_blk_size, Cq.col_blk_size, Cq.row_p, Cq.col_i, Cq.blk_p, Cq.row_p[:0]).to_host()
+                rows = np.repeat(np.arange(len(rs), dtype=np.int64), np.diff(row_p))
+                rows_l.append(rows)
+                cols_l.append(col_i.astype(np.int64) + int(self._cbounds[q]))
+                off_l.append(blk_p.astype(np.int64) + base)
+                offs.append(base)
+                base += int(Cq.data.numel())
+            rows, cols, off = np.concatenate(rows_l), np.concatenate(cols_l), np.concatenate(off_l)
+            order = np.lexsort((cols, rows))
+            row_p = np.zeros(len(self._rs) + 1, np.int64)
+            np.add.at(row_p, rows + 1, 1)
+            t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt).to(self.device)
+            self._merged = {"row_p": t(np.cumsum(row_p), torch.int32), "col_i": t(cols[order], torch.int32), "blk_p": t(off[order], torch.int64),
+                            "off": offs, "nze": base, "sizes": [int(Cq.data.numel()) for Cq in parts]}
+        mg = self._merged
+        assert [int(Cq.data.numel()) for Cq in parts] == mg["sizes"], "the pattern of a chunk of C changed between two multiplies of one plan"
+        if out_all is None or any(Cq.data.data_ptr() != out_all[mg["off"][q]:].data_ptr() for q, Cq in enumerate(parts) if Cq.data.numel()):
+            out_all = torch.cat([Cq.data for Cq in parts]) if parts else torch.empty(0, dtype=self.dtype, device=self.device)
+            self.colpipe_copies += 1   # (the first multiply of a plan, or an engine that allocates its own output)
+        return DbcsrMatrix(self._rs, self._cs, mg["row_p"], mg["col_i"], mg["blk_p"], out_all, "C")
 
     def _post_all(self):
         """gather mode: one batch with every image this rank misses (and every send the others expect)."""
@@ -704,6 +865,10 @@ class CannonMultiply:
                                                    filter_eps=filter_eps or 0.0)
             self.last_tick_flop = getattr(self.eng, "last_launch_flop", counts.flop)
             return Cout, counts
+        if self.mode == "colpipe":
+            if self._cbounds is None:
+                raise ValueError("CannonMultiply: mode 'colpipe' must be chosen at construction (the images are laid out for it)")
+            return self._multiply_colpipe(alpha, beta)
         if self.mode == "gather":
             return self._multiply_gather(alpha, beta)
         g, eng = self.grid, self.eng

@@ -185,13 +185,18 @@ class MultiplyEngine:
             raise RuntimeError("dbcsr_amd_mm_numeric failed (%d)" % rc)
         return counts
 
-    def numeric_after_symbolic(self, alpha, A, B, beta, Cm, row_p, counts, dtype, stream=None):
-        """Second half of multiply_local for a symbolic() call made earlier on the same operands."""
+    accepts_out_data = True
+
+    def numeric_after_symbolic(self, alpha, A, B, beta, Cm, row_p, counts, dtype, stream=None, out_data=None):
+        """Second half of multiply_local for a symbolic() call made earlier on the same operands.  out_data: where the blocks of C_out
+        go (a tensor of counts.c_nze elements, e.g. a slice of a larger buffer) instead of a new allocation."""
         st = StreamHandle(stream)
         dev = Cm.row_p.device
+        if out_data is not None and (out_data.numel() != counts.c_nze or out_data.dtype != dtype or not out_data.is_contiguous()):
+            raise ValueError("numeric_after_symbolic: out_data must be a contiguous tensor of c_nze = %d elements of %s" % (counts.c_nze, dtype))
         out = DbcsrMatrix(Cm.row_blk_size, Cm.col_blk_size, row_p, torch.empty(counts.c_nblks, dtype=torch.int32, device=dev),
                           torch.empty(counts.c_nblks, dtype=torch.int64, device=dev),
-                          torch.empty(counts.c_nze, dtype=dtype, device=dev), Cm.name)
+                          out_data if out_data is not None else torch.empty(counts.c_nze, dtype=dtype, device=dev), Cm.name)
         a, b, cin, cout = A.desc(), B.desc(), Cm.desc(), out.desc()
         rc = self.L.dbcsr_amd_mm_numeric(self.h, out.dtype_code, float(alpha), C.byref(a), C.byref(b), float(beta), C.byref(cin),
                                          C.byref(cout), st.ptr)

@@ -64,7 +64,8 @@ def _worker(rank, world, port, alpha, beta, q, mode, retain=False, eps=None):
 
 
 @pytest.mark.parametrize("world,mode", [(2, "gather"), (4, "gather+given"), (6, "gather"), (4, "ticks"), (6, "ticks+given"),
-                                        (4, "ticks+dist"), (6, "gather+dist"), (2, "ticks+dist"), (8, "ticks"), (8, "gather+dist")])
+                                        (4, "ticks+dist"), (6, "gather+dist"), (2, "ticks+dist"), (8, "ticks"), (8, "gather+dist"),
+                                        (2, "colpipe"), (3, "colpipe+given"), (4, "colpipe+dist"), (8, "colpipe")])
 def test_cannon_matches_global_oracle(world, mode):
     _run_and_compare(world, mode)
 

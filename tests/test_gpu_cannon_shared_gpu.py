@@ -23,7 +23,8 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,mode", [(2, "gather"), (2, "ticks"), (4, "ticks"), (4, "gather"), (4, "ticks+dist"), (2, "gather+dist"), (4, "gather+filter"), (2, "ticks+filter"), (8, "ticks"), (8, "gather+dist")])
+@pytest.mark.parametrize("world,mode", [(2, "gather"), (2, "ticks"), (4, "ticks"), (4, "gather"), (4, "ticks+dist"), (2, "gather+dist"), (4, "gather+filter"), (2, "ticks+filter"), (8, "ticks"), (8, "gather+dist"),
+                                        (2, "colpipe"), (4, "colpipe+dist"), (4, "colpipe+filter"), (8, "colpipe")])
 def test_cannon_hip_engine_ranks_share_one_gpu(world, mode):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
