@@ -238,6 +238,7 @@ struct Engine {
   int dbg = 0;      // DBCSR_AMD_MM_DBG: ablation switches of the LDS kernel (profiling only; the exact-size kernel honours them in its VAR = 1 build)
   // XCD-wide C tiles in registers (mm_tile.h): DBCSR_AMD_MM_TILE = 0 never, 1 automatic, 2 whenever the sizes allow;
   // DBCSR_AMD_MM_TILE_WINDOW = k window of the team (inner blocks; 0: no throttle); DBCSR_AMD_MM_TILE_RDV = 1: unpaired fragment reads
+  int tile_shape = 0;  // DBCSR_AMD_MM_TILE_SHAPE: 0 = 3 x 3 C blocks per wave, two waves per SIMD; 1 = 4 x 3, one wave per SIMD, four-slot ring (mm_tile.h)
   int use_tile = 0, tile_window = 256, tile_rdv = 0, tile_pub = 1, tile_prefetch = 0, tile_knobs = 0;  // DBCSR_AMD_MM_TILE_PUB: progress stores written through (0) / left in L2 (1)
   int hot_cnt_m = 0, hot_cnt_k = 0, hot_cnt_n = 0;  // block rows / inner blocks / block columns of the dominant size
   DevBuf<uint32_t> a_bm, bt_bm, tile_prog;
@@ -258,7 +259,7 @@ struct Engine {
   int* plan_host_flag = nullptr;  // pinned
   dbcsr_amd_mm_counts plan_counts = {0, 0, 0, 0};
   bool work_built = false, tile_built = false;
-  TileGeom tile_geom = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  TileGeom tile_geom = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   long long plan_hits = 0, plan_misses = 0;
   int hot_variant = 0;  // DBCSR_AMD_MM_HOT_VARIANT: 2 = exact-size kernel with unpaired ds_read_b64 fragment reads (23^3 only)
   int use_pipe = -1, pipe_g = 8;  // multi-block pipelined kernel: -1 automatic (short product lists only), DBCSR_AMD_MM_KERNEL=pipe|lds1 forces; DBCSR_AMD_MM_PIPE_G = blocks per wave
@@ -392,9 +393,10 @@ static int run_tile_f64(Engine* E, hipStream_t st, const dbcsr_amd_bcsr* a, cons
   TileGeom G;
   G.nfr = E->hot_cnt_m;
   G.nfc = E->hot_cnt_n;
-  G.nTR = (G.nfr + kTileT - 1) / kTileT;
-  G.nTC = (G.nfc + kTileT - 1) / kTileT;
-  G.team_rows = std::max(1, cu_per_xcd * 8 / kTeamCols);
+  if (!tile_shape(E->tile_shape, &G.tr, &G.tc, &G.wg_waves)) return 1;
+  G.nTR = (G.nfr + G.tr - 1) / G.tr;
+  G.nTC = (G.nfc + G.tc - 1) / G.tc;
+  G.team_rows = std::max(1, cu_per_xcd * G.wg_waves / kTeamCols);
   G.nSR = (G.nTR + G.team_rows - 1) / G.team_rows;
   G.nSC = (G.nTC + kTeamCols - 1) / kTeamCols;
   G.nseq = (G.nSR * G.nSC + 7) / 8;
@@ -449,7 +451,7 @@ static int run_tile_f64(Engine* E, hipStream_t st, const dbcsr_amd_bcsr* a, cons
     P.times = E->tile_times.p;
   }
   ACC_CHECK(hipEventRecord(E->ev[1], st));  // the timed numeric launch starts here (the index work above counts as fill time)
-  if (tile_launch(S_, S_, S_, E->tile_rdv, (unsigned)(8 * cu_per_xcd), st, P)) return -1;
+  if (tile_launch(S_, S_, S_, E->tile_rdv, E->tile_shape, (unsigned)(8 * cu_per_xcd), st, P)) return -1;
   if (tile_launch_remainder(S_, S_, st, G, E->tdescs.p, E->tentries.p, P.a_data, P.b_data, P.c_out, alpha)) return -1;
   return check(hipGetLastError(), "run_tile_f64", __FILE__, __LINE__);
 }
@@ -498,6 +500,7 @@ int dbcsr_amd_mm_create(void** handle) {
   if (const char* k = getenv("DBCSR_AMD_MM_TILE_PUB")) E->tile_pub = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_TILE_PREFETCH")) E->tile_prefetch = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_TILE_KNOBS")) E->tile_knobs = atoi(k);
+  if (const char* k = getenv("DBCSR_AMD_MM_TILE_SHAPE")) E->tile_shape = atoi(k) == 1 ? 1 : 0;
   if (const char* k = getenv("DBCSR_AMD_MM_HOT")) E->use_hot = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_TINY")) E->use_tiny = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_LDS_PAD")) E->lds_pad = atoi(k);

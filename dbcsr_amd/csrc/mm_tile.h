@@ -5,8 +5,8 @@
 // multiply of BASELINE config 2) is what bounds them.  Here the C blocks of an I x J TILE are accumulated at the same
 // time, so that an A block (i, k) is shared by the tile's columns and a B block (k, j) by its rows: every operand block crosses
 // the fabric once per tile, 10 (|I| + |J|) / (|I| |J|) blocks per product at 10 % fill (0.42 for 48 x 48) instead of 1.1.
-//   * a wavefront owns a T x T sub-tile of C blocks (T = 3: 81 fp64 accumulators per lane, in AGPRs) and walks ONE product list,
-//     sorted by k, whose entries name the accumulator set they feed ("slot"); two waves per SIMD, 256 registers each;
+//   * a wavefront owns a sub-tile of C blocks (3 x 3: 81 fp64 accumulators per lane, two waves per SIMD; or 4 x 3: 108, one wave per
+//     SIMD -- the shapes below) and walks ONE product list, sorted by k, whose entries name the accumulator set they feed ("slot");
 //   * the 256 waves of an XCD (32 CUs x 8 waves: one persistent workgroup per CU) form a TEAM that works on one 16 x 16
 //     arrangement of sub-tiles (48 x 48 C blocks) at a time; sharing happens in the XCD's 4 MB L2, which only holds about 100 k
 //     steps of the tile's operands, so the team moves through k together: every wave publishes the k it needs next, and a wave
@@ -27,8 +27,15 @@
 
 namespace dbcsr_amd {
 
-constexpr int kTileT = 3;                      // C blocks per wave: kTileT x kTileT
-constexpr int kTileSlots = kTileT * kTileT;
+// Two SHAPES of the dataflow (DBCSR_AMD_MM_TILE_SHAPE):
+//   0: sub-tiles of 3 x 3 C blocks, 8 waves per workgroup (two per SIMD, 256 registers each), ring of 2 slots per wave;
+//      team = 256 waves = 16 x 16 sub-tiles = 48 x 48 C blocks
+//   1: sub-tiles of 4 x 3 C blocks, 4 waves per workgroup (ONE per SIMD: 108 accumulators per lane in the 512 registers), ring of
+//      4 slots per wave -- three products' operands in flight behind the one being multiplied, which covers a trip over the fabric
+//      and lets a wave that is admitted late keep multiplying what it already has; team = 128 waves = 8 x 16 sub-tiles = 32 x 48
+//      C blocks
+constexpr int kTileMaxT = 4;                   // largest sub-tile edge of any shape
+constexpr int kTileMaxSlots = 16;              // C blocks per wave, at most (slot = tc * ti + tj)
 constexpr int kTeamCols = 16;                  // sub-tiles per super-tile row (team waves = rows x kTeamCols)
 constexpr unsigned kTileDone = 0x7fffffffu;    // progress value of a wave that needs nothing any more
 
@@ -38,11 +45,11 @@ struct TileEntry {  // one block product of a sub-tile, 16 bytes
   uint32_t k;           // inner block index (position in the team's sweep)
 };
 
-struct TileDesc {  // one sub-tile, 160 bytes
+struct TileDesc {  // one sub-tile, 272 bytes
   int64_t list_start;  // first TileEntry; the n_main entries with inner size K come first (sorted by k), the n_rem others last
   int32_t n_main, n_rem;
-  int64_t c_off[kTileSlots];    // element offset in C_out data, -1: no C block in this slot
-  int64_t cin_off[kTileSlots];  // element offset in C_in data, -1: the block is new
+  int64_t c_off[kTileMaxSlots];    // element offset in C_out data, -1: no C block in this slot
+  int64_t cin_off[kTileMaxSlots];  // element offset in C_in data, -1: the block is new
 };
 
 struct TileGeom {
@@ -52,6 +59,8 @@ struct TileGeom {
   int team_rows;       // sub-tile rows of a super-tile (team waves = team_rows * kTeamCols)
   int nseq;            // super-tiles per XCD (ceil)
   int kspan;           // progress units per super-tile (>= number of inner blocks)
+  int tr, tc;          // C block rows / columns of a sub-tile (the shape's)
+  int wg_waves;        // waves per workgroup = per CU (the shape's)
 };
 
 // ---- numeric kernels: mm_tile.hip (a translation unit of its own, see the Makefile) ------------------------------------------
@@ -77,11 +86,13 @@ struct TileArgs {
 // block sizes the tile kernels are built for (cubes)
 #define DBCSR_AMD_TILE_SIZES(X) X(23)
 
-// LDS bytes of a workgroup of 8 waves, 0 when there is no kernel for (m, n, k)
-int tile_lds_bytes(int m, int n, int k);
-// the persistent tile kernel (8 waves per workgroup, nwg workgroups: 8 per CU slot of an XCD) and the products with inner blocks of
+// sub-tile and workgroup geometry of a shape; false: no such shape
+bool tile_shape(int shape, int* tr, int* tc, int* wg_waves);
+// LDS bytes of a workgroup, 0 when there is no kernel for (m, n, k)
+int tile_lds_bytes(int m, int n, int k, int shape);
+// the persistent tile kernel (one workgroup per CU, nwg workgroups: 8 per CU slot of an XCD) and the products with inner blocks of
 // another size; 0 = launched, 1 = no kernel for this size, < 0 error
-int tile_launch(int m, int n, int k, int rdv, unsigned nwg, hipStream_t st, const TileArgs& P);
+int tile_launch(int m, int n, int k, int rdv, int shape, unsigned nwg, hipStream_t st, const TileArgs& P);
 int tile_launch_remainder(int m, int n, hipStream_t st, const TileGeom& G, const TileDesc* tdescs, const TileEntry* entries, const double* a_data,
                           const double* b_data, double* c_out, double alpha);
 

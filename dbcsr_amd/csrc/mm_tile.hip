@@ -47,16 +47,20 @@ __device__ __forceinline__ int64_t tile_uniform64(int64_t v) {
   return (int64_t)(((uint64_t)hi << 32) | lo);
 }
 
-template <int M, int N, int K, int RDV>
+template <int M, int N, int K, int RDV, int DEPTH = 2>
 struct TileKernel {
   static constexpr int MA = (M + 7) / 8, NC = (N + 7) / 8, KS = (K + 3) / 4;
   static constexpr int ABYTES = M * K * 8, BBYTES = K * N * 8;
   static constexpr int SA = (ABYTES + 15) & ~15, SB = (BBYTES + 15) & ~15, SLOT = SA + SB;
   static constexpr int PIECES = (ABYTES + 1023) / 1024 + (BBYTES + 1023) / 1024;
   static constexpr int CBYTES = ((M * N * 8 + 1023) / 1024) * 1024;
-  static constexpr int RING = (2 * SLOT > CBYTES ? 2 * SLOT : CBYTES) + 64;  // per wave; + 64: fragment reads of lanes past the last column, whole 16-byte lanes of the C staging
-  static_assert(MA == 3 && NC == 3, "sub-tiles of 3 x 3 C blocks are sized for blocks of 17..24 (9 accumulators per block and lane)");
-  static_assert(PIECES < 32, "vmcnt budget");
+  // per wave: DEPTH slots; the C blocks leave through the ring itself when it has two slots, through a staging area of their own
+  // behind a deeper one.  + 64: fragment reads of lanes past the last column, whole 16-byte lanes of the C staging
+  static constexpr int STAGE = DEPTH > 2 ? DEPTH * SLOT : 0;
+  static constexpr int RING = (DEPTH > 2 ? DEPTH * SLOT + CBYTES : (2 * SLOT > CBYTES ? 2 * SLOT : CBYTES)) + 64;
+  static_assert(MA == 3 && NC == 3, "the sub-tiles are sized for blocks of 17..24 (9 accumulators per block and lane)");
+  static_assert((DEPTH - 1) * PIECES < 64, "vmcnt budget");
+  static_assert((DEPTH & (DEPTH - 1)) == 0, "ring slots are addressed with a mask");
   static_assert(KS >= 3, "first / middle / last k step");
 };
 
@@ -152,17 +156,21 @@ __device__ __forceinline__ void tile_store_block(const double (&acc)[3][3], char
   }
 }
 
-// One persistent workgroup per CU, 8 waves; workgroup b belongs to the team of XCD b % 8 (round-robin dispatch; a different
-// placement costs L2 hits, never correctness).
-template <int M, int N, int K, int RDV>
-__global__ void __launch_bounds__(512) mm_numeric_f64_tile(TileArgs P) {
-  typedef TileKernel<M, N, K, RDV> TK;
+// One persistent workgroup per CU, WAVES waves; workgroup b belongs to the team of XCD b % 8 (round-robin dispatch; a different
+// placement costs L2 hits, never correctness).  TR x TC: C blocks of a wave's sub-tile; DEPTH: ring slots per wave (the product being
+// multiplied + DEPTH - 1 in flight).
+template <int M, int N, int K, int RDV, int TR, int TC, int WAVES, int DEPTH>
+__global__ void __launch_bounds__(64 * WAVES) mm_numeric_f64_tile(TileArgs P) {
+  typedef TileKernel<M, N, K, RDV, DEPTH> TK;
+  constexpr int SLOTS = TR * TC, AHEAD = DEPTH - 1;
+  static_assert(SLOTS <= kTileMaxSlots && TR <= kTileMaxT && TC <= kTileMaxT, "slot numbering of the index kernels");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, voff = lane * 16;
   const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int xcd = blockIdx.x & 7, cu = blockIdx.x >> 3;
-  const int q = cu * 8 + wid;  // position in the team
+  const int q = cu * WAVES + wid;  // position in the team
   char* ring = smem + wid * TK::RING;
+  char* stage = ring + TK::STAGE;
   const unsigned ring_lds = lds_offset_of(ring);
   const LaneMap L(lane);
   const TileGeom G = P.G;
@@ -170,18 +178,20 @@ __global__ void __launch_bounds__(512) mm_numeric_f64_tile(TileArgs P) {
   // lane parts of the fragment addresses inside a ring slot (doubles): constant for the whole life of the wave
   const int la = L.rowl + M * L.kq, lb = TK::SA / 8 + L.kq + K * L.coll;
   const bool ktail_dead = (K & 3) != 0 && (4 * (TK::KS - 1) + L.kq) >= K;
-  const bool in_team = q < G.team_rows * kTeamCols && q < 256;
+  const int team_n = G.team_rows * kTeamCols < 256 ? G.team_rows * kTeamCols : 256;
+  const bool in_team = q < team_n;
+  const bool my_counters = 4 * lane < team_n;  // (team_n is a multiple of 4: kTeamCols is)
   int window = __builtin_amdgcn_readfirstlane(P.window);
   unsigned seen_min = 0;  // last minimum read from the team (the true minimum only grows: a stale value is conservative)
   const __amdgpu_buffer_rsrc_t rs_team = __builtin_amdgcn_make_buffer_rsrc((void*)team, 0, 1024, 0x00020000);
   // Publishing is branch-free: every lane issues the store, the lanes other than 0 with an offset past the end of the buffer
   // descriptor (dropped by the bounds check).  A divergent branch inside the product loop would make the compiler restructure the
-  // whole loop body -- including the nine-way choice of the accumulator set, whose joins then copy whole sets.
+  // whole loop body -- including the choice of the accumulator set, whose joins then copy whole sets.
   const int pub_off = lane == 0 ? 4 * q : 0x7ffffff0;
-  // Stores to the team's counters are rationed: 256 waves share eight cache lines, and a store per product (29 M per multiply of
-  // config 2, every one a partial-line write) took longer than the multiply itself.  A wave republishes only when its need has
-  // moved on by a quantum (an eighth of the window): what it publishes is a LOWER bound of what it still needs, so publishing
-  // late is always safe, and the team's view of it lags by less than the quantum.
+  // Stores to the team's counters are rationed: the team's waves share eight cache lines, and a store per product (29 M per
+  // multiply of config 2, every one a partial-line write) took longer than the multiply itself.  A wave republishes only when its
+  // need has moved on by a quantum (an eighth of the window): what it publishes is a LOWER bound of what it still needs, so
+  // publishing late is always safe, and the team's view of it lags by less than the quantum.
   const int qshift = P.knobs & 7 ? (P.knobs & 7) : 3;             // knobs bits 0-2: publish quantum = window >> qshift (default 3)
   const bool use_prio = (P.knobs >> 3) & 1;                       // bit 3: issue priority by distance from the team's minimum
   const unsigned quantum = (window >> qshift) > 0 ? (unsigned)(window >> qshift) : 1u;
@@ -200,14 +210,13 @@ __global__ void __launch_bounds__(512) mm_numeric_f64_tile(TileArgs P) {
     else
       __builtin_amdgcn_raw_buffer_store_b32(g, rs_team, pub_off, 0, 0);   // into this XCD's L2 (where the whole team reads it)
   };
-  // next-need protocol: the wave that holds the minimum may always go on
+  // next-need protocol: the wave that holds the minimum may always go on.  What a wave publishes is the k of the next product it
+  // will FETCH (what is already on its way to LDS needs no L2 residency any more).
   auto admit = [&](unsigned g) {
     if (window <= 0) return;
     if (g <= seen_min + (unsigned)window) {  // inside the window already: no traffic at all, except the rationed progress report
       if (g >= published + quantum) publish(g);
       if (use_prio) {
-        // the two waves of a SIMD share its MFMA pipe: the one further behind in the team's sweep gets the pipe first, the one
-        // near the front of the window (it will have to wait there anyway) yields -- spread reduced without anybody idling
         const unsigned lead = g - seen_min;   // (seen_min is a stale lower bound of the minimum: lead is an upper bound)
         if (lead * 4 < (unsigned)window)
           __builtin_amdgcn_s_setprio(3);
@@ -223,8 +232,9 @@ __global__ void __launch_bounds__(512) mm_numeric_f64_tile(TileArgs P) {
     ++n_blocked;
     for (;;) {
       ++n_polls;
-      // the 256 counters of the team in one 1 KiB read (sc1: not from this CU's vector cache)
-      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_team, voff, 0, 16);
+      // the counters of the team in one 1 KiB read (sc1: not from this CU's vector cache); lanes past the team see "done"
+      u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_team, voff, 0, 16);
+      if (!my_counters) v = u32x4{kTileDone, kTileDone, kTileDone, kTileDone};
       unsigned m = v[0] < v[1] ? v[0] : v[1];
       const unsigned m2 = v[2] < v[3] ? v[2] : v[3];
       m = m < m2 ? m : m2;
@@ -242,7 +252,7 @@ __global__ void __launch_bounds__(512) mm_numeric_f64_tile(TileArgs P) {
         __builtin_amdgcn_s_sleep(2);
     }
   };
-  double acc[kTileSlots][3][3];
+  double acc[SLOTS][3][3];
   for (int s = 0; in_team && s < G.nseq; ++s) {
     const int st = xcd + 8 * s;
     if (st >= G.nSR * G.nSC) break;
@@ -255,8 +265,9 @@ __global__ void __launch_bounds__(512) mm_numeric_f64_tile(TileArgs P) {
     const int n = __builtin_amdgcn_readfirstlane(td->n_main);
     const int64_t ls = tile_uniform64(td->list_start);
     const TileEntry* e = P.entries + ls;
+    const unsigned kbase = (unsigned)(s * G.kspan);
 #pragma unroll
-    for (int sl = 0; sl < kTileSlots; ++sl)
+    for (int sl = 0; sl < SLOTS; ++sl)
 #pragma unroll
       for (int a = 0; a < 3; ++a)
 #pragma unroll
@@ -265,7 +276,7 @@ __global__ void __launch_bounds__(512) mm_numeric_f64_tile(TileArgs P) {
     // no scalar load next to the fragment reads (SMEM returns out of order: one in flight turns every lgkmcnt wait of the
     // multiply into lgkmcnt(0) -- measured: 22.4 -> 27.2 ms), and no vector load INSIDE the loop over a window's products (the
     // compiler would have to place s_waitcnt vmcnt(0) where a refill branch joins, i.e. before every product, and that wait also
-    // covers the LDS-DMA pieces in flight).  Windows overlap by one entry: product p needs entry p + 1 to request its operands.
+    // covers the LDS-DMA pieces in flight).  Windows overlap by AHEAD entries: product p requests the operands of product p + AHEAD.
     const __amdgpu_buffer_rsrc_t rs_list = __builtin_amdgcn_make_buffer_rsrc((void*)e, 0, n * 16, 0x00020000);
     u32x4 ev = {0u, 0u, 0u, 0u};
     auto entry_of = [&](int j) {  // entry base + j of the current window, j wave-uniform
@@ -282,32 +293,36 @@ __global__ void __launch_bounds__(512) mm_numeric_f64_tile(TileArgs P) {
       dma_block<TK::ABYTES>(P.a_data + ao, lds, voff);
       dma_block<TK::BBYTES>(P.b_data + bo, lds + TK::SA, voff);
     };
-    TileEntry cur = {0u, 0u, 0u, 0u}, nxt = {0u, 0u, 0u, 0u};
-    for (int base = 0; base < n; base += 63) {
+    constexpr int STEP = 64 - AHEAD;
+    for (int base = 0; base < n; base += STEP) {
       ev = __builtin_amdgcn_raw_buffer_load_b128(rs_list, voff, base * 16, 0);  // entries base .. base + 63 (zeros past the end)
-      const int jn = n - base < 63 ? n - base : 63;
-      if (base == 0) {
-        cur = entry_of(0);
-        admit((unsigned)(s * G.kspan) + cur.k);
-        issue(cur, 0);
+      const int jn = n - base < STEP ? n - base : STEP;
+      if (base == 0) {  // the first AHEAD products of the list
+#pragma unroll
+        for (int i = 0; i < AHEAD; ++i)
+          if (i < n) {
+            const TileEntry en = entry_of(i);
+            admit(kbase + en.k);
+            issue(en, i);
+          }
       }
       for (int j = 0; j < jn; ++j) {
         const int p = base + j;
-        const bool more = p + 1 < n;
         unsigned long long t0 = timing ? __builtin_amdgcn_s_memrealtime() : 0ull;
-        if (more) {
-          nxt = entry_of(j + 1);
-          admit((unsigned)(s * G.kspan) + nxt.k);
+        const uint32_t cur_w = (uint32_t)__builtin_amdgcn_readlane((int)ev[2], j);
+        if (p + AHEAD < n) {
+          const TileEntry nxt = entry_of(j + AHEAD);
+          admit(kbase + nxt.k);
           if (timing) {
             const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
             t_admit += t1 - t0;
             t0 = t1;
           }
-          issue(nxt, (p + 1) & 1);
-          if (P.prefetch && j + 2 < 64 && p + 2 < n) {
+          issue(nxt, (p + AHEAD) & (DEPTH - 1));
+          if (DEPTH == 2 && P.prefetch && j + 2 < 64 && p + 2 < n) {
             // pull the blocks of product p + 2 into this XCD's L2 ahead of their DMA (one dword per 128-byte line, lanes past the
-            // block are dropped by the descriptor's bounds check; the loaded values are never used): the ring holds one product
-            // in flight per wave, which covers an L2 hit but not a trip over the fabric
+            // block are dropped by the descriptor's bounds check; the loaded values are never used): the two-slot ring holds one
+            // product in flight per wave, which covers an L2 hit but not a trip over the fabric
             const TileEntry pf = entry_of(j + 2);
             const uint64_t ao = (uint64_t)pf.a_lo | ((uint64_t)((pf.w >> 16) & 0xffu) << 32), bo = (uint64_t)pf.b_lo | ((uint64_t)(pf.w >> 24) << 32);
             const dma_rsrc_t ra = dma_make_rsrc(P.a_data + ao, (unsigned)TK::ABYTES), rb = dma_make_rsrc(P.b_data + bo, (unsigned)TK::BBYTES);
@@ -319,39 +334,50 @@ __global__ void __launch_bounds__(512) mm_numeric_f64_tile(TileArgs P) {
                          : "memory");
             dma_wait<TK::PIECES + 2>();
           } else {
-            dma_wait<TK::PIECES>();  // the pieces of product p have landed (loads return in order; a pending store only makes this wait longer)
+            dma_wait<AHEAD * TK::PIECES>();  // the pieces of product p have landed (loads return in order; a pending store only makes this wait longer)
           }
         } else {
-          dma_wait<0>();
+          // the tail of the list: fewer products in flight behind this one
+          const int newer = n - 1 - p;  // < AHEAD
+          if (AHEAD >= 3 && newer == 2)
+            dma_wait<2 * TK::PIECES>();
+          else if (AHEAD >= 2 && newer == 1)
+            dma_wait<1 * TK::PIECES>();
+          else
+            dma_wait<0>();
         }
         if (timing) {
           const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
           t_wait += t1 - t0;
           t0 = t1;
         }
-        const double* sl = reinterpret_cast<const double*>(ring + (p & 1) * TK::SLOT);
+        const double* sl = reinterpret_cast<const double*>(ring + (p & (DEPTH - 1)) * TK::SLOT);
         const double *pa = sl + la, *pb = sl + lb;
         // one multiply body per accumulator set (the set is a compile-time choice: registers cannot be indexed)
-        switch (cur.w & 15u) {
-#define DBCSR_TILE_CASE(S_) \
-  case S_: tile_multiply<M, N, K, RDV>(acc[S_], pa, pb, ktail_dead); break;
-          DBCSR_TILE_CASE(0) DBCSR_TILE_CASE(1) DBCSR_TILE_CASE(2) DBCSR_TILE_CASE(3) DBCSR_TILE_CASE(4)
-          DBCSR_TILE_CASE(5) DBCSR_TILE_CASE(6) DBCSR_TILE_CASE(7)
+        switch (cur_w & 15u) {
+#define DBCSR_TILE_CASE(S_)                                                                     \
+  case S_:                                                                                      \
+    if constexpr (S_ < SLOTS) tile_multiply<M, N, K, RDV>(acc[S_], pa, pb, ktail_dead);         \
+    break;
+          DBCSR_TILE_CASE(0) DBCSR_TILE_CASE(1) DBCSR_TILE_CASE(2) DBCSR_TILE_CASE(3) DBCSR_TILE_CASE(4) DBCSR_TILE_CASE(5)
+          DBCSR_TILE_CASE(6) DBCSR_TILE_CASE(7) DBCSR_TILE_CASE(8) DBCSR_TILE_CASE(9) DBCSR_TILE_CASE(10) DBCSR_TILE_CASE(11)
+          DBCSR_TILE_CASE(12) DBCSR_TILE_CASE(13) DBCSR_TILE_CASE(14)
 #undef DBCSR_TILE_CASE
-          default: tile_multiply<M, N, K, RDV>(acc[8], pa, pb, ktail_dead); break;
+          default:
+            if constexpr (15 < SLOTS) tile_multiply<M, N, K, RDV>(acc[SLOTS - 1], pa, pb, ktail_dead);
+            break;
         }
         if (timing) t_mul += __builtin_amdgcn_s_memrealtime() - t0;
-        cur = nxt;
       }
     }
     const unsigned long long t_e0 = timing ? __builtin_amdgcn_s_memrealtime() : 0ull;
     // the wave needs nothing below the next super-tile any more: do not hold the team back during the epilogue
     if (window > 0) publish((unsigned)((s + 1) * G.kspan));
 #pragma unroll
-    for (int sl2 = 0; sl2 < kTileSlots; ++sl2) {
+    for (int sl2 = 0; sl2 < SLOTS; ++sl2) {
       // (wave-uniform by construction; said explicitly so that the buffer descriptors made from them stay in scalar registers)
       const int64_t c_off = tile_uniform64(td->c_off[sl2]), cin_off = tile_uniform64(td->cin_off[sl2]);
-      if (c_off >= 0) tile_store_block<M, N>(acc[sl2], ring, c_off, cin_off, P.c_out, P.c_in, P.alpha, P.beta, L, voff);
+      if (c_off >= 0) tile_store_block<M, N>(acc[sl2], stage, c_off, cin_off, P.c_out, P.c_in, P.alpha, P.beta, L, voff);
     }
     if (timing) t_epi += __builtin_amdgcn_s_memrealtime() - t_e0;
   }
@@ -370,7 +396,7 @@ __global__ void __launch_bounds__(512) mm_numeric_f64_tile(TileArgs P) {
     }
   }
   if (P.window > 0) {
-    atomicAdd(P.flags + 2, lane == 0 ? (int)(n_polls >> 4) : 0);   // (in units of 16: the sum over 2048 waves stays in range)
+    atomicAdd(P.flags + 2, lane == 0 ? (int)(n_polls >> 4) : 0);   // (in units of 16: the sum over the waves stays in range)
     atomicAdd(P.flags + 3, lane == 0 ? (int)(n_blocked >> 4) : 0);
   }
 }
@@ -411,34 +437,49 @@ __global__ void __launch_bounds__(256) tile_remainder(TileGeom G, const TileDesc
 }
 
 
-int tile_lds_bytes(int m, int n, int k) {
+bool tile_shape(int shape, int* tr, int* tc, int* wg_waves) {
+  switch (shape) {
+    case 0: *tr = 3, *tc = 3, *wg_waves = 8; return true;
+    case 1: *tr = 4, *tc = 3, *wg_waves = 4; return true;
+    default: return false;
+  }
+}
+
+// (TR, TC, WAVES, DEPTH) of the shapes: the table of tile_shape(), as template arguments
+#define DBCSR_TILE_SHAPE0 3, 3, 8, 2
+#define DBCSR_TILE_SHAPE1 4, 3, 4, 4
+
+int tile_lds_bytes(int m, int n, int k, int shape) {
   if (m != n || m != k) return 0;
   switch (m) {
 #define DBCSR_TILE_LDS(S_) \
-  case S_: return 8 * TileKernel<S_, S_, S_, 0>::RING;
+  case S_: return shape == 1 ? 4 * TileKernel<S_, S_, S_, 0, 4>::RING : 8 * TileKernel<S_, S_, S_, 0, 2>::RING;
     DBCSR_AMD_TILE_SIZES(DBCSR_TILE_LDS)
 #undef DBCSR_TILE_LDS
     default: return 0;
   }
 }
 
-template <int S_, int RDV>
+template <int S_, int RDV, int TR, int TC, int WAVES, int DEPTH>
 static int tile_launch_one(unsigned nwg, hipStream_t st, const TileArgs& P) {
-  typedef TileKernel<S_, S_, S_, RDV> TK;
+  typedef TileKernel<S_, S_, S_, RDV, DEPTH> TK;
   static bool attr = false;
   if (!attr) {  // more than 64 KB of dynamic LDS needs the attribute, once per kernel
-    ACC_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(mm_numeric_f64_tile<S_, S_, S_, RDV>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * TK::RING));
+    ACC_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(mm_numeric_f64_tile<S_, S_, S_, RDV, TR, TC, WAVES, DEPTH>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, WAVES * TK::RING));
     attr = true;
   }
-  hipLaunchKernelGGL((mm_numeric_f64_tile<S_, S_, S_, RDV>), dim3(nwg), dim3(512), 8 * TK::RING, st, P);
+  hipLaunchKernelGGL((mm_numeric_f64_tile<S_, S_, S_, RDV, TR, TC, WAVES, DEPTH>), dim3(nwg), dim3(64 * WAVES), WAVES * TK::RING, st, P);
   return check(hipGetLastError(), "mm_numeric_f64_tile", __FILE__, __LINE__);
 }
 
-int tile_launch(int m, int n, int k, int rdv, unsigned nwg, hipStream_t st, const TileArgs& P) {
+int tile_launch(int m, int n, int k, int rdv, int shape, unsigned nwg, hipStream_t st, const TileArgs& P) {
   if (m != n || m != k) return 1;
   switch (m) {
-#define DBCSR_TILE_LAUNCH(S_) \
-  case S_: return rdv ? tile_launch_one<S_, 1>(nwg, st, P) : tile_launch_one<S_, 0>(nwg, st, P);
+#define DBCSR_TILE_LAUNCH(S_)                                                                                                         \
+  case S_:                                                                                                                            \
+    if (shape == 1) return rdv ? tile_launch_one<S_, 1, DBCSR_TILE_SHAPE1>(nwg, st, P) : tile_launch_one<S_, 0, DBCSR_TILE_SHAPE1>(nwg, st, P); \
+    return rdv ? tile_launch_one<S_, 1, DBCSR_TILE_SHAPE0>(nwg, st, P) : tile_launch_one<S_, 0, DBCSR_TILE_SHAPE0>(nwg, st, P);
     DBCSR_AMD_TILE_SIZES(DBCSR_TILE_LAUNCH)
 #undef DBCSR_TILE_LAUNCH
     default: return 1;

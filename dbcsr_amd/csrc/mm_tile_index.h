@@ -1,4 +1,4 @@
-// mm_tile_index.h -- index kernels of the tile dataflow (mm_tile.h): per sub-tile the descriptors of its nine C blocks and ONE
+// mm_tile_index.h -- index kernels of the tile dataflow (mm_tile.h): per sub-tile the descriptors of its C blocks and ONE
 // k-sorted product list, built from the bitmaps of A (rows) and of B transposed (columns) with wave-wide prefix sums.  Integer work,
 // bit-exact by construction; the host sequence is run_tile_f64 in mm_engine.hip (the only file that includes this one).
 #ifndef DBCSR_AMD_MM_TILE_INDEX_H
@@ -35,14 +35,14 @@ __global__ void __launch_bounds__(256) tile_bitmap_transposed(const int* __restr
 __global__ void __launch_bounds__(256) tile_descs(TileGeom G, const int* __restrict__ rows, const int* __restrict__ cols,
                                                   const uint32_t* __restrict__ c_bm, const int* __restrict__ c_pre, const int* __restrict__ c_row_p,
                                                   int W, const Desc* __restrict__ descs, TileDesc* __restrict__ td, int* __restrict__ tile_cnt) {
-  const int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;  // 16 lanes per sub-tile, 9 used
+  const int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;  // 16 lanes per sub-tile, one per slot
   const int s = threadIdx.x & 15;
   if (t >= (int64_t)G.nTR * G.nTC) return;
   const int tr = (int)(t / G.nTC), tc = (int)(t % G.nTC);
   int cnt = 0;
   int64_t c_off = -1, cin_off = -1;
-  if (s < kTileSlots) {
-    const int ri = kTileT * tr + s / kTileT, ci = kTileT * tc + s % kTileT;
+  if (s < G.tr * G.tc) {
+    const int ri = G.tr * tr + s / G.tc, ci = G.tc * tc + s % G.tc;
     if (ri < G.nfr && ci < G.nfc) {
       const int i = rows[ri], j = cols[ci];
       const uint32_t cw = c_bm[(size_t)i * W + (j >> 5)];
@@ -63,7 +63,7 @@ __global__ void __launch_bounds__(256) tile_descs(TileGeom G, const int* __restr
 }
 
 // one wavefront per sub-tile: the k-sorted product list.  Lane l of a trip looks at inner block k = k0 + l: which of the tile's
-// three rows have A(i, k), which of its three columns have B(k, j) (bitmap of B transposed), so popc x popc products; a wave-wide
+// rows have A(i, k), which of its columns have B(k, j) (bitmap of B transposed), so popc x popc products; a wave-wide
 // prefix sum gives every lane its place in the list.
 __global__ void __launch_bounds__(256)
 tile_lists(TileGeom G, const int* __restrict__ rows, const int* __restrict__ cols, int nbk, int Wk, const uint32_t* __restrict__ a_bm,
@@ -75,18 +75,18 @@ tile_lists(TileGeom G, const int* __restrict__ rows, const int* __restrict__ col
   const int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (t >= (int64_t)G.nTR * G.nTC) return;
   const int tr = (int)(t / G.nTC), tc = (int)(t % G.nTC);
-  int ri[kTileT], cj[kTileT];
+  int ri[kTileMaxT], cj[kTileMaxT];
 #pragma unroll
-  for (int q = 0; q < kTileT; ++q) {
-    ri[q] = kTileT * tr + q < G.nfr ? rows[kTileT * tr + q] : -1;
-    cj[q] = kTileT * tc + q < G.nfc ? cols[kTileT * tc + q] : -1;
+  for (int q = 0; q < kTileMaxT; ++q) {
+    ri[q] = (q < G.tr && G.tr * tr + q < G.nfr) ? rows[G.tr * tr + q] : -1;
+    cj[q] = (q < G.tc && G.tc * tc + q < G.nfc) ? cols[G.tc * tc + q] : -1;
   }
   // slots that have a C block (a product only exists where C has a block: C's pattern contains the product's by construction,
   // except under retain_sparsity, where products outside C_in's pattern are dropped)
   unsigned cmask = 0;
 #pragma unroll
-  for (int s = 0; s < kTileSlots; ++s)
-    if (td[t].c_off[s] >= 0) cmask |= 1u << s;
+  for (int s = 0; s < kTileMaxSlots; ++s)
+    if (s < G.tr * G.tc && td[t].c_off[s] >= 0) cmask |= 1u << s;
   const int64_t start = tile_start[t];
   const int total = tile_cnt[t];
   int n_main = 0, n_rem = 0;
@@ -94,19 +94,19 @@ tile_lists(TileGeom G, const int* __restrict__ rows, const int* __restrict__ col
     const int k = k0 + lane;
     const bool kin = k < nbk;
     unsigned am = 0, bm = 0;
-    uint32_t aw[kTileT], bw[kTileT];
+    uint32_t aw[kTileMaxT], bw[kTileMaxT];
 #pragma unroll
-    for (int q = 0; q < kTileT; ++q) {
+    for (int q = 0; q < kTileMaxT; ++q) {
       aw[q] = (kin && ri[q] >= 0) ? a_bm[(size_t)ri[q] * Wk + (k >> 5)] : 0u;
       bw[q] = (kin && cj[q] >= 0) ? bt_bm[(size_t)cj[q] * Wk + (k >> 5)] : 0u;
       am |= ((aw[q] >> (k & 31)) & 1u) << q;
       bm |= ((bw[q] >> (k & 31)) & 1u) << q;
     }
-    // products of this lane: slot 3 ti + tj for every (ti, tj) with both operands and a C block
+    // products of this lane: slot tc * ti + tj for every (ti, tj) with both operands and a C block
     unsigned pm = 0;
 #pragma unroll
-    for (int ti = 0; ti < kTileT; ++ti)
-      if ((am >> ti) & 1u) pm |= bm << (kTileT * ti);
+    for (int ti = 0; ti < kTileMaxT; ++ti)
+      if ((am >> ti) & 1u) pm |= bm << (G.tc * ti);
     pm &= cmask;
     if (!__ballot(pm != 0)) continue;
     const int ks = kin ? k_sizes[k] : 0;
@@ -123,9 +123,9 @@ tile_lists(TileGeom G, const int* __restrict__ rows, const int* __restrict__ col
     n_main += __shfl(inc_m, 63, 64);
     n_rem += __shfl(inc_r, 63, 64);
     if (pm) {
-      int64_t aoff[kTileT], boff[kTileT];
+      int64_t aoff[kTileMaxT], boff[kTileMaxT];
 #pragma unroll
-      for (int q = 0; q < kTileT; ++q) {
+      for (int q = 0; q < kTileMaxT; ++q) {
         aoff[q] = boff[q] = 0;
         if ((am >> q) & 1u)
           aoff[q] = a_blk_p[a_row_p[ri[q]] + a_pre[(size_t)ri[q] * Wk + (k >> 5)] + __popc(aw[q] & ((1u << (k & 31)) - 1u))];
@@ -136,9 +136,9 @@ tile_lists(TileGeom G, const int* __restrict__ rows, const int* __restrict__ col
         }
       }
 #pragma unroll
-      for (int s = 0; s < kTileSlots; ++s)
+      for (int s = 0; s < kTileMaxSlots; ++s)
         if ((pm >> s) & 1u) {
-          const int64_t a = aoff[s / kTileT], b = boff[s % kTileT];
+          const int64_t a = aoff[s / G.tc], b = boff[s % G.tc];
           TileEntry e;
           e.a_lo = (uint32_t)a;
           e.b_lo = (uint32_t)b;

@@ -19,7 +19,7 @@ SPARSE_C = (23 * 60 + 16, 23 * 64 + 16, 23 * 62 + 16, 0.93, 0.93, 0.95, [1, 23],
 MANY = (23 * 170 + 16, 23 * 150 + 16, 23 * 160 + 16, 0.9, 0.9, 0.9, [1, 23], [1, 23], [1, 23])       # 16 super-tiles: two per XCD
 TAILS = (23 * 40 + 16 + 7, 23 * 44 + 9, 23 * 42 + 16 + 5, 0.7, 0.7, 0.8, [20, 23, 1, 16, 1, 7], [22, 23, 1, 9], [21, 23, 1, 16, 1, 5])
 
-ENV_KEYS = ("DBCSR_AMD_MM_TILE", "DBCSR_AMD_MM_TILE_WINDOW", "DBCSR_AMD_MM_TILE_RDV", "DBCSR_AMD_MM_TILE_PUB", "DBCSR_AMD_MM_TILE_PREFETCH", "DBCSR_AMD_MM_KERNEL", "DBCSR_AMD_MM_HOT", "DBCSR_AMD_MM_CLASSES",
+ENV_KEYS = ("DBCSR_AMD_MM_TILE", "DBCSR_AMD_MM_TILE_SHAPE", "DBCSR_AMD_MM_TILE_WINDOW", "DBCSR_AMD_MM_TILE_RDV", "DBCSR_AMD_MM_TILE_PUB", "DBCSR_AMD_MM_TILE_PREFETCH", "DBCSR_AMD_MM_KERNEL", "DBCSR_AMD_MM_HOT", "DBCSR_AMD_MM_CLASSES",
             "DBCSR_AMD_MM_DBG", "DBCSR_AMD_MM_WG_WAVES")
 
 
@@ -46,14 +46,27 @@ def run(monkeypatch, env, case, alpha=0.7, beta=1.3, retain=False):
     return gave_up
 
 
+# shape 0: 3 x 3 C blocks per wave, two waves per SIMD, two-slot ring; shape 1: 4 x 3, one wave per SIMD, four-slot ring (mm_tile.h)
+SHAPES = ["0", "1"]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
 @pytest.mark.parametrize("case", [H2O, DENSE, SPARSE_C, MANY, TAILS], ids=["h2o", "dense", "sparse_c", "many_tiles", "tails"])
-def test_tile_kernel_matches_oracle(monkeypatch, case):
-    run(monkeypatch, {}, case)
+def test_tile_kernel_matches_oracle(monkeypatch, case, shape):
+    run(monkeypatch, {"DBCSR_AMD_MM_TILE_SHAPE": shape}, case)
 
 
+@pytest.mark.parametrize("shape", SHAPES)
 @pytest.mark.parametrize("case", [H2O, MANY], ids=["h2o", "many_tiles"])
-def test_tile_kernel_retain_sparsity(monkeypatch, case):
-    run(monkeypatch, {}, case, alpha=1.0, beta=1.0, retain=True)
+def test_tile_kernel_retain_sparsity(monkeypatch, case, shape):
+    run(monkeypatch, {"DBCSR_AMD_MM_TILE_SHAPE": shape}, case, alpha=1.0, beta=1.0, retain=True)
+
+
+@pytest.mark.parametrize("window", ["0", "1", "8", "64", "100000"])
+def test_tile_kernel_deep_ring_any_window(monkeypatch, window):
+    """shape 1: results never depend on the team protocol, and short lists (fewer products than ring slots) drain correctly"""
+    run(monkeypatch, {"DBCSR_AMD_MM_TILE_WINDOW": window, "DBCSR_AMD_MM_TILE_SHAPE": "1"}, MANY)
+    run(monkeypatch, {"DBCSR_AMD_MM_TILE_WINDOW": window, "DBCSR_AMD_MM_TILE_SHAPE": "1"}, SPARSE_C)
 
 
 @pytest.mark.parametrize("window", ["0", "1", "8", "64", "100000"])
