@@ -22,6 +22,8 @@ def main():
     p.add_argument("--workload", default="config2_32768_23x23_fill10_fp64")
     p.add_argument("--ranks", default="1,2,4,8")
     p.add_argument("--steps", type=int, default=10)
+    p.add_argument("--colpipe", type=int, default=0, help="N x 1 grid and the colpipe schedule with this many column chunks (its whole compute path, "
+                                                          "exchange left out): kernel_ms is then the SUM over the chunk multiplies")
     a = p.parse_args()
     import bench
     from dbcsr_amd import cannon
@@ -32,8 +34,9 @@ def main():
     print("# ranks grid  C_blocks  products   GFLOP   wall_ms  kernel_ms  fill_ms  non_kernel_ms  kernel")
     for n in [int(x) for x in a.ranks.split(",")]:
         eng = MultiplyEngine()
-        g = cannon.Grid(n, 0)
-        plan = cannon.CannonMultiply(M, N, K, (1 - fill,) * 3, mix, dtype=dtype, engine=eng, grid=g)
+        g = cannon.Grid(n, 0, nprows=n, npcols=1) if a.colpipe else cannon.Grid(n, 0)
+        plan = cannon.CannonMultiply(M, N, K, (1 - fill,) * 3, mix, dtype=dtype, engine=eng, grid=g, mode="colpipe" if a.colpipe else "gather",
+                                     col_chunks=max(1, a.colpipe))
         # images owned by other ranks: synthetic values in place (what would have arrived over xGMI)
         for buf in (plan._a_all, plan._b_all):
             buf.uniform_(0.0, 1.0)
@@ -43,6 +46,18 @@ def main():
             row_p, counts = eng.symbolic(plan.A_panel, plan.B_panel, plan.C_in, retain_sparsity=False)
             out = eng.numeric_after_symbolic(1.0, plan.A_panel, plan.B_panel, 1.0, plan.C_in, row_p, counts, dtype)
             return out, counts
+
+        kernel_time = lambda: eng.last_timing()
+        if a.colpipe:
+            plan._exchange = lambda sends, recvs: ([], [])   # nothing travels here: the panels are in place
+
+            def step():
+                return plan._multiply_colpipe(1.0, 1.0)
+
+            def kernel_time():
+                engines = [plan._engine(None if q == 0 else ("col", q)) for q in range(len(plan._cbounds) - 1)]
+                t = [e.last_timing() for e in engines]
+                return sum(x[0] for x in t), sum(x[1] for x in t)
 
         for _ in range(3):
             out, counts = step()
@@ -55,7 +70,7 @@ def main():
         ks, fs = [], []
         for _ in range(3):
             out, counts = step()
-            f, k = eng.last_timing()
+            f, k = kernel_time()
             ks.append(k)
             fs.append(f)
         km, fm = sum(ks) / len(ks), sum(fs) / len(fs)
