@@ -463,6 +463,8 @@ class CannonMultiply:
         e = self._engines.get(key)
         if e is None:
             e = self._engines[key] = type(self.eng)()
+            if hasattr(e, "trust_plan"):
+                e.trust_plan(True)   # the plan's operands are this object's own and their index is never written again
         return e
 
     def _native_selftest(self, timeout_s=60.0):
@@ -638,7 +640,7 @@ class CannonMultiply:
                     else:
                         recvs.append((self._b_all[self._b_base[v] + lo:self._b_base[v] + hi], b_own))
             posted.append(self._exchange(sends, recvs))
-        engines = [self._engine(None if q == 0 else ("col", q)) for q in range(nch)]
+        engines = [self._engine(("col", q)) for q in range(nch)]   # (none of them the caller's: these reuse their plans by address)
         # C's structure per chunk needs the (replicated) index only: the symbolic phases run while the first chunk travels
         sym = [engines[q].symbolic(self.A_panel, self._Bc[q], self._Cc[q], retain_sparsity=False) for q in range(nch)]
         mg = self._merged

@@ -252,6 +252,9 @@ struct Engine {
   bool plan_saved = false, plan_hit = false, plan_numeric = false;
   int plan_dims[3] = {0, 0, 0}, plan_retain = 0, plan_canonical = 0, plan_datatype = 0;
   int64_t plan_nblks[3] = {0, 0, 0};
+  // dbcsr_amd_mm_trust_plan: index arrays at the ADDRESSES the saved plan saw are taken as unchanged (no comparison on the device, no
+  // synchronisation): for callers that own their operands' index and never write it in place
+  bool plan_trusted = false;
   const void* plan_ptrs[12] = {nullptr};
   DevBuf<int32_t> plan_words, plan_c_col_i;
   DevBuf<int64_t> plan_c_blk_p;
@@ -331,6 +334,11 @@ static int plan_matches(Engine* E, const dbcsr_amd_bcsr* a, const dbcsr_amd_bcsr
   const void* ptr[12];
   long long n[12];
   plan_segments(a, b, c_in, ptr, n);
+  if (E->plan_trusted) {
+    bool same = true;
+    for (int i = 0; i < 12; ++i) same = same && ptr[i] == E->plan_ptrs[i];
+    if (same) return 1;
+  }
   PlanSegs S;
   S.nseg = 12;
   long long off = 0, total = 0;
@@ -372,6 +380,7 @@ static int plan_save(Engine* E, const dbcsr_amd_bcsr* a, const dbcsr_amd_bcsr* b
   E->plan_retain = retain;
   E->plan_canonical = E->canonical_c;
   E->plan_counts = counts;
+  for (int i = 0; i < 12; ++i) E->plan_ptrs[i] = ptr[i];
   E->plan_saved = true;
   return 0;
 }
@@ -1533,6 +1542,13 @@ const char* dbcsr_amd_mm_kernel_name(libsmm_acc_data_t datatype) {
 const char* dbcsr_amd_mm_last_kernel(void* handle) {
   Engine* E = static_cast<Engine*>(handle);
   return E ? E->last_kernel : "";
+}
+
+int dbcsr_amd_mm_trust_plan(void* handle, int on) {
+  Engine* E = static_cast<Engine*>(handle);
+  if (!E) return -1;
+  E->plan_trusted = on != 0;
+  return 0;
 }
 
 int dbcsr_amd_mm_plan_stats(void* handle, int64_t* reused, int64_t* built) {

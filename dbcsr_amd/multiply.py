@@ -117,6 +117,11 @@ class MultiplyEngine:
             raise RuntimeError("dbcsr_amd_mm_plan_stats failed")
         return a.value, b.value
 
+    def trust_plan(self, on=True):
+        """Plan reuse by address (dbcsr_amd_mm_trust_plan): for operands whose index arrays are never written in place."""
+        if self.L.dbcsr_amd_mm_trust_plan(self.h, 1 if on else 0) != 0:
+            raise RuntimeError("dbcsr_amd_mm_trust_plan failed")
+
     def tile_stats(self):
         """(waves that gave up waiting in the k window, sub-tile lists that disagreed with the per-block counts) of the last numeric
         call, or None when it did not run the tile kernel (dbcsr_amd_mm_tile_stats)"""

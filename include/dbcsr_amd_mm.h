@@ -204,6 +204,11 @@ const char* dbcsr_amd_mm_last_kernel(void* handle);
  * multiply of this handle -- every SCF step of a CP2K run -- skips its symbolic phase: the engine keeps device copies of the last
  * call's index arrays and compares the incoming ones on the device (one small kernel, one flag).  Multiplies with filter_eps > 0
  * never reuse (their pattern depends on the values).  DBCSR_AMD_MM_PLAN=0 switches it off.  Counters since the handle was made: */
+/* Plan reuse without the comparison: while `on`, operands whose twelve index arrays (row_p / col_i / blk_p of A, B, C_in, the three
+   block-size arrays) sit at the ADDRESSES the saved plan saw are taken as unchanged -- no comparison kernel, no synchronisation of
+   the stream in dbcsr_amd_mm_symbolic.  For callers that own these arrays and never write them in place (the panels of a
+   distributed multiply: dbcsr_amd/cannon.py); anything at another address is compared as always. */
+int dbcsr_amd_mm_trust_plan(void* handle, int on);
 int dbcsr_amd_mm_plan_stats(void* handle, int64_t* reused, int64_t* built);
 
 /* Diagnostics of the tile kernel (dbcsr_amd/csrc/mm_tile.h) in the last dbcsr_amd_mm_numeric of this handle: waves that gave up

@@ -90,3 +90,38 @@ def test_plan_switch_off(monkeypatch):
     check(eng, A, B, Cm)
     check(eng, A, B, Cm)
     assert eng.plan_stats() == (0, 2)
+
+
+def test_trusted_plan_reuses_by_address_and_compares_everything_else(monkeypatch):
+    """dbcsr_amd_mm_trust_plan: the same device arrays -> plan reused without a comparison (new VALUES in the same buffers are new
+    values); other arrays, even with the same content, are compared as always; a changed pattern at another address builds a new plan"""
+    monkeypatch.delenv("DBCSR_AMD_MM_PLAN", raising=False)
+    eng = MultiplyEngine()
+    eng.trust_plan(True)
+    A, B, Cm = O.perf_case(*H2O)
+    ref, _ = O.multiply("N", "N", 0.7, A, B, 1.3, Cm)
+    dA, dB, dC = to_dev(A), to_dev(B), to_dev(Cm)
+
+    def run(a, b, c, alpha, beta, expect):
+        out, counts = eng.multiply_local(alpha, a, b, beta, c)
+        torch.cuda.synchronize()
+        got = dev_to_bcsr(out)
+        assert np.array_equal(got.col_i, expect.col_i) and np.array_equal(got.blk_p, expect.blk_p)
+        assert rel_err(got.data, expect.data) <= 1e-10
+
+    run(dA, dB, dC, 0.7, 1.3, ref)
+    run(dA, dB, dC, 0.7, 1.3, ref)
+    assert eng.plan_stats() == (1, 1)
+    dA.data.mul_(2.0)   # new values in place: same plan, new product
+    ref2, _ = O.multiply("N", "N", 0.7, O.Bcsr(A.row_sizes, A.col_sizes, A.row_p, A.col_i, A.blk_p, A.data * 2.0), B, 1.3, Cm)
+    run(dA, dB, dC, 0.7, 1.3, ref2)
+    assert eng.plan_stats() == (2, 1)
+    # the same index at OTHER addresses: compared, found equal, reused
+    dB2 = to_dev(B)
+    run(dA, dB2, dC, 0.7, 1.3, ref2)
+    assert eng.plan_stats() == (3, 1)
+    # another pattern of C_in (at other addresses): a new plan
+    A3, B3, C3 = O.perf_case(H2O[0], H2O[1], H2O[2], 0.6, 0.6, 0.5, [1, 23], [1, 23], [1, 23])
+    ref3, _ = O.multiply("N", "N", 0.7, O.Bcsr(A.row_sizes, A.col_sizes, A.row_p, A.col_i, A.blk_p, A.data * 2.0), B, 1.3, C3)
+    run(dA, dB2, to_dev(C3), 0.7, 1.3, ref3)
+    assert eng.plan_stats() == (3, 2)

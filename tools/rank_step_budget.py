@@ -55,7 +55,7 @@ def main():
                 return plan._multiply_colpipe(1.0, 1.0)
 
             def kernel_time():
-                engines = [plan._engine(None if q == 0 else ("col", q)) for q in range(len(plan._cbounds) - 1)]
+                engines = [plan._engine(("col", q)) for q in range(len(plan._cbounds) - 1)]
                 t = [e.last_timing() for e in engines]
                 return sum(x[0] for x in t), sum(x[1] for x in t)
 
