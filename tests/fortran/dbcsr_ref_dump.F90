@@ -112,6 +112,7 @@ PROGRAM dbcsr_ref_dump
    cs_pos = dbcsr_checksum(mc, pos=.TRUE.)
 
    nblk = dbcsr_get_num_blocks(mc)
+   IF (numnodes > 1) WRITE (fout, '(A,A,I0)') TRIM(fout), '.rank', mynode   ! (one file per rank: its own blocks, the global checksums)
    OPEN (newunit=u, file=TRIM(fout), status='replace', action='write')
    WRITE (u, '(A,3(1X,I0))') 'dims', dbcsr_nblkrows_total(mc), dbcsr_nblkcols_total(mc), nblk
    WRITE (u, '(A,1X,I0)') 'flop', flop

@@ -100,3 +100,64 @@ def test_resident_multi_rank_falls_through_together(tmp_path):
     r = subprocess.run([MPIEXEC, "-n", "2", exe], cwd=tmp_path, env=dict(ENV, DBCSR_AMD_RESIDENT="1"), capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " FAILED !" not in r.stdout.upper() and r.stdout.upper().count("PASSED !") > 0, r.stdout[-3000:]
+
+
+def run_dump_and_compare_with_fixture(host, name, nranks, tmp_path, env):
+    """dbcsr_ref_dump of `host` on `nranks` ranks (one output file per rank: its blocks, the global checksum); the union of the ranks'
+    C blocks must be the block set of the reference's single-rank result (tests/golden/ref_dump.json), values to 1e-10"""
+    import base64
+    import sys
+
+    import numpy as np
+    from tests import ref_dump_util as R
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_ref_fixtures as F
+    exe = os.path.join(ROOT, "oracle", "_ref", host, "dbcsr_ref_dump")
+    if not (os.path.exists(exe) and os.path.exists(MPIEXEC)):
+        pytest.skip("%s or mpiexec not available" % host)
+    ref = R.RefResult(name)
+    F.write_nml(ref.params, str(tmp_path / "case.nml"))
+    r = subprocess.run([MPIEXEC, "-n", str(nranks), exe, str(tmp_path / "case.nml"), str(tmp_path / "out.txt")], cwd=tmp_path,
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    got = {}
+    for q in range(nranks):
+        d = F.parse_dump(str(tmp_path / ("out.txt.rank%d" % q)))
+        assert abs(d["checksum"][0] / ref.checksum - 1.0) <= 1e-11   # (the checksum is global: every rank wrote the same one)
+        vals = np.frombuffer(base64.b64decode(d["values_b64"]), "<f8") if d["nblks"] else np.zeros(0)
+        off = 0
+        for row, col, m, n in zip(d["row"], d["col"], d["m"], d["n"]):
+            assert (row, col) not in got, "a block of C on two ranks"
+            got[(row, col)] = vals[off:off + m * n]
+            off += m * n
+    assert len(got) == ref.nblks
+    scale = max(float(np.max(np.abs(ref.data))), 1e-300) if ref.nblks else 1.0
+    off = 0
+    for b in range(ref.nblks):
+        key = (int(ref.rows[b]) + 1, int(ref.col_i[b]) + 1)
+        ne = int(ref.m[b] * ref.n[b])
+        assert key in got, key
+        assert np.max(np.abs(got[key] - ref.data[off:off + ne])) <= 1e-10 * scale, key
+        off += ne
+    return r.stdout
+
+
+FILTER_CASES = ["filter_eps_mid", "filter_eps_mixed", "filter_eps_retain", "basic_5"]
+
+
+@pytest.mark.parametrize("nranks", [2, 4])
+@pytest.mark.parametrize("name", FILTER_CASES[:2])
+def test_reference_mpi_filtered_multiply_equals_the_single_rank_fixture(name, nranks, tmp_path):
+    """what the GPU test below relies on: the reference itself, on several ranks, filters to the block set of its single-rank run"""
+    run_dump_and_compare_with_fixture("host_cpu_mpi", name, nranks, tmp_path, ENV)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nranks", [2, 4])
+@pytest.mark.parametrize("name", FILTER_CASES)
+def test_resident_multi_rank_filtered_multiply_matches_the_reference(name, nranks, tmp_path):
+    """filter_eps under the multi-rank glue: every rank holds the whole block row panel of A, so the on-the-fly filter sees the row
+    counts the reference sums over the process row (dbcsr_mm_cannon.F:1040-1113) and takes the decisions one rank would."""
+    out = run_dump_and_compare_with_fixture("host_resident_mpi", name, nranks, tmp_path, dict(ENV, DBCSR_AMD_RESIDENT="1v"))
+    ranks = set(int(m) for m in re.findall(r"dbcsr_amd_resident: rank\s+(\d+) of", out))
+    assert ranks == set(range(nranks)), "not every rank multiplied on the device:\n" + out[-2500:]
