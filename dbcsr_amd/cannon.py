@@ -33,7 +33,9 @@ The local engine is duck-typed (``symbolic``, ``init_c``, ``accumulate``,
 distribution / schedule / communication logic can be exercised on CPU with the
 ``gloo`` backend in tests.
 """
+import contextlib
 import math
+import os
 
 import numpy as np
 import torch
@@ -280,7 +282,7 @@ class CannonMultiply:
 
     def __init__(self, M=0, N=0, K=0, sparsities=(0, 0, 0), mix=(1, 1), dtype=torch.float64, engine=None, device=None, grid=None,
                  mix_n=None, mix_k=None, mode="gather", local_first=True, matrices=None, transport="torch", distributed=None,
-                 col_chunks=4, share_comm_with=None):
+                 col_chunks=8, share_comm_with=None):
         # transport: "torch" = torch.distributed point-to-point (RCCL under the nccl backend, gloo on CPU);
         #            "native" = the C-ABI exchange of include/dbcsr_amd_comm.h (RCCL group on a dedicated HIP stream);
         #            "auto"   = native when it can be set up (GPU tensors, more than one rank), else torch
@@ -443,6 +445,8 @@ class CannonMultiply:
         self._Bc = self._Cc = None
         self._merged = None
         self.colpipe_copies = 0
+        self.colpipe_two_streams = os.environ.get("DBCSR_AMD_COLPIPE_STREAMS", "2") != "1"
+        self._side_stream = None
         if self._cbounds is not None:
             nch = len(self._cbounds) - 1
             self._Bc = [self._col_sub(self.B_panel, int(self._cbounds[q]), int(self._cbounds[q + 1])) for q in range(nch)]
@@ -646,17 +650,35 @@ class CannonMultiply:
         mg = self._merged
         out_all = torch.empty(mg["nze"], dtype=self.dtype, device=self.device) if mg is not None else None
         parts, flop, nprod = [], 0, 0
+        # Odd chunks are multiplied on a second stream: a chunk's kernel is short (0.7 ms at 8 ranks), and the tail of one then runs
+        # under the head of the next (they touch disjoint C blocks and have an engine each; each waits for its own batch only)
+        main = side = None
+        if self.device.type == "cuda" and nch > 1 and self.colpipe_two_streams:
+            main = torch.cuda.current_stream()
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(device=self.device)
+            side = self._side_stream
+            side.wait_stream(main)   # the symbolic phases' results, and whatever used the output buffer's memory before
+            if out_all is not None:
+                out_all.record_stream(side)
         for q in range(nch):
-            self._arrived(*posted[q])
             row_p, cnt = sym[q]
             eng = self.last_engine = engines[q]
             kw = {}
             if out_all is not None and getattr(eng, "accepts_out_data", False):
                 kw["out_data"] = out_all[mg["off"][q]:mg["off"][q] + cnt.c_nze]
-            parts.append(eng.numeric_after_symbolic(alpha, self.A_panel, self._Bc[q], beta, self._Cc[q], row_p, cnt, self.dtype, **kw))
+            with torch.cuda.stream(side if (side is not None and q % 2 == 1) else main) if main is not None else contextlib.nullcontext():
+                self._arrived(*posted[q])
+                parts.append(eng.numeric_after_symbolic(alpha, self.A_panel, self._Bc[q], beta, self._Cc[q], row_p, cnt, self.dtype, **kw))
             flop += cnt.flop
             nprod += cnt.nproducts
             self.last_tick_flop = cnt.flop
+        if side is not None:
+            main.wait_stream(side)
+            for Cq in parts[1::2]:   # made on the second stream, used by the caller on the first
+                for t in (Cq.col_i, Cq.blk_p, Cq.data):
+                    if t.numel():
+                        t.record_stream(main)
         counts = sym[0][1]
         counts.flop, counts.nproducts = flop, nprod
         counts.c_nblks, counts.c_nze = sum(int(x[1].c_nblks) for x in sym), sum(int(x[1].c_nze) for x in sym)
