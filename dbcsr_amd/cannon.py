@@ -659,8 +659,8 @@ class CannonMultiply:
                 self._side_stream = torch.cuda.Stream(device=self.device)
             side = self._side_stream
             side.wait_stream(main)   # the symbolic phases' results, and whatever used the output buffer's memory before
-            if out_all is not None:
-                out_all.record_stream(side)
+            # (no record_stream on the output buffer: the first stream waits for the second below, before anybody can free it --
+            #  and a recorded buffer of several GB is not reusable by the next step's allocation, which then goes to hipMalloc)
         for q in range(nch):
             row_p, cnt = sym[q]
             eng = self.last_engine = engines[q]
@@ -675,8 +675,8 @@ class CannonMultiply:
             self.last_tick_flop = cnt.flop
         if side is not None:
             main.wait_stream(side)
-            for Cq in parts[1::2]:   # made on the second stream, used by the caller on the first
-                for t in (Cq.col_i, Cq.blk_p, Cq.data):
+            for Cq in parts[1::2]:   # index arrays made on the second stream, used by the caller on the first
+                for t in (Cq.col_i, Cq.blk_p):
                     if t.numel():
                         t.record_stream(main)
         counts = sym[0][1]
