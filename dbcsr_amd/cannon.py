@@ -675,8 +675,8 @@ class CannonMultiply:
             self.last_tick_flop = cnt.flop
         if side is not None:
             main.wait_stream(side)
-            for Cq in parts[1::2]:   # index arrays made on the second stream, used by the caller on the first
-                for t in (Cq.col_i, Cq.blk_p):
+            for Cq in parts[1::2]:   # made on the second stream, used by the caller on the first
+                for t in (Cq.col_i, Cq.blk_p) + ((Cq.data,) if out_all is None else ()):   # (data: own allocations in a plan's first multiply only)
                     if t.numel():
                         t.record_stream(main)
         counts = sym[0][1]
@@ -688,7 +688,7 @@ class CannonMultiply:
         """The column chunks of C as ONE matrix of the local tile.  The patterns of a plan never change, so the merged index is made
         once; from the second multiply on the chunks were written straight into their slices of one buffer (no copy)."""
         if self._merged is None:
-            rows_l, cols_l, off_l, chunk_l, base = [], [], [], [], 0
+            rows_l, cols_l, off_l, base = [], [], [], 0
             offs = []
             for q, Cq in enumerate(parts):
                 rs, cs, row_p, col_i, blk_p, _ = DbcsrMatrix(Cq.row_blk_size, Cq.col_blk_size, Cq.row_p, Cq.col_i, Cq.blk_p, Cq.row_p[:0]).to_host()
