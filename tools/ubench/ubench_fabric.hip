@@ -98,6 +98,23 @@ __global__ void __launch_bounds__(256) stream_read(const u32x4* __restrict__ p, 
   if (acc == 0x12345u) sink[0] = acc;
 }
 
+// the same read by the workgroups of SOME XCDs only (workgroup b runs on XCD b % 8; the others leave at once): is the L2 <-> fabric
+// ceiling a sum of per-XCD limits or one shared limit?
+__global__ void __launch_bounds__(256) stream_read_xcds(const u32x4* __restrict__ p, size_t n16, int reps, unsigned xcd_mask, int nactive,
+                                                        double* __restrict__ sink) {
+  const unsigned xcd = blockIdx.x & 7u;
+  if (!((xcd_mask >> xcd) & 1u)) return;
+  const unsigned rank = __popc(xcd_mask & ((1u << xcd) - 1u));          // position of this XCD among the active ones
+  const size_t wg = (size_t)(blockIdx.x >> 3) * nactive + rank, nwg = (size_t)(gridDim.x >> 3) * nactive;
+  unsigned acc = 0;
+  for (int r = 0; r < reps; ++r)
+    for (size_t i = wg * 256 + threadIdx.x; i < n16; i += nwg * 256) {
+      const u32x4 v = p[i];
+      acc += v[0] ^ v[1] ^ v[2] ^ v[3];
+    }
+  if (acc == 0x12345u) sink[0] = acc;
+}
+
 // C-block write pattern: wave w writes block w (4232 B payload) at w * stride, in 1 KiB pieces of 16 B per lane
 template <int AUX>
 __global__ void __launch_bounds__(256) write_blocks(char* __restrict__ c, size_t nblk, int stride) {
@@ -206,6 +223,21 @@ int main(int argc, char** argv) {
       const float ms = timed(l, &sc);
       printf("%8.0f  %8.3f  %8.0f\n", w, ms, (double)n16 * 16 * reps / ms * 1e-6);
     }
+  }
+  if (want(argc, argv, "xcds")) {
+    printf("# [xcds] plain streaming read of a 1 GB window (Infinity Cache / HBM) and of 128 MB (Infinity Cache), 16 B per lane, by the workgroups of some XCDs only\n");
+    printf("# window_MB  active XCDs (mask)  ms  GB/s  GB/s per active XCD\n");
+    for (double w : {128.0, 1024.0})
+      for (unsigned mask : {0xffu, 0x0fu, 0x55u, 0x03u, 0x01u}) {
+        const size_t n16 = (size_t)(w * 1048576.0) / 16;
+        const int reps = w < 1024 ? 16 : 2;
+        const int na = __builtin_popcount(mask);
+        struct SC { const u32x4* p; size_t n; int reps; unsigned mask; int na; double* sink; } sc{(const u32x4*)b, n16, reps, mask, na, sink};
+        auto l = [](void* q) { SC* s = (SC*)q; hipLaunchKernelGGL(stream_read_xcds, dim3(2048), dim3(256), 0, 0, s->p, s->n, s->reps, s->mask, s->na, s->sink); };
+        const float ms = timed(l, &sc);
+        const double gbs = (double)n16 * 16 * reps / ms * 1e-6;
+        printf("%8.0f  %d (0x%02x)  %8.3f  %8.0f  %8.0f\n", w, na, mask, ms, gbs, gbs / na);
+      }
   }
   if (want(argc, argv, "write")) {
     printf("# [write] C-block write pattern of config 4: 14.3 M blocks of 4232 B, wave w -> block w\n# layout  aux  ms  GB/s(payload)\n");
