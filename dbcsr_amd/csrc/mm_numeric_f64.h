@@ -393,6 +393,10 @@ __global__ void __launch_bounds__(256) mm_numeric_f64_hot(const Desc* __restrict
   first.a_lo = w.a_lo, first.b_lo = w.b_lo, first.w = w.w;
   if ((dbg & 32) && d.prod_cnt == 0) return;
   if ((dbg & 64) && d.m == M && d.n == N) return;  // the tile kernel (mm_tile.h) computed the blocks of the dominant size
+  // profiling variant only: bits 8-15 of DBCSR_AMD_MM_DBG switch whole XCDs off (their C blocks are simply not computed): how fast is an
+  // XCD whose neighbours leave the fabric alone?
+  if constexpr (VAR == 1)
+    if ((dbg >> 8) & 0xff & (1 << (blockIdx.x & 7))) return;
   char* lds_a = smem + (size_t)wid * lds_wave_doubles * 8;
   char* lds_b = lds_a + (size_t)lds_a_doubles * 8;
   const LaneMap L(lane);
