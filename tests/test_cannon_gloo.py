@@ -71,7 +71,7 @@ def test_cannon_matches_global_oracle(world, mode):
 
 
 @pytest.mark.parametrize("world,mode,retain,eps", [(4, "gather", False, 60.0), (6, "ticks", False, 80.0), (4, "ticks+dist", True, None),
-                                                  (2, "gather", True, 60.0)])
+                                                  (2, "gather", True, 60.0), (3, "colpipe", False, 60.0), (2, "colpipe+dist", True, None)])
 def test_cannon_filter_and_retain_match_global_oracle(world, mode, retain, eps):
     """filter_eps / retain_sparsity on several ranks: every rank takes the decisions one rank would (row counts of the WHOLE block
     row enter the on-the-fly filter, dbcsr_mm_cannon.F:1040-1113), block structure and values equal the single-rank oracle's."""
