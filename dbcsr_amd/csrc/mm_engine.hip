@@ -264,6 +264,9 @@ struct Engine {
   bool work_built = false, tile_built = false;
   TileGeom tile_geom = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   long long plan_hits = 0, plan_misses = 0;
+  int hot_persistent = 0;  // DBCSR_AMD_MM_HOT_PERSISTENT=1: the 23^3 kernel as persistent waves with a work counter per XCD (mm_numeric_f64.h)
+  unsigned hot_xcd_mask = 0xffu;  // DBCSR_AMD_MM_HOT_XCDS: XCDs the persistent form runs on (experiments: the others' C blocks are NOT computed)
+  DevBuf<unsigned> hot_counters;
   int hot_variant = 0;  // DBCSR_AMD_MM_HOT_VARIANT: 2 = exact-size kernel with unpaired ds_read_b64 fragment reads (23^3 only)
   int use_pipe = -1, pipe_g = 8;  // multi-block pipelined kernel: -1 automatic (short product lists only), DBCSR_AMD_MM_KERNEL=pipe|lds1 forces; DBCSR_AMD_MM_PIPE_G = blocks per wave
   // (m, n) classes (mixed block sizes, see order_count_cls): DBCSR_AMD_MM_CLASSES = 0 never, 1 automatic, 2 always when the sizes allow
@@ -501,6 +504,8 @@ int dbcsr_amd_mm_create(void** handle) {
     return -1;
   if (const char* k = getenv("DBCSR_AMD_MM_DBG")) E->dbg = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_HOT_VARIANT")) E->hot_variant = atoi(k);
+  if (const char* k = getenv("DBCSR_AMD_MM_HOT_PERSISTENT")) E->hot_persistent = atoi(k);
+  if (const char* k = getenv("DBCSR_AMD_MM_HOT_XCDS")) E->hot_xcd_mask = (unsigned)strtoul(k, nullptr, 0) & 0xffu;
   if (const char* k = getenv("DBCSR_AMD_MM_PLAN")) E->use_plan = atoi(k);
   if (hipHostMalloc(reinterpret_cast<void**>(&E->plan_host_flag), sizeof(int), hipHostMallocDefault) != hipSuccess) return -1;
   if (const char* k = getenv("DBCSR_AMD_MM_TILE")) E->use_tile = atoi(k);
@@ -551,6 +556,7 @@ int dbcsr_amd_mm_destroy(void* handle) {
   E->order.release(); E->order_cnt.release(); E->order_base.release();
   E->stat_table.release();
   E->norms64.release(); E->a_norms.release(); E->b_norms.release(); E->keep.release();
+  E->hot_counters.release();
   E->a_bm.release(); E->bt_bm.release(); E->tile_prog.release(); E->a_pre.release(); E->tile_rows.release(); E->tile_cols.release();
   E->tile_cnt.release(); E->tile_flags.release(); E->tile_start.release(); E->tdescs.release(); E->tentries.release();
   if (E->host_scalars) (void)hipHostFree(E->host_scalars);
@@ -1069,6 +1075,28 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
                          static_cast<const double*>(a->data), static_cast<const double*>(b->data), static_cast<double*>(c_out->data),
                          static_cast<const double*>(c_in->data), alpha, beta, skip_empty, E->order.p)) {
         snprintf(E->last_kernel, sizeof E->last_kernel, "mm_numeric_f64_dma<%d,%d,%d,%d>", E->hot_m, E->hot_n, E->hot_k, E->dma_stages);
+      } else if (E->hot_persistent && E->use_hot && E->use_pipe != 1 && E->hot_m == 23 && E->hot_n == 23 && E->hot_k == 23 && hot_work &&
+                 !(E->dbg & ~32) && E->hot_counters.ensure(8) == 0) {
+        // persistent waves, one counter per XCD (an experiment: see the kernel); 16 one-wave workgroups per CU is what the LDS slice allows
+        static int n_cu_p = 0;
+        if (n_cu_p == 0) {
+          int dev = 0;
+          ACC_CHECK(hipGetDevice(&dev));
+          ACC_CHECK(hipDeviceGetAttribute(&n_cu_p, hipDeviceAttributeMultiprocessorCount, dev));
+        }
+        const int per_cu = std::max(1, (int)((160 * 1024) / ((size_t)lds_wave * sizeof(double) + (size_t)E->lds_pad)));
+        ACC_CHECK(hipMemsetAsync(E->hot_counters.p, 0, 8 * sizeof(unsigned), st));
+        hipLaunchKernelGGL((mm_numeric_f64_hot_persistent<23, 23, 23>), dim3((unsigned)(n_cu_p * per_cu)), dim3(64),
+                           (size_t)lds_wave * sizeof(double) + (size_t)E->lds_pad, st, E->entries.p, static_cast<const double*>(a->data),
+                           static_cast<const double*>(b->data), static_cast<double*>(c_out->data), static_cast<const double*>(c_in->data), alpha, beta,
+                           lds_a, skip_empty ? 32 : 0, hot_work, (long)E->order_len, E->hot_counters.p, E->hot_xcd_mask, epi_norms);
+        if (epi_norms) {
+          hipLaunchKernelGGL(block_norms_other_sizes, grid_for(nblk * 64), dim3(256), 0, st, E->descs.p, nblk, static_cast<const double*>(c_out->data),
+                             E->hot_m, E->hot_n, epi_norms);
+          E->norms_data = c_out->data;
+          E->norms_nblks = nblk;
+        }
+        snprintf(E->last_kernel, sizeof E->last_kernel, "mm_numeric_f64_hot_persistent<%d,%d,%d>", E->hot_m, E->hot_n, E->hot_k);
       } else if (E->use_hot && E->use_pipe != 1 && E->hot_m > 0 &&
           launch_hot_f64(E->hot_m, E->hot_n, E->hot_k, dim3((unsigned)(8 * E->order_len / ww)),
                          (size_t)ww * lds_wave * sizeof(double) + (size_t)E->lds_pad, st, E->descs.p, nblk, E->entries.p,

@@ -409,6 +409,67 @@ __global__ void __launch_bounds__(256) mm_numeric_f64_hot(const Desc* __restrict
   cblock_f64<4, 4>(d, entries, a_data, b_data, c_out, c_in, alpha, beta, L, 0, 0);
 }
 
+// PERSISTENT form of the kernel above (DBCSR_AMD_MM_HOT_PERSISTENT=1; an experiment, and the groundwork of a launch that leaves some
+// XCDs to another kernel): as many one-wave workgroups as the chip holds at once; the waves of XCD x take the positions of
+// x's stream of the launch order one after the other from a counter of their own (an L2 atomic inside the XCD), so the frontier of
+// the stream stays as compact as under the hardware dispatcher -- unlike a static share of positions per wave, which drifts apart
+// (section 7, "STREAM kernel").  XCDs outside `xcd_mask` leave at once and their streams stay untouched.
+template <int M, int N, int K>
+__global__ void __launch_bounds__(64) mm_numeric_f64_hot_persistent(const Entry* __restrict__ entries, const double* __restrict__ a_data,
+                                                                    const double* __restrict__ b_data, double* __restrict__ c_out,
+                                                                    const double* __restrict__ c_in, double alpha, double beta, int lds_a_doubles,
+                                                                    int dbg, const Work* __restrict__ work, long stream_len,
+                                                                    unsigned* __restrict__ counters, unsigned xcd_mask, double* __restrict__ norms) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const unsigned xcd = blockIdx.x & 7u;
+  if (!((xcd_mask >> xcd) & 1u)) return;
+  char* lds_a = smem;
+  char* lds_b = lds_a + (size_t)lds_a_doubles * 8;
+  const LaneMap L(lane);
+  const Work* stream = work + (long)xcd * stream_len;
+  // Positions are taken in CHUNKS of G consecutive ones (one atomic per chunk: 254 k atomics on one address per XCD and multiply were
+  // the bottleneck themselves -- 27.4 ms against 18.7 --, and so were they with their latency hidden), the counter is asked for
+  // the next chunk while this one is worked on, and the record of the next position is on its way while a block is computed.  A
+  // position past the end reads the last record of the stream again and is never used.
+  constexpr unsigned G = 8;
+  auto take = [&]() {
+    unsigned v = 0;
+    if (lane == 0) v = atomicAdd(&counters[xcd], G);
+    return v;  // (lane 0's value; made uniform where it is first needed)
+  };
+  unsigned base = (unsigned)__builtin_amdgcn_readfirstlane((int)take());
+  unsigned next_base_raw = take();
+  unsigned off = 0;
+  auto next_pos = [&]() {
+    const unsigned pos = base + off;
+    if (++off == G) {
+      base = (unsigned)__builtin_amdgcn_readfirstlane((int)next_base_raw);
+      next_base_raw = take();
+      off = 0;
+    }
+    return pos;
+  };
+  unsigned p_cur = next_pos();
+  Work w_cur = stream[(long)p_cur < stream_len ? (long)p_cur : stream_len - 1];
+  while ((long)p_cur < stream_len) {
+    const unsigned p_nxt = next_pos();
+    const Work w_nxt = stream[(long)p_nxt < stream_len ? (long)p_nxt : stream_len - 1];
+    const Work w = w_cur;
+    if (w.prod_cnt >= 0 && !((dbg & 32) && w.prod_cnt == 0)) {
+      const Desc d = {w.c_off, w.cin_off, w.prod_start, w.prod_cnt, w.m, w.n};
+      Entry first;
+      first.a_lo = w.a_lo, first.b_lo = w.b_lo, first.w = w.w;
+      if (d.m == M && d.n == N)
+        cblock_f64_exact<M, N, K, 0>(d, first, entries, a_data, b_data, c_out, c_in, alpha, beta, L, lane, lds_a, lds_b, 0, norms ? norms + w.cb : nullptr);
+      else
+        cblock_f64<4, 4>(d, entries, a_data, b_data, c_out, c_in, alpha, beta, L, 0, 0);
+    }
+    p_cur = p_nxt;
+    w_cur = w_nxt;
+  }
+}
+
 // all block dimensions of the launch are <= 8*MAXT (<= 32); lds_wave_doubles = per-wave LDS slice (A part then B part).
 // MAXT bounds the register allocation to what the largest block class present needs.
 template <int MAXT>

@@ -32,6 +32,8 @@ VARIANTS = [
     ({"DBCSR_AMD_MM_HOT_VARIANT": "2"}, H2O, "mm_numeric_f64_hot<23,23,23>"),
     ({"DBCSR_AMD_MM_HOT_VARIANT": "3"}, H2O, "mm_numeric_f64_hot<23,23,23>"),
     ({"DBCSR_AMD_MM_HOT_VARIANT": "4"}, H2O, "mm_numeric_f64_hot<23,23,23>"),
+    # the same kernel as persistent waves with a work counter per XCD
+    ({"DBCSR_AMD_MM_HOT_PERSISTENT": "1"}, H2O, "mm_numeric_f64_hot_persistent<23,23,23>"),
     ({"DBCSR_AMD_MM_HOT": "0", "DBCSR_AMD_MM_KERNEL": "lds1"}, H2O, "mm_numeric_f64_lds<3>"),
     ({"DBCSR_AMD_MM_KERNEL": "pipe"}, H2O, "mm_numeric_f64_pipe<3>"),
     ({"DBCSR_AMD_MM_KERNEL": "dma2"}, H2O, "mm_numeric_f64_dma<23,23,23,2>"),
@@ -82,7 +84,7 @@ VARIANTS = [
 
 
 def run_case(monkeypatch, env, case, dtype, tol, expect, alpha=0.7, beta=1.3, retain=False, in_place_twice=False):
-    for k in ("DBCSR_AMD_MM_KERNEL", "DBCSR_AMD_MM_HOT", "DBCSR_AMD_MM_TINY", "DBCSR_AMD_MM_PIPE_G", "DBCSR_AMD_MM_SYMBOLIC", "DBCSR_AMD_MM_CLASSES", "DBCSR_AMD_MM_CLASS_G", "DBCSR_AMD_MM_WORK", "DBCSR_AMD_MM_WG_WAVES", "DBCSR_AMD_MM_CLASS_STREAMS", "DBCSR_AMD_MM_HOT_VARIANT"):
+    for k in ("DBCSR_AMD_MM_KERNEL", "DBCSR_AMD_MM_HOT", "DBCSR_AMD_MM_TINY", "DBCSR_AMD_MM_PIPE_G", "DBCSR_AMD_MM_SYMBOLIC", "DBCSR_AMD_MM_CLASSES", "DBCSR_AMD_MM_CLASS_G", "DBCSR_AMD_MM_WORK", "DBCSR_AMD_MM_WG_WAVES", "DBCSR_AMD_MM_CLASS_STREAMS", "DBCSR_AMD_MM_HOT_VARIANT", "DBCSR_AMD_MM_HOT_PERSISTENT", "DBCSR_AMD_MM_HOT_XCDS"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
