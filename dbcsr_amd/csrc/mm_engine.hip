@@ -1076,7 +1076,7 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
                          static_cast<const double*>(c_in->data), alpha, beta, skip_empty, E->order.p)) {
         snprintf(E->last_kernel, sizeof E->last_kernel, "mm_numeric_f64_dma<%d,%d,%d,%d>", E->hot_m, E->hot_n, E->hot_k, E->dma_stages);
       } else if (E->hot_persistent && E->use_hot && E->use_pipe != 1 && E->hot_m == 23 && E->hot_n == 23 && E->hot_k == 23 && hot_work &&
-                 !(E->dbg & ~32) && E->hot_counters.ensure(8) == 0) {
+                 !(E->dbg & ~32) && E->hot_counters.ensure(8 * 32) == 0) {
         // persistent waves, one counter per XCD (an experiment: see the kernel); 16 one-wave workgroups per CU is what the LDS slice allows
         static int n_cu_p = 0;
         if (n_cu_p == 0) {
@@ -1085,7 +1085,7 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
           ACC_CHECK(hipDeviceGetAttribute(&n_cu_p, hipDeviceAttributeMultiprocessorCount, dev));
         }
         const int per_cu = std::max(1, (int)((160 * 1024) / ((size_t)lds_wave * sizeof(double) + (size_t)E->lds_pad)));
-        ACC_CHECK(hipMemsetAsync(E->hot_counters.p, 0, 8 * sizeof(unsigned), st));
+        ACC_CHECK(hipMemsetAsync(E->hot_counters.p, 0, 8 * 32 * sizeof(unsigned), st));
         hipLaunchKernelGGL((mm_numeric_f64_hot_persistent<23, 23, 23>), dim3((unsigned)(n_cu_p * per_cu)), dim3(64),
                            (size_t)lds_wave * sizeof(double) + (size_t)E->lds_pad, st, E->entries.p, static_cast<const double*>(a->data),
                            static_cast<const double*>(b->data), static_cast<double*>(c_out->data), static_cast<const double*>(c_in->data), alpha, beta,

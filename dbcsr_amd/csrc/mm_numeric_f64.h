@@ -177,11 +177,16 @@ typedef const volatile double __attribute__((address_space(3))) lds_vd;  // vola
 // 2 = production with the fragment reads kept as single ds_read_b64 (the compiler pairs them into ds_read2_b64 otherwise),
 // 3 / 4 = production + every product also touches one dword per cache line of the one / two A blocks stored before its own (the block
 // row's neighbours): an A block is then referenced two / three times as often, against its eviction by the B stream
-template <int M, int N, int K, int VAR>
+struct NoHook {
+  __device__ __forceinline__ void operator()() const {}
+};
+// before_epilogue: called once, after the last product and before the C block is written (the persistent form of the kernel asks for
+// its next position there: the round trip then runs under the epilogue)
+template <int M, int N, int K, int VAR, class Hook = NoHook>
 __device__ __forceinline__ void cblock_f64_exact(const Desc& d, const Entry first, const Entry* __restrict__ entries, const double* __restrict__ a_data,
                                                  const double* __restrict__ b_data, double* __restrict__ c_out,
                                                  const double* __restrict__ c_in, double alpha, double beta, const LaneMap& L, int lane,
-                                                 char* lds_a, char* lds_b, int dbg_rt, double* __restrict__ norm_out) {
+                                                 char* lds_a, char* lds_b, int dbg_rt, double* __restrict__ norm_out, Hook before_epilogue = Hook()) {
   const int dbg = VAR == 1 ? dbg_rt : 0;
   constexpr int MA = (M + 7) / 8, NC = (N + 7) / 8, KS = (K + 3) / 4, K4 = 4 * KS;
   constexpr int CA = (M * K4 * 8 + 1023) / 1024, CB = (K * N * 8 + 1023) / 1024;
@@ -297,6 +302,7 @@ __device__ __forceinline__ void cblock_f64_exact(const Desc& d, const Entry firs
     if (ep.ks() != K) block_product_f64<MA, NC, false>(acc, a_data + ep.a_off(), b_data + ep.b_off(), M, N, ep.ks(), L);
   }
   if constexpr (VAR == 3 || VAR == 4) asm volatile("" ::"v"(touch));  // the keep-alive loads are loads the compiler must keep
+  before_epilogue();
   const bool has_in = d.cin_off >= 0;
   if (dbg & 8) {  // scattered 8-byte stores straight from the accumulators (the first version; kept for comparison)
     double* C = c_out + d.c_off;
@@ -428,45 +434,38 @@ __global__ void __launch_bounds__(64) mm_numeric_f64_hot_persistent(const Entry*
   char* lds_b = lds_a + (size_t)lds_a_doubles * 8;
   const LaneMap L(lane);
   const Work* stream = work + (long)xcd * stream_len;
-  // Positions are taken in CHUNKS of G consecutive ones (one atomic per chunk: 254 k atomics on one address per XCD and multiply were
-  // the bottleneck themselves -- 27.4 ms against 18.7 --, and so were they with their latency hidden), the counter is asked for
-  // the next chunk while this one is worked on, and the record of the next position is on its way while a block is computed.  A
-  // position past the end reads the last record of the stream again and is never used.
-  constexpr unsigned G = 8;
+  // ONE position per request and nothing taken ahead: what is in flight on the XCD must stay a window of ~512 consecutive positions
+  // (1.2 block rows of A: its L2 share), as under the hardware dispatcher.  Measured on config 2 (profiles/r03_hot_persistent.txt):
+  // positions taken two ahead or in chunks of eight widen the window to several block rows -- 230 GB over the fabric instead of 145,
+  // L2 hit rate 0.16 instead of 0.47, 29-31 ms; one request per block with its round trip, the record and the first operands all
+  // in a row between two blocks: 27 ms.  So the request goes out right before the C block is written and returns under the epilogue.
+  // The counter of an XCD has a cache line of its own and is incremented with WORKGROUP scope: the atomic is then carried out in this
+  // XCD's L2 -- every wave that uses it runs on this XCD -- instead of going out to memory as a device-scope atomic does (eight
+  // counters in one line, device scope: 2 M fabric round trips serialised on one line, 27 ms whatever else was hidden).
   auto take = [&]() {
     unsigned v = 0;
-    if (lane == 0) v = atomicAdd(&counters[xcd], G);
-    return v;  // (lane 0's value; made uniform where it is first needed)
+    if (lane == 0) v = __hip_atomic_fetch_add(&counters[32 * xcd], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return v;  // (lane 0's value; made uniform where it is used)
   };
-  unsigned base = (unsigned)__builtin_amdgcn_readfirstlane((int)take());
-  unsigned next_base_raw = take();
-  unsigned off = 0;
-  auto next_pos = [&]() {
-    const unsigned pos = base + off;
-    if (++off == G) {
-      base = (unsigned)__builtin_amdgcn_readfirstlane((int)next_base_raw);
-      next_base_raw = take();
-      off = 0;
-    }
-    return pos;
-  };
-  unsigned p_cur = next_pos();
-  Work w_cur = stream[(long)p_cur < stream_len ? (long)p_cur : stream_len - 1];
-  while ((long)p_cur < stream_len) {
-    const unsigned p_nxt = next_pos();
-    const Work w_nxt = stream[(long)p_nxt < stream_len ? (long)p_nxt : stream_len - 1];
-    const Work w = w_cur;
-    if (w.prod_cnt >= 0 && !((dbg & 32) && w.prod_cnt == 0)) {
+  unsigned pos = (unsigned)__builtin_amdgcn_readfirstlane((int)take());
+  while ((long)pos < stream_len) {
+    const Work w = stream[pos];
+    unsigned next_raw = 0;
+    if (w.prod_cnt >= 0 && !((dbg & 32) && w.prod_cnt == 0) && w.m == M && w.n == N) {
       const Desc d = {w.c_off, w.cin_off, w.prod_start, w.prod_cnt, w.m, w.n};
       Entry first;
       first.a_lo = w.a_lo, first.b_lo = w.b_lo, first.w = w.w;
-      if (d.m == M && d.n == N)
-        cblock_f64_exact<M, N, K, 0>(d, first, entries, a_data, b_data, c_out, c_in, alpha, beta, L, lane, lds_a, lds_b, 0, norms ? norms + w.cb : nullptr);
-      else
+      auto hook = [&]() { next_raw = take(); };
+      cblock_f64_exact<M, N, K, 0, decltype(hook)>(d, first, entries, a_data, b_data, c_out, c_in, alpha, beta, L, lane, lds_a, lds_b, 0,
+                                                   norms ? norms + w.cb : nullptr, hook);
+    } else {
+      next_raw = take();
+      if (w.prod_cnt >= 0 && !((dbg & 32) && w.prod_cnt == 0)) {
+        const Desc d = {w.c_off, w.cin_off, w.prod_start, w.prod_cnt, w.m, w.n};
         cblock_f64<4, 4>(d, entries, a_data, b_data, c_out, c_in, alpha, beta, L, 0, 0);
+      }
     }
-    p_cur = p_nxt;
-    w_cur = w_nxt;
+    pos = (unsigned)__builtin_amdgcn_readfirstlane((int)next_raw);
   }
 }
 
