@@ -19,7 +19,7 @@ metadata never travels (every rank derives all image indices from the replicated
 block pattern), only block data does; C's structure for all ticks is computed
 once on the GPU and the ticks accumulate in place.
 
-Two schedules are offered:
+Three schedules are offered:
   * ``mode="gather"`` (default): every rank posts ONE batch that fetches all the images it does not own
     -- all peers, hence all xGMI links, at the same time -- while the GPU already runs the symbolic phase
     (which needs index metadata only); then one device-resident multiply over the full row/column panels.
@@ -27,6 +27,11 @@ Two schedules are offered:
     instead of one per tick.
   * ``mode="ticks"``: the reference's tick-by-tick pipeline (one A and one B image per tick, next tick's
     images in flight during the current tick's multiply, in-place accumulation into C).
+  * ``mode="colpipe"`` (chosen at construction; an ``N x 1`` grid): A's block rows and C's stay where they are, B --
+    one k-image per rank, stored column chunk by column chunk -- travels from every owner to everybody in column
+    chunks, and chunk q of C is multiplied as soon as chunk q of B is complete while chunk q + 1 is on the links.
+    Every C block is written once (the chunks land in slices of one buffer under a merged index), the exposed
+    transfer is one chunk of one image per link, and odd chunks are multiplied on a second stream.
 
 The local engine is duck-typed (``symbolic``, ``init_c``, ``accumulate``,
 ``fill_random_dist`` of dbcsr_amd.multiply.MultiplyEngine) so that the
