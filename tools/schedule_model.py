@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""What the multi-GPU schedules of dbcsr_amd/cannon.py should cost per step, from numbers measured on ONE GPU and an
+assumed xGMI rate -- the model behind the scaling estimates, written down so that the first run on a multi-GPU node can be held against
+it line by line.
+
+Inputs per workload: bytes of A and B, the per-rank compute path measured with tools/rank_step_budget.py (gather schedule's one
+multiply; colpipe's chunk multiplies), the one-GPU step.  Every image travels over its own link (owner-direct exchange).
+   python tools/schedule_model.py [--link-gbs 50,64,76]"""
+import argparse
+
+# measured on one MI355X (profiles/r03_rank_step_budget_*.txt, r03_final_bench_line.json); ms
+WORKLOADS = {
+    "config2_32768_23x23_fill10_fp64": dict(
+        one_gpu=18.85, a_gb=0.859, b_gb=0.859, c_gb_per_rank={2: 4.3, 4: 2.15, 8: 1.07},
+        gather={2: 9.59, 4: 4.90, 8: 2.64},          # rank 0's whole multiply, default grid (2x1, 2x2, 4x2)
+        colpipe8={2: 10.28, 4: 5.38, 8: 2.94}),      # N x 1 grid, eight column chunks on two streams, panels in place
+    "config4_131072_23x23_fill1_fp64": dict(
+        one_gpu=22.74, a_gb=1.374, b_gb=1.374, c_gb_per_rank={2: 30.3, 4: 15.2, 8: 7.6},
+        gather={2: 11.22, 4: 5.73, 8: 3.04},
+        colpipe8={2: 11.39, 4: 5.84, 8: None}),      # (8 ranks: not measured cleanly, see profiles/r03_rank_step_budget_colpipe.txt)
+}
+GRID = {2: (2, 1), 4: (2, 2), 8: (4, 2)}
+HBM_TBS = 5.0   # read + write of C in an in-place pass
+
+
+def model(w, n, link):
+    pr, pc = GRID[n]
+    nvirt = pr * pc // __import__("math").gcd(pr, pc)
+    a_img, b_img = w["a_gb"] / (pr * nvirt), w["b_gb"] / (pc * nvirt)       # GB per image
+    per_link = max(a_img if pc > 1 else 0.0, b_img if pr > 1 else 0.0) * (nvirt / max(pr, pc))   # images a rank gets from ONE peer
+    t_link = per_link / link * 1e3                                          # ms: all links run at once
+    k = w["gather"][n]
+    local = 1.0 / nvirt if nvirt > 1 else 1.0                               # share of the multiply that needs no transfer (local-first)
+    c_pass = 2 * w["c_gb_per_rank"][n] / HBM_TBS                            # ms: one more pass over C
+    out = {"gather": t_link + k,
+           "gather/local-first": max(t_link, local * k) + (1 - local) * k + c_pass,
+           "ticks": t_link / nvirt + nvirt * max(k / nvirt + c_pass, t_link / nvirt) - (0 if nvirt > 1 else c_pass)}
+    cp = w["colpipe8"][n]
+    if cp is not None:
+        b_per_link = w["b_gb"] / n                                          # N x 1 grid: one k-image per rank, every image on its own link
+        t_chunk = b_per_link / 8 / link * 1e3
+        out["colpipe (8 chunks)"] = t_chunk + max(cp, 8 * t_chunk)
+    return out
+
+
+def main():
+    p = argparse.ArgumentParser()
+    p.add_argument("--link-gbs", default="50,64,76", help="GB/s per direction and link that RCCL send/recv reaches (assumptions)")
+    a = p.parse_args()
+    for name, w in WORKLOADS.items():
+        print("# %s: %.2f ms on one GPU" % (name, w["one_gpu"]))
+        for link in [float(x) for x in a.link_gbs.split(",")]:
+            print("#   link %.0f GB/s:  ranks  schedule -> ms per step (speed-up over one GPU)" % link)
+            for n in (2, 4, 8):
+                m = model(w, n, link)
+                best = min(m, key=m.get)
+                print("      %d  " % n + "   ".join("%s %.2f (%.1fx)%s" % (k, v, w["one_gpu"] / v, " *" if k == best else "") for k, v in m.items()))
+
+
+if __name__ == "__main__":
+    main()
