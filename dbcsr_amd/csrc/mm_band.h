@@ -1,0 +1,97 @@
+// mm_band.h -- CU-wide C tiles with the B operand shared in LDS: the third dataflow of the fp64 block-product engine.
+//
+// Why.  The one-wave-per-C-block kernel (mm_numeric_f64.h) stages one A and one B block per block product: at BASELINE config 2
+// that is 145 GB over the L2 <-> Infinity-Cache fabric (one B block per product: the fabric's ceiling) AND 2 x 4232 bytes
+// of ds_write_b128 per product next to the fragment reads -- the LDS pipe is as busy as the matrix pipe.  The XCD-wide tile
+// dataflow (mm_tile.h) cut the fabric bytes but not the LDS bytes, and paid for a 256-wave k window.  Here the unit that shares is
+// the CU, and what it shares lives in LDS:
+//   * a workgroup (8 waves = one CU, two waves per SIMD, persistent) owns a tile of 24 block rows x 3 block columns of C; wave w
+//     owns rows 3w .. 3w+2 (a 3 x 3 sub-tile: 81 fp64 accumulators per lane, as in mm_tile.h);
+//   * the B blocks (k, j) of the tile's three columns -- needed by every wave that has an A block in inner block k, 2.4 of the 8
+//     waves on average at 10 % fill -- are fetched ONCE per CU into a shared ring of D slots in LDS: 0.38 B blocks per product
+//     cross the fabric instead of 1.0, and reach LDS once instead of once per product;
+//   * A blocks go to a private two-slot ring per wave (0.9 per product; a product that shares its A block with the previous one
+//     skips the copy) and come out of the XCD's L2: the 32 CUs of an XCD work on the SAME 24 block rows at about the same k, so an
+//     A block is used by 8.7 CUs while it is L2-resident.  Nothing synchronises the CUs with each other (no k window, no team):
+//     a CU that falls behind costs L2 hits, never waits;
+//   * the ring is a tiny cache with reference counts, one state word per slot in LDS: the first wave that needs B block n (its
+//     sequence number in the CU's k-sorted sweep) and finds slot n % D free claims it (compare-and-swap), copies the block by
+//     LDS-DMA and publishes it one product later, when its own in-order wait has covered the copy; every user decrements the count
+//     after its last product with the block.  A wave runs ahead of the slowest user of the ring by at most D blocks; its SIMD
+//     partner takes the matrix pipe meanwhile.  The sweep never stops at tile boundaries: a CU's tiles form ONE sequence, and a
+//     wave writes its nine C blocks and goes on while others still finish theirs.
+// Per product: 5 x 1.28 DMA pieces instead of 10 staging loads + 10 ds_write_b128; fragment reads as single ds_read_b64.
+// Index work (band_* kernels in mm_band_index.h): per (tile, wave) one k-sorted product list whose entries carry the B sequence
+// number, the number of users of that B block and the two flags (new A block / last use of the B block); integer work, bit-exact by
+// construction, checked against the per-block product counts.
+// Results never depend on where workgroups run or on how the waves interleave: only WHEN a block is in the ring does.
+#ifndef DBCSR_AMD_MM_BAND_H
+#define DBCSR_AMD_MM_BAND_H
+
+#include "dma_lds.h"
+
+namespace dbcsr_amd {
+
+constexpr int kBandWaves = 8;      // waves per workgroup = sub-tiles per tile (stacked along the rows)
+constexpr int kBandT = 3;          // a sub-tile is kBandT x kBandT C blocks
+constexpr int kBandRows = kBandWaves * kBandT;  // block rows of a tile
+constexpr int kBandSlots = kBandT * kBandT;
+
+// list entry, 16 bytes
+struct BandEntry {
+  uint32_t a_lo, b_lo;  // low 32 bits of the element offsets into the A / B data areas
+  uint32_t w;           // bits 0-3: accumulator slot (3 ti + tj); 4: the A block differs from the previous entry's (copy it); 5: last product
+                        // of this wave with the B block (release it); 6: not a product (end-of-tile marker); 7: end of tile: write the
+                        // sub-tile's C blocks after this entry; bits 8-15: k extent; 16-23 / 24-31: bits 32-39 of the A / B offset
+  uint32_t s;           // bits 0-23: sequence number of the B block in the CU's sweep; bits 24-27: waves that use the block
+};
+constexpr uint32_t kBandNewA = 16u, kBandLastB = 32u, kBandNop = 64u, kBandFlush = 128u;
+
+struct BandRem {  // a product whose inner block has another size than K: added to the finished C block afterwards
+  uint32_t a_lo, b_lo;
+  uint32_t w;  // bits 0-3 slot, 8-15 k extent, 16-23 / 24-31 high offset bits
+  uint32_t pad;
+};
+
+struct BandDesc {  // one sub-tile
+  int64_t c_off[kBandSlots];    // element offset in C_out data, -1: no C block in this slot
+  int64_t cin_off[kBandSlots];  // element offset in C_in data, -1: the block is new
+};
+
+struct BandGeom {
+  int nfr, nfc;     // block rows / columns of the dominant size
+  int nBR, nBC;     // tile grid: bands of 24 rows x triples of columns
+  int ntiles;       // nBR * nBC, band-major
+  int cu_per_xcd;   // workgroups per XCD (a workgroup b works for XCD b % 8)
+  int max_i;        // tiles per workgroup, at most
+  // XCD x sweeps the tiles [x * ntiles / 8, (x + 1) * ntiles / 8); its workgroup c takes every cu_per_xcd-th of them, starting at c
+  __host__ __device__ int64_t lo(int x) const { return (int64_t)x * ntiles / 8; }
+};
+
+struct BandArgs {
+  const BandDesc* descs;      // [8 * nBR][nBC]: sub-tile (8 band + w, ct)
+  const BandEntry* entries;
+  const int64_t* list_off;    // [(8 cu_per_xcd * 8) * max_i + 1]: lists in processing order (workgroup, wave, tile of the workgroup)
+  const double* a_data;
+  const double* b_data;
+  double* c_out;
+  const double* c_in;
+  double alpha, beta;
+  BandGeom G;
+  int* flags;                 // [0] spins that gave up (must be 0: results are wrong otherwise), [1] list mismatches (index kernels)
+  unsigned long long* times;  // knob bit 0: [0] total [1] waits for A [2] waits for B [3] multiplies [4] epilogues (10 ns), [5] waves, [6] claims at the last moment, [7] B waits counted
+  int knobs;                  // bit 0: timing
+};
+
+// block sizes the band kernels are built for (cubes)
+#define DBCSR_AMD_BAND_SIZES(X) X(23)
+
+// LDS bytes of a workgroup for ring depth D (0: no kernel for this size / depth)
+int band_lds_bytes(int m, int n, int k, int depth);
+// the persistent kernel (8 * cu_per_xcd workgroups of 8 waves); bpol: cache policy of the B copies (0 default, 1 nt); 0 = launched, 1 = no kernel
+int band_launch(int m, int n, int k, int depth, int bpol, unsigned nwg, hipStream_t st, const BandArgs& P);
+int band_launch_remainder(int m, int n, hipStream_t st, int64_t nsub, const BandDesc* descs, const int64_t* rem_start, const BandRem* rem,
+                          const double* a_data, const double* b_data, double* c_out, double alpha);
+
+}  // namespace dbcsr_amd
+#endif

@@ -44,6 +44,7 @@
 #include "mm_aux.h"
 #include "mm_dma.h"
 #include "mm_tile_index.h"
+#include "mm_band_index.h"
 namespace dbcsr_amd {
 
 // ---- plan reuse ------------------------------------------------------------------------------------------------------
@@ -261,8 +262,20 @@ struct Engine {
   DevBuf<int> plan_flag;
   int* plan_host_flag = nullptr;  // pinned
   dbcsr_amd_mm_counts plan_counts = {0, 0, 0, 0};
-  bool work_built = false, tile_built = false;
+  bool work_built = false, tile_built = false, band_built = false;
   TileGeom tile_geom = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  // CU-wide C tiles, B shared in an LDS ring (mm_band.h): DBCSR_AMD_MM_BAND = 0 never, 1 automatic, 2 whenever the sizes allow;
+  // DBCSR_AMD_MM_BAND_DEPTH = slots of the ring (12 | 16 | 20 | 22); DBCSR_AMD_MM_BAND_BPOL = 1: B copies with the nt hint;
+  // DBCSR_AMD_MM_BAND_KNOBS bit 0: where the waves' time goes (printed by dbcsr_amd_mm_band_stats)
+  int use_band = 0, band_depth = 20, band_bpol = 0, band_knobs = 0;
+  BandGeom band_geom = {0, 0, 0, 0, 0, 0, 0};
+  int64_t band_nlist = 0, band_nrem = 0;
+  DevBuf<BandDesc> band_descs_buf;
+  DevBuf<BandEntry> band_entries;
+  DevBuf<BandRem> band_rem;
+  DevBuf<int> band_cnt_list, band_cnt_b, band_cnt_rem, band_sub_cnt, band_flags;
+  DevBuf<int64_t> band_list_off, band_seq_off, band_rem_start;
+  DevBuf<unsigned long long> band_times;
   long long plan_hits = 0, plan_misses = 0;
   int hot_persistent = 0;  // DBCSR_AMD_MM_HOT_PERSISTENT=1: the 23^3 kernel as persistent waves with a work counter per XCD (mm_numeric_f64.h)
   unsigned hot_xcd_mask = 0xffu;  // DBCSR_AMD_MM_HOT_XCDS: XCDs the persistent form runs on (experiments: the others' C blocks are NOT computed)
@@ -468,6 +481,107 @@ static int run_tile_f64(Engine* E, hipStream_t st, const dbcsr_amd_bcsr* a, cons
   return check(hipGetLastError(), "run_tile_f64", __FILE__, __LINE__);
 }
 
+// The band dataflow (mm_band.h) for the C blocks of the dominant size: bitmaps of A and of B transposed, sub-tile descriptors, the
+// product lists in sweep order (count, scan, fill), the persistent kernel, the products with inner blocks of another size.  The
+// caller then runs the exact-size kernel over the C blocks of the other sizes.  descs[] and C_out's index are already filled.
+template <int S_>
+static int run_band_f64(Engine* E, hipStream_t st, const dbcsr_amd_bcsr* a, const dbcsr_amd_bcsr* b, const dbcsr_amd_bcsr* c_in,
+                        dbcsr_amd_bcsr* c_out, double alpha, double beta) {
+  const int nbr = a->nblkrows, nbk = a->nblkcols, nbc = b->nblkcols, W = E->W, Wk = (nbk + 31) / 32;
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    ACC_CHECK(hipGetDevice(&dev));
+    ACC_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+  }
+  if (band_lds_bytes(S_, S_, S_, E->band_depth) == 0) return 1;
+  BandGeom G;
+  G.nfr = E->hot_cnt_m;
+  G.nfc = E->hot_cnt_n;
+  if (G.nfr <= 0 || G.nfc <= 0) return 1;
+  G.nBR = (G.nfr + kBandRows - 1) / kBandRows;
+  G.nBC = (G.nfc + kBandT - 1) / kBandT;
+  if ((int64_t)G.nBR * G.nBC > 0x3fffffff) return 1;
+  G.ntiles = G.nBR * G.nBC;
+  G.cu_per_xcd = std::min(32, std::max(1, n_cu / 8));
+  G.max_i = 1;
+  for (int x = 0; x < 8; ++x) G.max_i = std::max(G.max_i, (int)((G.lo(x + 1) - G.lo(x) + G.cu_per_xcd - 1) / G.cu_per_xcd));
+  const int nwg = 8 * G.cu_per_xcd;
+  const int64_t nsub = (int64_t)kBandWaves * G.ntiles, npl = (int64_t)nwg * kBandWaves * G.max_i, nps = (int64_t)nwg * G.max_i;
+  const bool reuse = E->plan_hit && E->plan_numeric && E->band_built;
+  if (E->band_flags.ensure(4)) return -1;
+  ACC_CHECK(hipMemsetAsync(E->band_flags.p, 0, sizeof(int) * 4, st));
+  if (!reuse) {
+    E->band_built = false;
+    if (E->a_bm.ensure((size_t)nbr * Wk + 1) || E->a_pre.ensure((size_t)nbr * Wk + 1) || E->bt_bm.ensure((size_t)nbc * Wk + 1) ||
+        E->tile_rows.ensure((size_t)nbr + 1) || E->tile_cols.ensure((size_t)nbc + 1) || E->band_descs_buf.ensure((size_t)nsub + 1) ||
+        E->band_sub_cnt.ensure((size_t)nsub + 1) || E->band_cnt_rem.ensure((size_t)nsub + 1) || E->band_rem_start.ensure((size_t)nsub + 2) ||
+        E->band_cnt_list.ensure((size_t)npl + 1) || E->band_list_off.ensure((size_t)npl + 2) || E->band_cnt_b.ensure((size_t)nps + 1) ||
+        E->band_seq_off.ensure((size_t)nps + 2))
+      return -1;
+    ACC_CHECK(hipMemsetAsync(E->a_bm.p, 0, sizeof(uint32_t) * (size_t)nbr * Wk, st));
+    ACC_CHECK(hipMemsetAsync(E->bt_bm.p, 0, sizeof(uint32_t) * (size_t)nbc * Wk, st));
+    ACC_CHECK(hipMemsetAsync(E->band_cnt_list.p, 0, sizeof(int) * (size_t)npl, st));
+    ACC_CHECK(hipMemsetAsync(E->band_cnt_b.p, 0, sizeof(int) * (size_t)nps, st));
+    hipLaunchKernelGGL(bitmap_from_index, grid_for((int64_t)nbr * 64), dim3(256), 0, st, a->row_p, a->col_i, nbr, Wk, E->a_bm.p);
+    hipLaunchKernelGGL(row_prefix, grid_for((int64_t)nbr * 64), dim3(256), 0, st, E->a_bm.p, nbr, Wk, E->a_pre.p, (int*)nullptr);
+    hipLaunchKernelGGL(tile_bitmap_transposed, grid_for((int64_t)nbk * 64), dim3(256), 0, st, b->row_p, b->col_i, nbk, Wk, E->bt_bm.p);
+    hipLaunchKernelGGL(tile_select, dim3(1), dim3(64), 0, st, a->row_blk_size, nbr, S_, E->tile_rows.p, nbr);
+    hipLaunchKernelGGL(tile_select, dim3(1), dim3(64), 0, st, b->col_blk_size, nbc, S_, E->tile_cols.p, nbc);
+    hipLaunchKernelGGL(band_descs, grid_for(nsub * 16), dim3(256), 0, st, G, E->tile_rows.p, E->tile_cols.p, E->c_bm.p, E->c_pre.p, c_out->row_p, W,
+                       E->descs.p, E->band_descs_buf.p, E->band_sub_cnt.p);
+    hipLaunchKernelGGL((band_lists<false>), grid_for(nsub * 64), dim3(256), 0, st, G, E->tile_rows.p, E->tile_cols.p, nbk, Wk, E->a_bm.p, E->a_pre.p,
+                       a->row_p, a->blk_p, E->bt_bm.p, W, E->b_bm.p, E->b_pre.p, b->row_p, b->blk_p, a->col_blk_size, S_, E->band_cnt_list.p,
+                       E->band_cnt_b.p, E->band_cnt_rem.p, (const int64_t*)nullptr, (const int64_t*)nullptr, (const int64_t*)nullptr,
+                       E->band_sub_cnt.p, (BandEntry*)nullptr, (BandRem*)nullptr, E->band_flags.p + 1);
+    if (exclusive_scan<int64_t>(E, E->band_cnt_list.p, npl, E->band_list_off.p, nullptr, true, st)) return -1;
+    if (exclusive_scan<int64_t>(E, E->band_cnt_b.p, nps, E->band_seq_off.p, nullptr, true, st)) return -1;
+    if (exclusive_scan<int64_t>(E, E->band_cnt_rem.p, nsub, E->band_rem_start.p, nullptr, true, st)) return -1;
+    hipLaunchKernelGGL(band_max_seq, grid_for(nwg), dim3(256), 0, st, G, nwg, E->band_seq_off.p, E->band_flags.p + 2);
+    // list sizes to the host (once per plan: a multiply that reuses the plan comes nowhere near this)
+    ACC_CHECK(hipMemcpyAsync(E->host_scalars + 8, E->band_list_off.p + npl, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    ACC_CHECK(hipMemcpyAsync(E->host_scalars + 9, E->band_rem_start.p + nsub, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    ACC_CHECK(hipMemcpyAsync(E->host_scalars + 10, E->band_flags.p + 2, sizeof(int), hipMemcpyDeviceToHost, st));
+    ACC_CHECK(hipStreamSynchronize(st));
+    E->band_nlist = E->host_scalars[8];
+    E->band_nrem = E->host_scalars[9];
+    const int max_seq = *reinterpret_cast<const int*>(E->host_scalars + 10);
+    if (max_seq >= (1 << 24) - 64) return 1;  // the entries carry 24 bits of the sequence number: not a band case
+    if (E->band_entries.ensure((size_t)E->band_nlist + 1) || E->band_rem.ensure((size_t)E->band_nrem + 1)) return -1;
+    hipLaunchKernelGGL((band_lists<true>), grid_for(nsub * 64), dim3(256), 0, st, G, E->tile_rows.p, E->tile_cols.p, nbk, Wk, E->a_bm.p, E->a_pre.p,
+                       a->row_p, a->blk_p, E->bt_bm.p, W, E->b_bm.p, E->b_pre.p, b->row_p, b->blk_p, a->col_blk_size, S_, (int*)nullptr,
+                       (int*)nullptr, (int*)nullptr, E->band_list_off.p, E->band_seq_off.p, E->band_rem_start.p, E->band_sub_cnt.p,
+                       E->band_entries.p, E->band_rem.p, E->band_flags.p + 1);
+    E->band_geom = G;
+    E->band_built = true;
+  }
+  BandArgs P;
+  P.descs = E->band_descs_buf.p;
+  P.entries = E->band_entries.p;
+  P.list_off = E->band_list_off.p;
+  P.a_data = static_cast<const double*>(a->data);
+  P.b_data = static_cast<const double*>(b->data);
+  P.c_out = static_cast<double*>(c_out->data);
+  P.c_in = static_cast<const double*>(c_in->data);
+  P.alpha = alpha;
+  P.beta = beta;
+  P.G = G;
+  P.flags = E->band_flags.p;
+  P.knobs = E->band_knobs;
+  P.times = nullptr;
+  if (E->band_knobs & 1) {
+    if (E->band_times.ensure(8)) return -1;
+    ACC_CHECK(hipMemsetAsync(E->band_times.p, 0, 8 * sizeof(unsigned long long), st));
+    P.times = E->band_times.p;
+  }
+  ACC_CHECK(hipEventRecord(E->ev[1], st));  // the timed numeric launch starts here (the index work above counts as fill time)
+  if (band_launch(S_, S_, S_, E->band_depth, E->band_bpol, (unsigned)nwg, st, P)) return -1;
+  if (E->band_nrem > 0 &&
+      band_launch_remainder(S_, S_, st, nsub, E->band_descs_buf.p, E->band_rem_start.p, E->band_rem.p, P.a_data, P.b_data, P.c_out, alpha))
+    return -1;
+  return check(hipGetLastError(), "run_band_f64", __FILE__, __LINE__);
+}
+
 }  // namespace dbcsr_amd
 
 using namespace dbcsr_amd;
@@ -515,6 +629,10 @@ int dbcsr_amd_mm_create(void** handle) {
   if (const char* k = getenv("DBCSR_AMD_MM_TILE_PREFETCH")) E->tile_prefetch = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_TILE_KNOBS")) E->tile_knobs = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_TILE_SHAPE")) E->tile_shape = atoi(k) == 1 ? 1 : 0;
+  if (const char* k = getenv("DBCSR_AMD_MM_BAND")) E->use_band = atoi(k);
+  if (const char* k = getenv("DBCSR_AMD_MM_BAND_DEPTH")) E->band_depth = atoi(k);
+  if (const char* k = getenv("DBCSR_AMD_MM_BAND_BPOL")) E->band_bpol = atoi(k) == 1 ? 1 : 0;
+  if (const char* k = getenv("DBCSR_AMD_MM_BAND_KNOBS")) E->band_knobs = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_HOT")) E->use_hot = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_TINY")) E->use_tiny = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_LDS_PAD")) E->lds_pad = atoi(k);
@@ -559,6 +677,9 @@ int dbcsr_amd_mm_destroy(void* handle) {
   E->hot_counters.release();
   E->a_bm.release(); E->bt_bm.release(); E->tile_prog.release(); E->a_pre.release(); E->tile_rows.release(); E->tile_cols.release();
   E->tile_cnt.release(); E->tile_flags.release(); E->tile_start.release(); E->tdescs.release(); E->tentries.release();
+  E->band_descs_buf.release(); E->band_entries.release(); E->band_rem.release(); E->band_cnt_list.release(); E->band_cnt_b.release();
+  E->band_cnt_rem.release(); E->band_sub_cnt.release(); E->band_flags.release(); E->band_list_off.release(); E->band_seq_off.release();
+  E->band_rem_start.release(); E->band_times.release();
   if (E->host_scalars) (void)hipHostFree(E->host_scalars);
   if (E->plan_host_flag) (void)hipHostFree(E->plan_host_flag);
   E->plan_words.release(); E->plan_c_col_i.release(); E->plan_c_blk_p.release(); E->plan_flag.release(); E->work.release();
@@ -879,7 +1000,7 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
   if (nblk == 0) return 0;
   // plan reuse: product lists, descriptors and launch order of the previous multiply stand; C's index is copied from the saved one
   const bool reuse = E->plan_hit && E->plan_numeric;
-  if (!reuse) E->work_built = E->tile_built = false;
+  if (!reuse) E->work_built = E->tile_built = E->band_built = false;
   if (E->entries.ensure((size_t)E->nproducts + 1) || E->descs.ensure((size_t)nblk + 1)) return -1;
   ACC_CHECK(hipEventRecord(E->ev[0], st));
   if (reuse) {
@@ -1060,16 +1181,25 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
           (E->use_tile > 1 || (E->nproducts >= 8 * nblk && nblk >= 200000)))
         tile_rc = run_tile_f64<23>(E, st, a, b, c_in, c_out, alpha, beta);
       if (tile_rc < 0) return -1;
+      // CU-wide C tiles, B shared in LDS (mm_band.h): the same conditions, and no retain_sparsity (its lists take C's pattern from the operands)
+      if (tile_rc != 0 && E->use_band > 0 && hot_work && E->use_hot && E->use_pipe != 1 && E->dma_stages == 0 && E->hot_m == 23 && E->hot_n == 23 &&
+          E->hot_k == 23 && !E->filter.a_norms && !skip_empty && !E->canonical_c && !epi_norms && !(E->dbg & ~32) && !E->retain && !E->hot_persistent &&
+          (E->use_band > 1 || (E->nproducts >= 8 * nblk && nblk >= 200000))) {
+        tile_rc = run_band_f64<23>(E, st, a, b, c_in, c_out, alpha, beta);
+        if (tile_rc < 0) return -1;
+        if (tile_rc == 0) tile_rc = 2;
+      }
       // measured: the pipelined kernel wins when C blocks have few products (config 3: 3.7 per block, 10.4 vs 11.8 ms) and
       // loses when they have many (config 2: 14.4 per block, 32 vs 22 ms)
-      if (tile_rc == 0) {
-        // the tile kernel computed the C blocks of the dominant size (products with inner blocks of another size included);
+      if (tile_rc == 0 || tile_rc == 2) {
+        // the tile / band kernel computed the C blocks of the dominant size (products with inner blocks of another size included);
         // this launch: the exact-size kernel over the blocks of the other sizes only
         launch_hot_f64(E->hot_m, E->hot_n, E->hot_k, dim3((unsigned)(8 * E->order_len / ww)), (size_t)ww * lds_wave * sizeof(double) + (size_t)E->lds_pad,
                        st, E->descs.p, nblk, E->entries.p, static_cast<const double*>(a->data), static_cast<const double*>(b->data),
                        static_cast<double*>(c_out->data), static_cast<const double*>(c_in->data), alpha, beta, lds_a, lds_wave, 64, E->order.p,
                        hot_work, ww, nullptr, 0);
-        snprintf(E->last_kernel, sizeof E->last_kernel, "mm_numeric_f64_tile<%d,%d,%d>", E->hot_m, E->hot_n, E->hot_k);
+        snprintf(E->last_kernel, sizeof E->last_kernel, tile_rc == 2 ? "mm_numeric_f64_band<%d,%d,%d>" : "mm_numeric_f64_tile<%d,%d,%d>", E->hot_m, E->hot_n,
+                 E->hot_k);
       } else if (E->use_hot && E->use_pipe != 1 && E->hot_m > 0 && E->dma_stages > 0 &&
           launch_dma_f64(E->dma_stages, E->hot_m, E->hot_n, E->hot_k, (unsigned)(8 * E->order_len), st, E->descs.p, nblk, E->entries.p,
                          static_cast<const double*>(a->data), static_cast<const double*>(b->data), static_cast<double*>(c_out->data),
@@ -1606,6 +1736,28 @@ int dbcsr_amd_mm_tile_stats(void* handle, int* waves_gave_up, int* list_mismatch
   if (getenv("DBCSR_AMD_MM_TILE_VERBOSE"))
     fprintf(stderr, "dbcsr_amd tile kernel: %d waves gave up, %lld reads of the team counters, %lld products waited for the window (of %lld)\n", h[0],
             16ll * h[2], 16ll * h[3], (long long)E->nproducts);
+  return 0;
+}
+
+int dbcsr_amd_mm_band_stats(void* handle, int* waits_gave_up, int* list_mismatches) {
+  Engine* E = static_cast<Engine*>(handle);
+  if (!E) return -1;
+  if (strncmp(E->last_kernel, "mm_numeric_f64_band", 19) != 0 || !E->band_flags.p) return 1;
+  int h[4] = {0, 0, 0, 0};
+  ACC_CHECK(hipDeviceSynchronize());
+  ACC_CHECK(hipMemcpy(h, E->band_flags.p, sizeof h, hipMemcpyDeviceToHost));
+  if (waits_gave_up) *waits_gave_up = h[0];
+  if (list_mismatches) *list_mismatches = h[1];
+  if ((E->band_knobs & 1) && E->band_times.p) {
+    unsigned long long t[8];
+    ACC_CHECK(hipMemcpy(t, E->band_times.p, sizeof t, hipMemcpyDeviceToHost));
+    const double w = t[5] ? (double)t[5] : 1.0;
+    fprintf(stderr,
+            "dbcsr_amd band kernel, mean per wave [ms]: total %.3f = issue + waits for A %.3f + waits for B %.3f + multiplies %.3f + epilogues %.3f + rest %.3f "
+            "(%llu waves; %llu of %lld products waited for their B block, %llu fetched it themselves at the last moment; %lld list entries, ring of %d)\n",
+            t[0] / w * 1e-5, t[1] / w * 1e-5, t[2] / w * 1e-5, t[3] / w * 1e-5, t[4] / w * 1e-5, ((double)t[0] - t[1] - t[2] - t[3] - t[4]) / w * 1e-5, t[5],
+            t[7], (long long)E->nproducts, t[6], (long long)E->band_nlist, E->band_depth);
+  }
   return 0;
 }
 

@@ -131,6 +131,15 @@ class MultiplyEngine:
             raise RuntimeError("dbcsr_amd_mm_tile_stats failed (%d)" % rc)
         return None if rc else (a.value, b.value)
 
+    def band_stats(self):
+        """(waits of the ring protocol that gave up, (tile, wave) lists that disagreed with the per-block counts) of the last numeric
+        call -- both must be 0 --, or None when it did not run the band kernel (dbcsr_amd_mm_band_stats)"""
+        a, b = C.c_int(), C.c_int()
+        rc = self.L.dbcsr_amd_mm_band_stats(self.h, C.byref(a), C.byref(b))
+        if rc < 0:
+            raise RuntimeError("dbcsr_amd_mm_band_stats failed (%d)" % rc)
+        return None if rc else (a.value, b.value)
+
     def last_timing(self):
         """(ms_fill, ms_numeric) of the last numeric call, from HIP events on its stream."""
         f, n = C.c_float(), C.c_float()

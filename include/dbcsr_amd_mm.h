@@ -216,6 +216,11 @@ int dbcsr_amd_mm_plan_stats(void* handle, int64_t* reused, int64_t* built);
  * product counts (must be 0).  Returns 1 when that call did not run the tile kernel.  Synchronises the device. */
 int dbcsr_amd_mm_tile_stats(void* handle, int* waves_gave_up, int* list_mismatches);
 
+/* The same for the band kernel (dbcsr_amd/csrc/mm_band.h: CU-wide C tiles, B shared in an LDS ring): waits of the ring protocol that
+ * gave up (must be 0: a block was used before it had landed), (tile, wave) lists that disagreed with the per-block product counts
+ * (must be 0).  Returns 1 when the last dbcsr_amd_mm_numeric of this handle did not run the band kernel.  Synchronises the device. */
+int dbcsr_amd_mm_band_stats(void* handle, int* waits_gave_up, int* list_mismatches);
+
 #if defined(__cplusplus)
 }
 #endif
