@@ -12,8 +12,10 @@
 //     cross the fabric instead of 1.0, and reach LDS once instead of once per product;
 //   * A blocks go to a private two-slot ring per wave (0.9 per product; a product that shares its A block with the previous one
 //     skips the copy) and come out of the XCD's L2: the 32 CUs of an XCD work on the SAME 24 block rows at about the same k, so an
-//     A block is used by 8.7 CUs while it is L2-resident.  Nothing synchronises the CUs with each other (no k window, no team):
-//     a CU that falls behind costs L2 hits, never waits;
+//     A block is used by 8.7 CUs while it is L2-resident -- IF the CUs stay together: left alone they drift apart by more than the L2
+//     holds (measured: L2 hit rate 0.19, 140 GB over the fabric), so the waves of an XCD keep a k window as in mm_tile.h (every wave
+//     publishes the position it will fetch next, nobody fetches beyond the minimum + W); the eight waves of a CU are already held
+//     together by the ring, so the spread that costs waiting is that of 32 CUs with 1026 +- 35 products per tile, not of 256 waves;
 //   * the ring is a tiny cache with reference counts, one state word per slot in LDS: the first wave that needs B block n (its
 //     sequence number in the CU's k-sorted sweep) and finds slot n % D free claims it (compare-and-swap), copies the block by
 //     LDS-DMA and publishes it one product later, when its own in-order wait has covered the copy; every user decrements the count
@@ -42,8 +44,10 @@ struct BandEntry {
   uint32_t a_lo, b_lo;  // low 32 bits of the element offsets into the A / B data areas
   uint32_t w;           // bits 0-3: accumulator slot (3 ti + tj); 4: the A block differs from the previous entry's (copy it); 5: last product
                         // of this wave with the B block (release it); 6: not a product (end-of-tile marker); 7: end of tile: write the
-                        // sub-tile's C blocks after this entry; bits 8-15: k extent; 16-23 / 24-31: bits 32-39 of the A / B offset
-  uint32_t s;           // bits 0-23: sequence number of the B block in the CU's sweep; bits 24-27: waves that use the block
+                        // sub-tile's C blocks after this entry; bits 8-15: low bits of the sweep position (inner block >> kshift);
+                        // 16-23 / 24-31: bits 32-39 of the A / B offset
+  uint32_t s;           // bits 0-23: sequence number of the B block in the CU's sweep; bits 24-27: waves that use the block; bits 28-31:
+                        // high bits of the sweep position
 };
 constexpr uint32_t kBandNewA = 16u, kBandLastB = 32u, kBandNop = 64u, kBandFlush = 128u;
 
@@ -64,6 +68,7 @@ struct BandGeom {
   int ntiles;       // nBR * nBC, band-major
   int cu_per_xcd;   // workgroups per XCD (a workgroup b works for XCD b % 8)
   int max_i;        // tiles per workgroup, at most
+  int kshift, kspan;  // sweep position of an inner block k: k >> kshift (< 4096); kspan > the largest: position of (tile i, k) = i * kspan + (k >> kshift)
   // XCD x sweeps the tiles [x * ntiles / 8, (x + 1) * ntiles / 8); its workgroup c takes every cu_per_xcd-th of them, starting at c
   __host__ __device__ int64_t lo(int x) const { return (int64_t)x * ntiles / 8; }
 };
@@ -78,9 +83,12 @@ struct BandArgs {
   const double* c_in;
   double alpha, beta;
   BandGeom G;
-  int* flags;                 // [0] spins that gave up (must be 0: results are wrong otherwise), [1] list mismatches (index kernels)
+  unsigned* prog;             // [8][256] next sweep position each wave of an XCD will fetch (zeroed before the launch)
+  int window;                 // a wave fetches operands for position p only while p <= (minimum over its XCD) + window; <= 0: no throttle
+  int* flags;                 // [0] spins that gave up (must be 0: results are wrong otherwise), [1] list mismatches (index kernels),
+                              // [2] largest sequence number, [3] waves that switched their throttle off (speed only)
   unsigned long long* times;  // knob bit 0: [0] total [1] waits for A [2] waits for B [3] multiplies [4] epilogues (10 ns), [5] waves, [6] claims at the last moment, [7] B waits counted
-  int knobs;                  // bit 0: timing
+  int knobs;                  // bit 0: timing; bits 1-3: publish quantum = window >> this (default 3)
 };
 
 // block sizes the band kernels are built for (cubes)

@@ -13,6 +13,38 @@ __device__ __forceinline__ int64_t band_uniform64(int64_t v) {
   return (int64_t)(((uint64_t)hi << 32) | lo);
 }
 
+constexpr unsigned kBandDone = 0x7fffffffu;  // position of a wave that needs nothing any more
+
+// minimum over the wavefront as a scalar: DPP row shifts and row broadcasts (no LDS, no index registers), result from lane 63
+__device__ __forceinline__ unsigned band_wave_min(unsigned v) {
+  // (the control word must be a literal: one call per step)
+  {
+    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)0xffffffff, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v = o < v ? o : v;
+  }
+  {
+    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)0xffffffff, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v = o < v ? o : v;
+  }
+  {
+    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)0xffffffff, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v = o < v ? o : v;
+  }
+  {
+    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)0xffffffff, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v = o < v ? o : v;
+  }
+  {
+    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)0xffffffff, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+    v = o < v ? o : v;
+  }
+  {
+    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)0xffffffff, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+    v = o < v ? o : v;
+  }
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 template <int M, int N, int K, int D>
 struct BandKernel {
   static constexpr int KS = (K + 3) / 4;
@@ -26,7 +58,7 @@ struct BandKernel {
   static_assert((M + 7) / 8 == 3 && (N + 7) / 8 == 3, "the sub-tiles are sized for blocks of 17..24 (9 accumulators per block and lane)");
   static_assert(D >= 4 && D <= 64, "ring depth");
   static_assert(PA == PB, "one wait count per copy");
-  static_assert(PA + PB < 32, "vmcnt budget");
+  static_assert(PA + 2 * PB < 32, "vmcnt budget");
   static_assert(KS >= 3, "first / middle / last k step");
   static_assert(M * N * 8 <= SA, "a C block is staged in an A slot");
 };
@@ -118,8 +150,9 @@ __device__ __forceinline__ void band_store_block(const double (&acc)[3][3], char
 template <int M, int N, int K, int D, int BPOL>
 __global__ void __launch_bounds__(64 * kBandWaves) mm_numeric_f64_band(BandArgs P) {
   typedef BandKernel<M, N, K, D> BK;
-  constexpr int LOOK = 2;  // a wave tries to bring in the B block of the product after the next one: claimed at boundary p, published at
-                           // boundary p + 1 (when the wave's own in-order wait has covered the copy), used at p + 2
+  constexpr int LOOK = 2;  // a wave tries to bring in the B block of the product after the next one: claimed at boundary p (after the A
+                           // block of product p + 1 has been requested), published at boundary p + 2, when the wave's in-order wait for
+                           // the A block of product p + 2 has covered the copy, used right then
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, voff = lane * 16;
   const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -181,20 +214,80 @@ __global__ void __launch_bounds__(64 * kBandWaves) mm_numeric_f64_band(BandArgs 
       for (int c = 0; c < 3; ++c) acc[sl][a][c] = 0.0;
   struct Ent {
     uint32_t a_lo, b_lo, w, s;
+    int t;  // tile of the workgroup's sweep the entry belongs to
   };
-  const Ent nop = {0u, 0u, kBandNop, 0u};
+  const Ent nop = {0u, 0u, kBandNop, 0u, 0};
   Ent cur = nop, nxt = nop;  // the sweep starts LOOK entries early, on two non-products
   int aslot = 0;             // A slot of the current product
-  unsigned pend = 0;         // slot + 1 of a B copy this wave has issued and not yet published
+  unsigned pend1 = 0, pend2 = 0;  // slot + 1 of the B copies this wave issued at the previous boundary / the one before and has not published
+  int nb_prev = 0;           // pieces of the B copy issued at the previous boundary
   int itile = 0;             // tiles of this workgroup the wave has written
+  int tile_far = 0;          // tile of the entry that enters the look-ahead
   bool dead = false;         // a wait gave up (a bug): finish without waiting, the host reports it
   auto issue_b = [&](const Ent& en, unsigned slot) {
     const uint64_t bo = (uint64_t)en.b_lo | ((uint64_t)(en.w >> 24) << 32);
     dma_block<BK::BBYTES, BPOL>(P.b_data + bo, ringb_lds + slot * BK::SB, voff);
   };
-  auto publish = [&]() {
-    if (pend) st_or(pend - 1u, 16u);
-    pend = 0;
+  // (call only when the copies are known to have landed)
+  auto publish_all = [&]() {
+    if (pend2) st_or(pend2 - 1u, 16u);
+    if (pend1) st_or(pend1 - 1u, 16u);
+    pend1 = pend2 = 0;
+  };
+  // ---- the XCD's k window (as in mm_tile.hip): what a wave publishes is the sweep position of the next operands it will FETCH, a lower
+  // bound of everything it still needs from L2; the wave that holds the minimum may always go on
+  int window = __builtin_amdgcn_readfirstlane(P.window);
+  unsigned* team = P.prog + xcd * 256;
+  const int q_team = cu * kBandWaves + wid;
+  const int team_n = G.cu_per_xcd * kBandWaves < 256 ? G.cu_per_xcd * kBandWaves : 256;
+  const bool my_counters = 4 * lane < team_n;
+  const __amdgpu_buffer_rsrc_t rs_team = __builtin_amdgcn_make_buffer_rsrc((void*)team, 0, 1024, 0x00020000);
+  const int pub_off = lane == 0 ? 4 * q_team : 0x7ffffff0;  // branch-free: the other lanes' stores are dropped by the bounds check
+  const int qshift = (P.knobs >> 1) & 7 ? (P.knobs >> 1) & 7 : 3;
+  const unsigned quantum = (window >> qshift) > 0 ? (unsigned)(window >> qshift) : 1u;
+  unsigned seen_min = 0, published = 0;
+  unsigned n_polls = 0, n_blocked = 0;
+  unsigned long long t_win = 0;
+  auto pos_of = [&](const Ent& en) -> unsigned { return (unsigned)en.t * (unsigned)G.kspan + (((en.w >> 8) & 255u) | ((en.s >> 28) << 8)); };
+  auto publish_pos = [&](unsigned gp) {
+    published = gp;
+    __builtin_amdgcn_raw_buffer_store_b32(gp, rs_team, pub_off, 0, 0);  // into this XCD's L2 (where the whole team reads it)
+  };
+  auto team_min = [&]() -> unsigned {
+    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_team, voff, 0, 16);  // sc1: not from this CU's vector cache
+    if (!my_counters) v = u32x4{kBandDone, kBandDone, kBandDone, kBandDone};
+    unsigned m = v[0] < v[1] ? v[0] : v[1];
+    const unsigned m2 = v[2] < v[3] ? v[2] : v[3];
+    m = m < m2 ? m : m2;
+    return band_wave_min(m);
+  };
+  auto admit = [&](unsigned gp) {
+    if (window <= 0) return;
+    if (gp <= seen_min + (unsigned)window) {
+      if (gp >= published + quantum) publish_pos(gp);
+      return;
+    }
+    publish_pos(gp);
+    ++n_blocked;
+    const unsigned long long tw0 = timing ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    if (pend1 | pend2) {  // a waiting wave owes nothing
+      dma_wait<0>();
+      publish_all();
+    }
+    int polls = 0;
+    for (;;) {
+      ++n_polls;
+      seen_min = team_min();
+      if (gp <= seen_min + (unsigned)window) break;
+      if (++polls > (1 << 15)) {  // never hang on the protocol: go on unthrottled (speed only)
+        window = 0;
+        atomicAdd(P.flags + 3, lane == 0 ? 1 : 0);
+        publish_pos(kBandDone);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    if (timing) t_win += __builtin_amdgcn_s_memrealtime() - tw0;
   };
   // descriptors of the tile being swept, one vector load per tile, requested a whole tile ahead (right after the previous tile was
   // written): lane l < 9 holds c_off[l], lane 9 + l cin_off[l].  (Per-block scalar-looking loads inside the epilogue became vector loads
@@ -228,37 +321,49 @@ __global__ void __launch_bounds__(64 * kBandWaves) mm_numeric_f64_band(BandArgs 
         far.b_lo = (uint32_t)__builtin_amdgcn_readlane((int)ev1, j);
         far.w = (uint32_t)__builtin_amdgcn_readlane((int)ev2, j);
         far.s = (uint32_t)__builtin_amdgcn_readlane((int)ev3, j);
+        far.t = tile_far;
+        if (far.w & kBandFlush) ++tile_far;
       }
       unsigned long long t0 = timing ? __builtin_amdgcn_s_memrealtime() : 0ull;
-      // (1) the B block of the product after the next one: claim its slot if nobody has and the previous tenant is done with
-      int nw = 0;
-      unsigned newpend = 0;
-      if (!(far.w & kBandNop)) {
-        const unsigned seq = far.s & 0xffffffu, slot = seq % (unsigned)D;
-        const unsigned expect = band_enc(seq, 1u, 0u);
-        if (st_cas(slot, expect, band_enc(seq + D, 0u, far.s >> 24)) == expect) {
-          issue_b(far, slot);
-          nw += BK::PB;
-          newpend = slot + 1u;
-        }
-      }
-      // (2) the A block of the next product, into the wave's other slot
+      // (1) the A block of the next product, into the wave's other slot -- first the window: nobody fetches beyond the team's minimum + W
       const bool next_a = !(nxt.w & kBandNop) && (nxt.w & kBandNewA);
+      int nw = nb_prev;
       if (next_a) {
+        admit(pos_of(nxt));
+        if (timing) t0 = __builtin_amdgcn_s_memrealtime();
         const uint64_t ao = (uint64_t)nxt.a_lo | ((uint64_t)((nxt.w >> 16) & 0xffu) << 32);
         dma_block<BK::ABYTES>(P.a_data + ao, ringa_lds + (unsigned)(aslot ^ 1) * BK::SA, voff);
         nw += BK::PA;
       }
-      // (3) everything this wave issued before this boundary has landed: the A block of the current product, the B copy of the previous
-      // boundary (copies complete in order)
+      // (2) the B block of the product after the next one: claim its slot if nobody has, the previous tenant is done with and the window
+      // allows it (no waiting here: a wave that finds the block missing when it needs it fetches it then)
+      unsigned newpend = 0;
+      nb_prev = 0;
+      if (!(far.w & kBandNop) && (window <= 0 || pos_of(far) <= seen_min + (unsigned)window)) {
+        const unsigned seq = far.s & 0xffffffu, slot = seq % (unsigned)D;
+        const unsigned expect = band_enc(seq, 1u, 0u);
+        if (st_cas(slot, expect, band_enc(seq + D, 0u, (far.s >> 24) & 15u)) == expect) {
+          issue_b(far, slot);
+          nw += BK::PB;
+          nb_prev = BK::PB;
+          newpend = slot + 1u;
+        }
+      }
+      // (3) copies complete in order.  Issued since the A block of the CURRENT product (first thing of the previous boundary): the B copy
+      // of the previous boundary, this boundary's A and B copies.  When no more than those are in flight, the current A block has
+      // landed, and so has the B copy issued two boundaries ago: it is published now -- two products of flight time, none of it spent
+      // in this wait unless it was late
       if (nw == 0)
         dma_wait<0>();
       else if (nw == BK::PA)
         dma_wait<BK::PA>();
+      else if (nw == 2 * BK::PA)
+        dma_wait<2 * BK::PA>();
       else
-        dma_wait<BK::PA + BK::PB>();
-      publish();
-      pend = newpend;
+        dma_wait<3 * BK::PA>();
+      if (pend2) st_or(pend2 - 1u, 16u);
+      pend2 = pend1;
+      pend1 = newpend;
       if (timing) {
         const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
         t_a += t1 - t0;
@@ -273,16 +378,16 @@ __global__ void __launch_bounds__(64 * kBandWaves) mm_numeric_f64_band(BandArgs 
           // not there yet.  A wave that waits publishes what it holds first (its own copy may be what it -- or the wave it waits for -- needs),
           // so a waiting wave never owes anything: whoever it waits for is running
           ++n_bwait;
-          if (pend) {
+          if (pend1 | pend2) {
             dma_wait<0>();
-            publish();
+            publish_all();
             v = st_read(slot);
           }
           const unsigned expect = band_enc(seq, 1u, 0u);
           unsigned spins = 0;
           while ((v >> 4) != want) {
             if (v == expect) {  // free and unclaimed: bring it in now
-              v = st_cas(slot, expect, band_enc(seq + D, 0u, cur.s >> 24));
+              v = st_cas(slot, expect, band_enc(seq + D, 0u, (cur.s >> 24) & 15u));
               if (v == expect) {
                 ++n_late;
                 issue_b(cur, slot);
@@ -347,8 +452,9 @@ __global__ void __launch_bounds__(64 * kBandWaves) mm_numeric_f64_band(BandArgs 
       nxt = far;
     }
   }
+  if (window > 0) publish_pos(kBandDone);
   dma_wait<0>();
-  publish();
+  publish_all();
   if (timing && P.times) {
     const unsigned long long t_all = __builtin_amdgcn_s_memrealtime() - t_begin;
     if (lane == 0) {
@@ -360,6 +466,9 @@ __global__ void __launch_bounds__(64 * kBandWaves) mm_numeric_f64_band(BandArgs 
       atomicAdd(P.times + 5, 1ull);
       atomicAdd(P.times + 6, (unsigned long long)n_late);
       atomicAdd(P.times + 7, (unsigned long long)n_bwait);
+      atomicAdd(P.times + 8, t_win);
+      atomicAdd(P.times + 9, (unsigned long long)n_blocked);
+      atomicAdd(P.times + 10, (unsigned long long)n_polls);
     }
   }
 }

@@ -153,8 +153,9 @@ band_lists(BandGeom G, const int* __restrict__ rows, const int* __restrict__ col
             BandEntry e;
             e.a_lo = (uint32_t)a;
             e.b_lo = (uint32_t)b;
-            e.w = slot | (first ? kBandNewA : 0u) | (ti == last_ti ? kBandLastB : 0u) | ((uint32_t)ks << 8) | hi;
-            e.s = ((sq + jj) & 0xffffffu) | (users << 24);
+            const uint32_t kq = (uint32_t)(k >> G.kshift);
+            e.w = slot | (first ? kBandNewA : 0u) | (ti == last_ti ? kBandLastB : 0u) | ((kq & 255u) << 8) | hi;
+            e.s = ((sq + jj) & 0xffffffu) | (users << 24) | ((kq >> 8) << 28);
             entries[at++] = e;
           } else {
             BandRem e;

@@ -267,8 +267,10 @@ struct Engine {
   // CU-wide C tiles, B shared in an LDS ring (mm_band.h): DBCSR_AMD_MM_BAND = 0 never, 1 automatic, 2 whenever the sizes allow;
   // DBCSR_AMD_MM_BAND_DEPTH = slots of the ring (12 | 16 | 20 | 22); DBCSR_AMD_MM_BAND_BPOL = 1: B copies with the nt hint;
   // DBCSR_AMD_MM_BAND_KNOBS bit 0: where the waves' time goes (printed by dbcsr_amd_mm_band_stats)
-  int use_band = 0, band_depth = 20, band_bpol = 0, band_knobs = 0;
-  BandGeom band_geom = {0, 0, 0, 0, 0, 0, 0};
+  // DBCSR_AMD_MM_BAND_WINDOW = k window of an XCD's waves (inner blocks; 0: no throttle)
+  int use_band = 0, band_depth = 20, band_bpol = 0, band_knobs = 0, band_window = 96;
+  BandGeom band_geom = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  DevBuf<unsigned> band_prog;
   int64_t band_nlist = 0, band_nrem = 0;
   DevBuf<BandDesc> band_descs_buf;
   DevBuf<BandEntry> band_entries;
@@ -506,11 +508,16 @@ static int run_band_f64(Engine* E, hipStream_t st, const dbcsr_amd_bcsr* a, cons
   G.cu_per_xcd = std::min(32, std::max(1, n_cu / 8));
   G.max_i = 1;
   for (int x = 0; x < 8; ++x) G.max_i = std::max(G.max_i, (int)((G.lo(x + 1) - G.lo(x) + G.cu_per_xcd - 1) / G.cu_per_xcd));
+  G.kshift = 0;
+  while ((nbk >> G.kshift) >= 4096) ++G.kshift;
+  G.kspan = (nbk >> G.kshift) + 1;
+  if ((int64_t)(G.max_i + 1) * G.kspan >= 0x7ff00000ll) return 1;  // sweep positions would overflow: not a band case
   const int nwg = 8 * G.cu_per_xcd;
   const int64_t nsub = (int64_t)kBandWaves * G.ntiles, npl = (int64_t)nwg * kBandWaves * G.max_i, nps = (int64_t)nwg * G.max_i;
   const bool reuse = E->plan_hit && E->plan_numeric && E->band_built;
-  if (E->band_flags.ensure(4)) return -1;
+  if (E->band_flags.ensure(4) || E->band_prog.ensure(8 * 256)) return -1;
   ACC_CHECK(hipMemsetAsync(E->band_flags.p, 0, sizeof(int) * 4, st));
+  ACC_CHECK(hipMemsetAsync(E->band_prog.p, 0, sizeof(unsigned) * 8 * 256, st));
   if (!reuse) {
     E->band_built = false;
     if (E->a_bm.ensure((size_t)nbr * Wk + 1) || E->a_pre.ensure((size_t)nbr * Wk + 1) || E->bt_bm.ensure((size_t)nbc * Wk + 1) ||
@@ -567,11 +574,13 @@ static int run_band_f64(Engine* E, hipStream_t st, const dbcsr_amd_bcsr* a, cons
   P.beta = beta;
   P.G = G;
   P.flags = E->band_flags.p;
+  P.prog = E->band_prog.p;
+  P.window = E->band_window > 0 ? std::max(1, E->band_window >> G.kshift) : 0;
   P.knobs = E->band_knobs;
   P.times = nullptr;
   if (E->band_knobs & 1) {
-    if (E->band_times.ensure(8)) return -1;
-    ACC_CHECK(hipMemsetAsync(E->band_times.p, 0, 8 * sizeof(unsigned long long), st));
+    if (E->band_times.ensure(16)) return -1;
+    ACC_CHECK(hipMemsetAsync(E->band_times.p, 0, 16 * sizeof(unsigned long long), st));
     P.times = E->band_times.p;
   }
   ACC_CHECK(hipEventRecord(E->ev[1], st));  // the timed numeric launch starts here (the index work above counts as fill time)
@@ -633,6 +642,7 @@ int dbcsr_amd_mm_create(void** handle) {
   if (const char* k = getenv("DBCSR_AMD_MM_BAND_DEPTH")) E->band_depth = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_BAND_BPOL")) E->band_bpol = atoi(k) == 1 ? 1 : 0;
   if (const char* k = getenv("DBCSR_AMD_MM_BAND_KNOBS")) E->band_knobs = atoi(k);
+  if (const char* k = getenv("DBCSR_AMD_MM_BAND_WINDOW")) E->band_window = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_HOT")) E->use_hot = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_TINY")) E->use_tiny = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_LDS_PAD")) E->lds_pad = atoi(k);
@@ -679,7 +689,7 @@ int dbcsr_amd_mm_destroy(void* handle) {
   E->tile_cnt.release(); E->tile_flags.release(); E->tile_start.release(); E->tdescs.release(); E->tentries.release();
   E->band_descs_buf.release(); E->band_entries.release(); E->band_rem.release(); E->band_cnt_list.release(); E->band_cnt_b.release();
   E->band_cnt_rem.release(); E->band_sub_cnt.release(); E->band_flags.release(); E->band_list_off.release(); E->band_seq_off.release();
-  E->band_rem_start.release(); E->band_times.release();
+  E->band_rem_start.release(); E->band_times.release(); E->band_prog.release();
   if (E->host_scalars) (void)hipHostFree(E->host_scalars);
   if (E->plan_host_flag) (void)hipHostFree(E->plan_host_flag);
   E->plan_words.release(); E->plan_c_col_i.release(); E->plan_c_blk_p.release(); E->plan_flag.release(); E->work.release();
@@ -1749,14 +1759,16 @@ int dbcsr_amd_mm_band_stats(void* handle, int* waits_gave_up, int* list_mismatch
   if (waits_gave_up) *waits_gave_up = h[0];
   if (list_mismatches) *list_mismatches = h[1];
   if ((E->band_knobs & 1) && E->band_times.p) {
-    unsigned long long t[8];
+    unsigned long long t[16];
     ACC_CHECK(hipMemcpy(t, E->band_times.p, sizeof t, hipMemcpyDeviceToHost));
     const double w = t[5] ? (double)t[5] : 1.0;
     fprintf(stderr,
-            "dbcsr_amd band kernel, mean per wave [ms]: total %.3f = issue + waits for A %.3f + waits for B %.3f + multiplies %.3f + epilogues %.3f + rest %.3f "
-            "(%llu waves; %llu of %lld products waited for their B block, %llu fetched it themselves at the last moment; %lld list entries, ring of %d)\n",
-            t[0] / w * 1e-5, t[1] / w * 1e-5, t[2] / w * 1e-5, t[3] / w * 1e-5, t[4] / w * 1e-5, ((double)t[0] - t[1] - t[2] - t[3] - t[4]) / w * 1e-5, t[5],
-            t[7], (long long)E->nproducts, t[6], (long long)E->band_nlist, E->band_depth);
+            "dbcsr_amd band kernel, mean per wave [ms]: total %.3f = window waits %.3f + issue and waits for A %.3f + waits for B %.3f + multiplies %.3f + "
+            "epilogues %.3f + rest %.3f (%llu waves; %llu of %lld products waited for their B block, %llu fetched it themselves at the last moment; %llu "
+            "fetches waited for the window, %llu reads of the team's counters, %d waves switched the throttle off; %lld list entries, ring of %d, window %d)\n",
+            t[0] / w * 1e-5, t[8] / w * 1e-5, t[1] / w * 1e-5, t[2] / w * 1e-5, t[3] / w * 1e-5, t[4] / w * 1e-5,
+            ((double)t[0] - t[1] - t[2] - t[3] - t[4] - t[8]) / w * 1e-5, t[5], t[7], (long long)E->nproducts, t[6], t[9], t[10], h[3], (long long)E->band_nlist,
+            E->band_depth, E->band_window);
   }
   return 0;
 }

@@ -22,7 +22,7 @@ MANY = (23 * 170 + 16, 23 * 150 + 16, 23 * 160 + 16, 0.9, 0.9, 0.9, [1, 23], [1,
 TAILS = (23 * 40 + 16 + 7, 23 * 44 + 9, 23 * 42 + 16 + 5, 0.7, 0.7, 0.8, [20, 23, 1, 16, 1, 7], [22, 23, 1, 9], [21, 23, 1, 16, 1, 5])
 WIDE = (23 * 30, 23 * 40, 23 * 700, 0.85, 0.85, 0.9, [1, 23], [1, 23], [1, 23])                      # 2 bands x 234 column triples: long sweeps per workgroup
 
-ENV_KEYS = ("DBCSR_AMD_MM_BAND", "DBCSR_AMD_MM_BAND_DEPTH", "DBCSR_AMD_MM_BAND_BPOL", "DBCSR_AMD_MM_BAND_KNOBS", "DBCSR_AMD_MM_TILE", "DBCSR_AMD_MM_KERNEL",
+ENV_KEYS = ("DBCSR_AMD_MM_BAND", "DBCSR_AMD_MM_BAND_WINDOW", "DBCSR_AMD_MM_BAND_DEPTH", "DBCSR_AMD_MM_BAND_BPOL", "DBCSR_AMD_MM_BAND_KNOBS", "DBCSR_AMD_MM_TILE", "DBCSR_AMD_MM_KERNEL",
             "DBCSR_AMD_MM_HOT", "DBCSR_AMD_MM_CLASSES", "DBCSR_AMD_MM_DBG", "DBCSR_AMD_MM_WG_WAVES", "DBCSR_AMD_MM_HOT_PERSISTENT")
 
 
@@ -60,6 +60,13 @@ def test_band_kernel_matches_oracle(monkeypatch, case):
 def test_band_kernel_any_ring_depth(monkeypatch, depth):
     run(monkeypatch, {"DBCSR_AMD_MM_BAND_DEPTH": depth}, MANY)
     run(monkeypatch, {"DBCSR_AMD_MM_BAND_DEPTH": depth}, DENSE)
+
+
+@pytest.mark.parametrize("window", ["0", "1", "8", "64", "100000"])
+def test_band_kernel_any_window(monkeypatch, window):
+    # the k window of an XCD's waves is a speed knob: a window of one inner block serialises them, none lets every wave run free
+    run(monkeypatch, {"DBCSR_AMD_MM_BAND_WINDOW": window}, MANY)
+    run(monkeypatch, {"DBCSR_AMD_MM_BAND_WINDOW": window}, SPARSE_C)
 
 
 def test_band_kernel_streaming_b_copies_and_timing_knob(monkeypatch):
