@@ -6,7 +6,8 @@
 // dataflow (mm_tile.h) cut the fabric bytes but not the LDS bytes, and paid for a 256-wave k window.  Here the unit that shares is
 // the CU, and what it shares lives in LDS:
 //   * a workgroup (8 waves = one CU, two waves per SIMD, persistent) owns a tile of 24 block rows x 3 block columns of C; wave w
-//     owns rows 3w .. 3w+2 (a 3 x 3 sub-tile: 81 fp64 accumulators per lane, as in mm_tile.h);
+//     owns rows 3w .. 3w+2 (a 3 x 3 sub-tile: 81 fp64 accumulators per lane, as in mm_tile.h) -- shape 0; shape 1 (below): 16 waves
+//     with 2 x 2 sub-tiles, tiles of 32 x 2;
 //   * the B blocks (k, j) of the tile's three columns -- needed by every wave that has an A block in inner block k, 2.4 of the 8
 //     waves on average at 10 % fill -- are fetched ONCE per CU into a shared ring of D slots in LDS: 0.38 B blocks per product
 //     cross the fabric instead of 1.0, and reach LDS once instead of once per product;
@@ -34,10 +35,18 @@
 
 namespace dbcsr_amd {
 
-constexpr int kBandWaves = 8;      // waves per workgroup = sub-tiles per tile (stacked along the rows)
-constexpr int kBandT = 3;          // a sub-tile is kBandT x kBandT C blocks
-constexpr int kBandRows = kBandWaves * kBandT;  // block rows of a tile
-constexpr int kBandSlots = kBandT * kBandT;
+// Two SHAPES of the dataflow (DBCSR_AMD_MM_BAND_SHAPE), both with tiles three or two block columns wide and one sub-tile per wave, stacked
+// along the rows:
+//   0: 8 waves per workgroup (two per SIMD, up to 256 registers), sub-tiles of 3 x 3 C blocks: tiles of 24 x 3; two A slots per wave (the
+//      next product's A block is copied while the current one is multiplied)
+//   1: 16 waves per workgroup (FOUR per SIMD, up to 128 registers), sub-tiles of 2 x 2: tiles of 32 x 2, 0.30 B blocks per product; ONE A
+//      slot per wave (its copy is requested when the previous product's fragments have been read: three other waves of the SIMD cover the
+//      wait).  Why: measured on shape 0 (profiles/r04_band_*), a wave spends 1250 cycles per product outside its 864 cycles of MFMAs (copy
+//      issue, ring protocol, list handling), and with two waves per SIMD one partner cannot cover that -- the matrix pipe was 45 % busy
+//      with a ring that never made anybody wait in the model.
+constexpr int kBandMaxWaves = 16;  // waves per workgroup = sub-tiles per tile, at most
+constexpr int kBandMaxT = 3;       // largest sub-tile edge
+constexpr int kBandSlots = 9;      // C blocks per sub-tile, at most (slot = tc * ti + tj)
 
 // list entry, 16 bytes
 struct BandEntry {
@@ -46,7 +55,7 @@ struct BandEntry {
                         // of this wave with the B block (release it); 6: not a product (end-of-tile marker); 7: end of tile: write the
                         // sub-tile's C blocks after this entry; bits 8-15: low bits of the sweep position (inner block >> kshift);
                         // 16-23 / 24-31: bits 32-39 of the A / B offset
-  uint32_t s;           // bits 0-23: sequence number of the B block in the CU's sweep; bits 24-27: waves that use the block; bits 28-31:
+  uint32_t s;           // bits 0-22: sequence number of the B block in the CU's sweep; bits 23-27: waves that use the block; bits 28-31:
                         // high bits of the sweep position
 };
 constexpr uint32_t kBandNewA = 16u, kBandLastB = 32u, kBandNop = 64u, kBandFlush = 128u;
@@ -64,7 +73,8 @@ struct BandDesc {  // one sub-tile
 
 struct BandGeom {
   int nfr, nfc;     // block rows / columns of the dominant size
-  int nBR, nBC;     // tile grid: bands of 24 rows x triples of columns
+  int waves, tr, tc;  // the shape: sub-tiles (= waves) per tile, C block rows / columns of a sub-tile
+  int nBR, nBC;     // tile grid: bands of waves * tr rows x groups of tc columns
   int ntiles;       // nBR * nBC, band-major
   int cu_per_xcd;   // workgroups per XCD (a workgroup b works for XCD b % 8)
   int max_i;        // tiles per workgroup, at most
@@ -74,16 +84,16 @@ struct BandGeom {
 };
 
 struct BandArgs {
-  const BandDesc* descs;      // [8 * nBR][nBC]: sub-tile (8 band + w, ct)
+  const BandDesc* descs;      // [waves * nBR][nBC]: sub-tile (waves * band + w, ct)
   const BandEntry* entries;
-  const int64_t* list_off;    // [(8 cu_per_xcd * 8) * max_i + 1]: lists in processing order (workgroup, wave, tile of the workgroup)
+  const int64_t* list_off;    // [(8 cu_per_xcd * waves) * max_i + 1]: lists in processing order (workgroup, wave, tile of the workgroup)
   const double* a_data;
   const double* b_data;
   double* c_out;
   const double* c_in;
   double alpha, beta;
   BandGeom G;
-  unsigned* prog;             // [8][256] next sweep position each wave of an XCD will fetch (zeroed before the launch)
+  unsigned* prog;             // [8][512] next sweep position each wave of an XCD will fetch (zeroed before the launch)
   int window;                 // a wave fetches operands for position p only while p <= (minimum over its XCD) + window; <= 0: no throttle
   int* flags;                 // [0] spins that gave up (must be 0: results are wrong otherwise), [1] list mismatches (index kernels),
                               // [2] largest sequence number, [3] waves that switched their throttle off (speed only)
@@ -94,10 +104,12 @@ struct BandArgs {
 // block sizes the band kernels are built for (cubes)
 #define DBCSR_AMD_BAND_SIZES(X) X(23)
 
-// LDS bytes of a workgroup for ring depth D (0: no kernel for this size / depth)
-int band_lds_bytes(int m, int n, int k, int depth);
-// the persistent kernel (8 * cu_per_xcd workgroups of 8 waves); bpol: cache policy of the B copies (0 default, 1 nt); 0 = launched, 1 = no kernel
-int band_launch(int m, int n, int k, int depth, int bpol, unsigned nwg, hipStream_t st, const BandArgs& P);
+// geometry of a shape; false: no such shape
+bool band_shape(int shape, int* waves, int* tr, int* tc);
+// LDS bytes of a workgroup for ring depth D (0: no kernel for this size / shape / depth)
+int band_lds_bytes(int m, int n, int k, int shape, int depth);
+// the persistent kernel (8 * cu_per_xcd workgroups); bpol: cache policy of the B copies (0 default, 1 nt); 0 = launched, 1 = no kernel
+int band_launch(int m, int n, int k, int shape, int depth, int bpol, unsigned nwg, hipStream_t st, const BandArgs& P);
 int band_launch_remainder(int m, int n, hipStream_t st, int64_t nsub, const BandDesc* descs, const int64_t* rem_start, const BandRem* rem,
                           const double* a_data, const double* b_data, double* c_out, double alpha);
 

@@ -45,16 +45,16 @@ __device__ __forceinline__ unsigned band_wave_min(unsigned v) {
   return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
-template <int M, int N, int K, int D>
+template <int M, int N, int K, int D, int WAVES, int ASL>
 struct BandKernel {
   static constexpr int KS = (K + 3) / 4;
   static constexpr int ABYTES = M * K * 8, BBYTES = K * N * 8;
   static constexpr int SA = (ABYTES + 15) & ~15, SB = (BBYTES + 15) & ~15;
   static constexpr int PA = (ABYTES + 1023) / 1024, PB = (BBYTES + 1023) / 1024;
   static constexpr int STATE = 512;  // D state words (D <= 64), then at + 256 the 64 words lanes 1..63 of an LDS atomic are sent to
-  // [state][B ring: D slots][A rings: 8 waves x 2 slots][slack: fragment reads of lanes past the last column / row of the last slot and
+  // [state][B ring: D slots][A rings: WAVES waves x ASL slots][slack: fragment reads of lanes past the last column / row of the last slot and
   // the whole 1 KiB pieces of the C staging read past a slot's end]
-  static constexpr int LDS = STATE + D * SB + kBandWaves * 2 * SA + 1024;
+  static constexpr int LDS = STATE + D * SB + WAVES * ASL * SA + 1024;
   static_assert((M + 7) / 8 == 3 && (N + 7) / 8 == 3, "the sub-tiles are sized for blocks of 17..24 (9 accumulators per block and lane)");
   static_assert(D >= 4 && D <= 64, "ring depth");
   static_assert(PA == PB, "one wait count per copy");
@@ -63,9 +63,10 @@ struct BandKernel {
   static_assert(M * N * 8 <= SA, "a C block is staged in an A slot");
 };
 
-// state word of a ring slot: bits 5.. = sequence number of the block + D (so that "nothing yet" is a valid predecessor), bit 4 = the
-// block has landed, bits 0-3 = waves that have not finished with it
-__device__ __forceinline__ unsigned band_enc(unsigned seq_plus_d, unsigned landed, unsigned left) { return (seq_plus_d << 5) | (landed << 4) | left; }
+// state word of a ring slot: bits 6.. = sequence number of the block + D (so that "nothing yet" is a valid predecessor), bit 5 = the
+// block has landed, bits 0-4 = waves that have not finished with it
+__device__ __forceinline__ unsigned band_enc(unsigned seq_plus_d, unsigned landed, unsigned left) { return (seq_plus_d << 6) | (landed << 5) | left; }
+constexpr unsigned kBandLanded = 32u;
 
 // fragments of k step s: A from the wave's own slot, B from the shared ring.  One address register per operand, every fragment at a
 // compile-time offset; single ds_read_b64 (volatile: never paired into ds_read2_b64, which costs 8 LDS cycles against 2 x 2).  No
@@ -147,9 +148,12 @@ __device__ __forceinline__ void band_store_block(const double (&acc)[3][3], char
 // One persistent workgroup of 8 waves per CU; workgroup b works for XCD b % 8 (round-robin dispatch: a different placement costs L2
 // hits, never correctness -- nothing here waits for another workgroup).  D: slots of the shared B ring; BPOL: cache policy of the B
 // copies (dma_lds.h).
-template <int M, int N, int K, int D, int BPOL>
-__global__ void __launch_bounds__(64 * kBandWaves) mm_numeric_f64_band(BandArgs P) {
-  typedef BandKernel<M, N, K, D> BK;
+template <int M, int N, int K, int D, int BPOL, int WAVES, int TR, int TC, int ASL>
+__global__ void __launch_bounds__(64 * WAVES) mm_numeric_f64_band(BandArgs P) {
+  typedef BandKernel<M, N, K, D, WAVES, ASL> BK;
+  constexpr int SLOTS = TR * TC;
+  static_assert(ASL == 1 || ASL == 2, "A slots per wave");
+  static_assert(SLOTS <= kBandSlots && WAVES <= kBandMaxWaves && WAVES * TR <= 32, "geometry the index kernels can express");
   constexpr int LOOK = 2;  // a wave tries to bring in the B block of the product after the next one: claimed at boundary p (after the A
                            // block of product p + 1 has been requested), published at boundary p + 2, when the wave's in-order wait for
                            // the A block of product p + 2 has covered the copy, used right then
@@ -161,9 +165,9 @@ __global__ void __launch_bounds__(64 * kBandWaves) mm_numeric_f64_band(BandArgs 
   if (cu >= G.cu_per_xcd) return;
   const unsigned state_lds = lds_offset_of(smem);
   const unsigned ringb_lds = state_lds + BK::STATE;
-  const unsigned ringa_lds = ringb_lds + D * BK::SB + (unsigned)wid * 2u * BK::SA;
+  const unsigned ringa_lds = ringb_lds + D * BK::SB + (unsigned)wid * (unsigned)ASL * BK::SA;
   char* const ringb = smem + BK::STATE;
-  char* const ringa = ringb + D * BK::SB + wid * 2 * BK::SA;
+  char* const ringa = ringb + D * BK::SB + wid * ASL * BK::SA;
   if (threadIdx.x < D) reinterpret_cast<unsigned*>(smem)[threadIdx.x] = band_enc(threadIdx.x, 1u, 0u);  // slot s: "block s - D" landed, nobody left
   __syncthreads();
   const LaneMap L(lane);
@@ -195,8 +199,8 @@ __global__ void __launch_bounds__(64 * kBandWaves) mm_numeric_f64_band(BandArgs 
     asm volatile("ds_or_b32 %0, %1" ::"v"(addr), "v"(val) : "memory");
   };
   const int g = xcd * G.cu_per_xcd + cu;
-  const int64_t l0 = band_uniform64(P.list_off[(int64_t)(g * kBandWaves + wid) * G.max_i]);
-  const int64_t l1 = band_uniform64(P.list_off[(int64_t)(g * kBandWaves + wid + 1) * G.max_i]);
+  const int64_t l0 = band_uniform64(P.list_off[(int64_t)(g * WAVES + wid) * G.max_i]);
+  const int64_t l1 = band_uniform64(P.list_off[(int64_t)(g * WAVES + wid + 1) * G.max_i]);
   const int n = (int)(l1 - l0);
   const BandEntry* e = P.entries + l0;
   const __amdgpu_buffer_rsrc_t rs_list = __builtin_amdgcn_make_buffer_rsrc((void*)e, 0, n * 16, 0x00020000);
@@ -205,9 +209,9 @@ __global__ void __launch_bounds__(64 * kBandWaves) mm_numeric_f64_band(BandArgs 
   unsigned long long t_a = 0, t_b = 0, t_mul = 0, t_epi = 0;
   unsigned n_late = 0, n_bwait = 0;
   const unsigned long long t_begin = timing ? __builtin_amdgcn_s_memrealtime() : 0ull;
-  double acc[kBandSlots][3][3];
+  double acc[SLOTS][3][3];
 #pragma unroll
-  for (int sl = 0; sl < kBandSlots; ++sl)
+  for (int sl = 0; sl < SLOTS; ++sl)
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
@@ -230,18 +234,18 @@ __global__ void __launch_bounds__(64 * kBandWaves) mm_numeric_f64_band(BandArgs 
   };
   // (call only when the copies are known to have landed)
   auto publish_all = [&]() {
-    if (pend2) st_or(pend2 - 1u, 16u);
-    if (pend1) st_or(pend1 - 1u, 16u);
+    if (pend2) st_or(pend2 - 1u, kBandLanded);
+    if (pend1) st_or(pend1 - 1u, kBandLanded);
     pend1 = pend2 = 0;
   };
   // ---- the XCD's k window (as in mm_tile.hip): what a wave publishes is the sweep position of the next operands it will FETCH, a lower
   // bound of everything it still needs from L2; the wave that holds the minimum may always go on
   int window = __builtin_amdgcn_readfirstlane(P.window);
-  unsigned* team = P.prog + xcd * 256;
-  const int q_team = cu * kBandWaves + wid;
-  const int team_n = G.cu_per_xcd * kBandWaves < 256 ? G.cu_per_xcd * kBandWaves : 256;
-  const bool my_counters = 4 * lane < team_n;
-  const __amdgpu_buffer_rsrc_t rs_team = __builtin_amdgcn_make_buffer_rsrc((void*)team, 0, 1024, 0x00020000);
+  constexpr int TEAM = 32 * WAVES;  // counters of an XCD's team: 4 (8) words per lane
+  unsigned* team = P.prog + xcd * 512;
+  const int q_team = cu * WAVES + wid;
+  const int team_n = G.cu_per_xcd * WAVES < TEAM ? G.cu_per_xcd * WAVES : TEAM;  // (a multiple of 4)
+  const __amdgpu_buffer_rsrc_t rs_team = __builtin_amdgcn_make_buffer_rsrc((void*)team, 0, 4 * TEAM, 0x00020000);
   const int pub_off = lane == 0 ? 4 * q_team : 0x7ffffff0;  // branch-free: the other lanes' stores are dropped by the bounds check
   const int qshift = (P.knobs >> 1) & 7 ? (P.knobs >> 1) & 7 : 3;
   const unsigned quantum = (window >> qshift) > 0 ? (unsigned)(window >> qshift) : 1u;
@@ -254,11 +258,16 @@ __global__ void __launch_bounds__(64 * kBandWaves) mm_numeric_f64_band(BandArgs 
     __builtin_amdgcn_raw_buffer_store_b32(gp, rs_team, pub_off, 0, 0);  // into this XCD's L2 (where the whole team reads it)
   };
   auto team_min = [&]() -> unsigned {
-    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_team, voff, 0, 16);  // sc1: not from this CU's vector cache
-    if (!my_counters) v = u32x4{kBandDone, kBandDone, kBandDone, kBandDone};
-    unsigned m = v[0] < v[1] ? v[0] : v[1];
-    const unsigned m2 = v[2] < v[3] ? v[2] : v[3];
-    m = m < m2 ? m : m2;
+    unsigned m = kBandDone;
+#pragma unroll
+    for (int h = 0; h < TEAM / 256; ++h) {
+      u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_team, voff, 1024 * h, 16);  // sc1: not from this CU's vector cache
+      if (256 * h + 4 * lane >= team_n) v = u32x4{kBandDone, kBandDone, kBandDone, kBandDone};
+      unsigned m1 = v[0] < v[1] ? v[0] : v[1];
+      const unsigned m2 = v[2] < v[3] ? v[2] : v[3];
+      m1 = m1 < m2 ? m1 : m2;
+      m = m < m1 ? m : m1;
+    }
     return band_wave_min(m);
   };
   auto admit = [&](unsigned gp) {
@@ -299,7 +308,7 @@ __global__ void __launch_bounds__(64 * kBandWaves) mm_numeric_f64_band(BandArgs 
     const int64_t T = tile0 + (int64_t)G.cu_per_xcd * itile;
     if (T >= tile_end) return;
     const int band = (int)(T / G.nBC), ct = (int)(T % G.nBC);
-    const int64_t* tdp = reinterpret_cast<const int64_t*>(P.descs + ((int64_t)(kBandWaves * band + wid) * G.nBC + ct));
+    const int64_t* tdp = reinterpret_cast<const int64_t*>(P.descs + ((int64_t)(WAVES * band + wid) * G.nBC + ct));
     dval = tdp[lane < 2 * kBandSlots ? lane : 2 * kBandSlots - 1];
   };
   load_descs();
@@ -325,10 +334,11 @@ __global__ void __launch_bounds__(64 * kBandWaves) mm_numeric_f64_band(BandArgs 
         if (far.w & kBandFlush) ++tile_far;
       }
       unsigned long long t0 = timing ? __builtin_amdgcn_s_memrealtime() : 0ull;
-      // (1) the A block of the next product, into the wave's other slot -- first the window: nobody fetches beyond the team's minimum + W
+      // (1) [two A slots] the A block of the next product, into the wave's other slot -- first the window: nobody fetches beyond the
+      // team's minimum + W
       const bool next_a = !(nxt.w & kBandNop) && (nxt.w & kBandNewA);
-      int nw = nb_prev;
-      if (next_a) {
+      int nw = ASL == 2 ? nb_prev : 0;
+      if (ASL == 2 && next_a) {
         admit(pos_of(nxt));
         if (timing) t0 = __builtin_amdgcn_s_memrealtime();
         const uint64_t ao = (uint64_t)nxt.a_lo | ((uint64_t)((nxt.w >> 16) & 0xffu) << 32);
@@ -340,19 +350,20 @@ __global__ void __launch_bounds__(64 * kBandWaves) mm_numeric_f64_band(BandArgs 
       unsigned newpend = 0;
       nb_prev = 0;
       if (!(far.w & kBandNop) && (window <= 0 || pos_of(far) <= seen_min + (unsigned)window)) {
-        const unsigned seq = far.s & 0xffffffu, slot = seq % (unsigned)D;
+        const unsigned seq = far.s & 0x7fffffu, slot = seq % (unsigned)D;
         const unsigned expect = band_enc(seq, 1u, 0u);
-        if (st_cas(slot, expect, band_enc(seq + D, 0u, (far.s >> 24) & 15u)) == expect) {
+        if (st_cas(slot, expect, band_enc(seq + D, 0u, (far.s >> 23) & 31u)) == expect) {
           issue_b(far, slot);
           nw += BK::PB;
           nb_prev = BK::PB;
           newpend = slot + 1u;
         }
       }
-      // (3) copies complete in order.  Issued since the A block of the CURRENT product (first thing of the previous boundary): the B copy
-      // of the previous boundary, this boundary's A and B copies.  When no more than those are in flight, the current A block has
-      // landed, and so has the B copy issued two boundaries ago: it is published now -- two products of flight time, none of it spent
-      // in this wait unless it was late
+      // (3) copies complete in order.  Two A slots: issued since the A block of the CURRENT product (first thing of the previous boundary)
+      // are the B copy of the previous boundary and this boundary's A and B copies; when no more than those are in flight, the current A
+      // block has landed, and so has the B copy issued two boundaries ago: it is published now -- two products of flight time, none of
+      // it spent in this wait unless it was late.  One A slot: the current A block was requested at the end of the previous trip, after
+      // that trip's B copy: only this trip's B copy is younger, and the previous trip's is published.
       if (nw == 0)
         dma_wait<0>();
       else if (nw == BK::PA)
@@ -361,8 +372,12 @@ __global__ void __launch_bounds__(64 * kBandWaves) mm_numeric_f64_band(BandArgs 
         dma_wait<2 * BK::PA>();
       else
         dma_wait<3 * BK::PA>();
-      if (pend2) st_or(pend2 - 1u, 16u);
-      pend2 = pend1;
+      if (ASL == 2) {
+        if (pend2) st_or(pend2 - 1u, kBandLanded);
+        pend2 = pend1;
+      } else {
+        if (pend1) st_or(pend1 - 1u, kBandLanded);
+      }
       pend1 = newpend;
       if (timing) {
         const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
@@ -371,10 +386,10 @@ __global__ void __launch_bounds__(64 * kBandWaves) mm_numeric_f64_band(BandArgs 
       }
       if (!(cur.w & kBandNop)) {
         // (4) the B block of the current product
-        const unsigned seq = cur.s & 0xffffffu, slot = seq % (unsigned)D;
-        const unsigned want = (band_enc(seq + D, 1u, 0u)) >> 4;  // this block, landed (any number of users left)
+        const unsigned seq = cur.s & 0x7fffffu, slot = seq % (unsigned)D;
+        const unsigned want = (band_enc(seq + D, 1u, 0u)) >> 5;  // this block, landed (any number of users left)
         unsigned v = st_read(slot);
-        if ((v >> 4) != want && !dead) {
+        if ((v >> 5) != want && !dead) {
           // not there yet.  A wave that waits publishes what it holds first (its own copy may be what it -- or the wave it waits for -- needs),
           // so a waiting wave never owes anything: whoever it waits for is running
           ++n_bwait;
@@ -385,14 +400,14 @@ __global__ void __launch_bounds__(64 * kBandWaves) mm_numeric_f64_band(BandArgs 
           }
           const unsigned expect = band_enc(seq, 1u, 0u);
           unsigned spins = 0;
-          while ((v >> 4) != want) {
+          while ((v >> 5) != want) {
             if (v == expect) {  // free and unclaimed: bring it in now
-              v = st_cas(slot, expect, band_enc(seq + D, 0u, (cur.s >> 24) & 15u));
+              v = st_cas(slot, expect, band_enc(seq + D, 0u, (cur.s >> 23) & 31u));
               if (v == expect) {
                 ++n_late;
                 issue_b(cur, slot);
                 dma_wait<0>();
-                st_or(slot, 16u);
+                st_or(slot, kBandLanded);
                 break;
               }
               continue;
@@ -412,15 +427,17 @@ __global__ void __launch_bounds__(64 * kBandWaves) mm_numeric_f64_band(BandArgs 
           t0 = t1;
         }
         // (5) multiply: one body per accumulator set (registers cannot be indexed)
-        const double* pa = reinterpret_cast<const double*>(ringa + aslot * BK::SA) + la;
+        const double* pa = reinterpret_cast<const double*>(ringa + (ASL == 2 ? aslot : 0) * BK::SA) + la;
         const double* pb = reinterpret_cast<const double*>(ringb + slot * BK::SB) + lb;
         switch (cur.w & 15u) {
-#define DBCSR_BAND_CASE(S_) \
-  case S_: band_multiply<M, N, K>(acc[S_], pa, pb, ktail_dead); break;
+#define DBCSR_BAND_CASE(S_)                                                             \
+  case S_:                                                                              \
+    if constexpr (S_ < SLOTS - 1) band_multiply<M, N, K>(acc[S_], pa, pb, ktail_dead);  \
+    break;
           DBCSR_BAND_CASE(0) DBCSR_BAND_CASE(1) DBCSR_BAND_CASE(2) DBCSR_BAND_CASE(3) DBCSR_BAND_CASE(4) DBCSR_BAND_CASE(5)
           DBCSR_BAND_CASE(6) DBCSR_BAND_CASE(7)
 #undef DBCSR_BAND_CASE
-          default: band_multiply<M, N, K>(acc[8], pa, pb, ktail_dead); break;
+          default: band_multiply<M, N, K>(acc[SLOTS - 1], pa, pb, ktail_dead); break;
         }
         // (6) last product of this wave with the block: one user less
         if (cur.w & kBandLastB) st_add(slot, 0xffffffffu);
@@ -430,10 +447,10 @@ __global__ void __launch_bounds__(64 * kBandWaves) mm_numeric_f64_band(BandArgs 
         // end of a tile: write the sub-tile's C blocks (staged in the A slot of the last product: its fragments have been read) and
         // go on with the next tile of the workgroup -- the other waves may still be in this one
         const unsigned long long t_e0 = timing ? __builtin_amdgcn_s_memrealtime() : 0ull;
-        char* stage = ringa + aslot * BK::SA;
+        char* stage = ringa + (ASL == 2 ? aslot : 0) * BK::SA;
         const unsigned dlo = (unsigned)dval, dhi = (unsigned)((uint64_t)dval >> 32);
 #pragma unroll
-        for (int sl = 0; sl < kBandSlots; ++sl) {
+        for (int sl = 0; sl < SLOTS; ++sl) {
           const int64_t c_off = (int64_t)(((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)dhi, sl) << 32) | (unsigned)__builtin_amdgcn_readlane((int)dlo, sl));
           const int64_t cin_off = (int64_t)(((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)dhi, kBandSlots + sl) << 32) |
                                             (unsigned)__builtin_amdgcn_readlane((int)dlo, kBandSlots + sl));
@@ -447,7 +464,15 @@ __global__ void __launch_bounds__(64 * kBandWaves) mm_numeric_f64_band(BandArgs 
         load_descs();
         if (timing) t_epi += __builtin_amdgcn_s_memrealtime() - t_e0;
       }
-      if (next_a) aslot ^= 1;
+      if (ASL == 2) {
+        if (next_a) aslot ^= 1;
+      } else if (next_a) {
+        // (7) [one A slot] the fragments of the current product have been read (its MFMAs were issued), a tile's C blocks have left the
+        // slot: request the next product's A block now -- the other waves of the SIMD multiply meanwhile
+        admit(pos_of(nxt));
+        const uint64_t ao = (uint64_t)nxt.a_lo | ((uint64_t)((nxt.w >> 16) & 0xffu) << 32);
+        dma_block<BK::ABYTES>(P.a_data + ao, ringa_lds, voff);
+      }
       cur = nxt;
       nxt = far;
     }
@@ -507,14 +532,25 @@ __global__ void __launch_bounds__(256) band_remainder(int64_t nsub, const BandDe
   }
 }
 
-// ring depths the kernel is built for (LDS: 512 + D x 4240 + 67840 + 1024 bytes for 23 x 23 blocks; 160 KB per CU)
+bool band_shape(int shape, int* waves, int* tr, int* tc) {
+  switch (shape) {
+    case 0: *waves = 8, *tr = 3, *tc = 3; return true;
+    case 1: *waves = 16, *tr = 2, *tc = 2; return true;
+    default: return false;
+  }
+}
+// (WAVES, TR, TC, ASL) of the shapes, as template arguments
+#define DBCSR_BAND_SHAPE0 8, 3, 3, 2
+#define DBCSR_BAND_SHAPE1 16, 2, 2, 1
+
+// ring depths the kernel is built for (LDS: 512 + D x 4240 + 67840 + 1024 bytes for 23 x 23 blocks in both shapes; 160 KB per CU)
 #define DBCSR_AMD_BAND_DEPTHS(X, S_) X(S_, 12) X(S_, 16) X(S_, 20) X(S_, 22)
 
-int band_lds_bytes(int m, int n, int k, int depth) {
-  if (m != n || m != k) return 0;
+int band_lds_bytes(int m, int n, int k, int shape, int depth) {
+  if (m != n || m != k || (shape != 0 && shape != 1)) return 0;
   switch (m) {
 #define DBCSR_BAND_LDS_D(S_, D_) \
-  if (depth == D_) return BandKernel<S_, S_, S_, D_>::LDS;
+  if (depth == D_) return shape == 1 ? BandKernel<S_, S_, S_, D_, 16, 1>::LDS : BandKernel<S_, S_, S_, D_, 8, 2>::LDS;
 #define DBCSR_BAND_LDS(S_)                           \
   case S_:                                           \
     DBCSR_AMD_BAND_DEPTHS(DBCSR_BAND_LDS_D, S_)      \
@@ -526,24 +562,27 @@ int band_lds_bytes(int m, int n, int k, int depth) {
   }
 }
 
-template <int S_, int D_, int BPOL>
+template <int S_, int D_, int BPOL, int WAVES, int TR, int TC, int ASL>
 static int band_launch_one(unsigned nwg, hipStream_t st, const BandArgs& P) {
-  typedef BandKernel<S_, S_, S_, D_> BK;
+  typedef BandKernel<S_, S_, S_, D_, WAVES, ASL> BK;
   static bool attr = false;
   if (!attr) {  // more than 64 KB of dynamic LDS needs the attribute, once per kernel
-    ACC_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(mm_numeric_f64_band<S_, S_, S_, D_, BPOL>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  BK::LDS));
+    ACC_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(mm_numeric_f64_band<S_, S_, S_, D_, BPOL, WAVES, TR, TC, ASL>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, BK::LDS));
     attr = true;
   }
-  hipLaunchKernelGGL((mm_numeric_f64_band<S_, S_, S_, D_, BPOL>), dim3(nwg), dim3(64 * kBandWaves), BK::LDS, st, P);
+  hipLaunchKernelGGL((mm_numeric_f64_band<S_, S_, S_, D_, BPOL, WAVES, TR, TC, ASL>), dim3(nwg), dim3(64 * WAVES), BK::LDS, st, P);
   return check(hipGetLastError(), "mm_numeric_f64_band", __FILE__, __LINE__);
 }
 
-int band_launch(int m, int n, int k, int depth, int bpol, unsigned nwg, hipStream_t st, const BandArgs& P) {
+int band_launch(int m, int n, int k, int shape, int depth, int bpol, unsigned nwg, hipStream_t st, const BandArgs& P) {
   if (m != n || m != k) return 1;
   switch (m) {
-#define DBCSR_BAND_LAUNCH_D(S_, D_) \
-  if (depth == D_) return bpol == 1 ? band_launch_one<S_, D_, 1>(nwg, st, P) : band_launch_one<S_, D_, 0>(nwg, st, P);
+#define DBCSR_BAND_LAUNCH_D(S_, D_)                                                                                                         \
+  if (depth == D_) {                                                                                                                        \
+    if (shape == 1) return bpol == 1 ? band_launch_one<S_, D_, 1, DBCSR_BAND_SHAPE1>(nwg, st, P) : band_launch_one<S_, D_, 0, DBCSR_BAND_SHAPE1>(nwg, st, P); \
+    return bpol == 1 ? band_launch_one<S_, D_, 1, DBCSR_BAND_SHAPE0>(nwg, st, P) : band_launch_one<S_, D_, 0, DBCSR_BAND_SHAPE0>(nwg, st, P);           \
+  }
 #define DBCSR_BAND_LAUNCH(S_)                        \
   case S_:                                           \
     DBCSR_AMD_BAND_DEPTHS(DBCSR_BAND_LAUNCH_D, S_)   \

@@ -22,20 +22,20 @@ __device__ __forceinline__ void band_owner(const BandGeom& G, int T, int* g, int
 }
 
 // one lane per (sub-tile, slot): offsets of the slot's C block, product count of the sub-tile.  Sub-tile (8 band + w, ct) holds the C
-// blocks (rows[24 band + 3 w + ti], cols[3 ct + tj]).
+// blocks (rows[tr (waves band + w) + ti], cols[tc ct + tj]).
 __global__ void __launch_bounds__(256) band_descs(BandGeom G, const int* __restrict__ rows, const int* __restrict__ cols,
                                                   const uint32_t* __restrict__ c_bm, const int* __restrict__ c_pre, const int* __restrict__ c_row_p,
                                                   int W, const Desc* __restrict__ descs, BandDesc* __restrict__ bd, int* __restrict__ sub_cnt) {
   const int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;  // 16 lanes per sub-tile, one per slot
   const int s = threadIdx.x & 15;
-  const int64_t nsub = (int64_t)kBandWaves * G.nBR * G.nBC;
+  const int64_t nsub = (int64_t)G.waves * G.nBR * G.nBC;
   if (t >= nsub) return;
   const int tr = (int)(t / G.nBC), tc = (int)(t % G.nBC);
   int cnt = 0;
   int64_t c_off = -1, cin_off = -1;
   if (s < kBandSlots) {
-    const int ri = kBandT * tr + s / kBandT, ci = kBandT * tc + s % kBandT;
-    if (ri < G.nfr && ci < G.nfc) {
+    const int ri = G.tr * tr + s / G.tc, ci = G.tc * tc + s % G.tc;
+    if (s < G.tr * G.tc && ri < G.nfr && ci < G.nfc) {
       const int i = rows[ri], j = cols[ci];
       const uint32_t cw = c_bm[(size_t)i * W + (j >> 5)];
       if ((cw >> (j & 31)) & 1u) {
@@ -68,20 +68,22 @@ band_lists(BandGeom G, const int* __restrict__ rows, const int* __restrict__ col
            int* __restrict__ err) {
   const int lane = threadIdx.x & 63;
   const int64_t u = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (u >= (int64_t)G.ntiles * kBandWaves) return;
-  const int T = (int)(u / kBandWaves), w = (int)(u % kBandWaves);
+  if (u >= (int64_t)G.ntiles * G.waves) return;
+  const int T = (int)(u / G.waves), w = (int)(u % G.waves);
+  const int band_rows = G.waves * G.tr;
   const int band = T / G.nBC, ct = T % G.nBC;
   int g, it;
   band_owner(G, T, &g, &it);
-  const int64_t pl = (int64_t)(g * kBandWaves + w) * G.max_i + it;  // this list, in processing order
+  const int64_t pl = (int64_t)(g * G.waves + w) * G.max_i + it;  // this list, in processing order
   const int64_t ps = (int64_t)g * G.max_i + it;                     // this tile, in processing order
-  const int64_t sub = (int64_t)(kBandWaves * band + w) * G.nBC + ct;
-  int cj[kBandT], ri[kBandT];
+  const int64_t sub = (int64_t)(G.waves * band + w) * G.nBC + ct;
+  int cj[kBandMaxT], ri[kBandMaxT];
 #pragma unroll
-  for (int q = 0; q < kBandT; ++q) {
-    cj[q] = kBandT * ct + q < G.nfc ? cols[kBandT * ct + q] : -1;
-    ri[q] = kBandRows * band + kBandT * w + q < G.nfr ? rows[kBandRows * band + kBandT * w + q] : -1;
+  for (int q = 0; q < kBandMaxT; ++q) {
+    cj[q] = (q < G.tc && G.tc * ct + q < G.nfc) ? cols[G.tc * ct + q] : -1;
+    ri[q] = (q < G.tr && band_rows * band + G.tr * w + q < G.nfr) ? rows[band_rows * band + G.tr * w + q] : -1;
   }
+  const unsigned trmask = (1u << G.tr) - 1u;
   int64_t pos = 0, rpos = 0;
   unsigned seq = 0;
   if (FILL) {
@@ -93,20 +95,19 @@ band_lists(BandGeom G, const int* __restrict__ rows, const int* __restrict__ col
   for (int k0 = 0; k0 < nbk; k0 += 64) {
     const int k = k0 + lane;
     const bool kin = k < nbk;
-    unsigned am24 = 0, bm = 0;
-#pragma unroll
-    for (int r = 0; r < kBandRows; ++r) {
-      const int rr = kBandRows * band + r;
+    unsigned am24 = 0, bm = 0;  // (am24: the rows of the whole tile, at most 32)
+    for (int r = 0; r < band_rows; ++r) {
+      const int rr = band_rows * band + r;
       const int row = rr < G.nfr ? rows[rr] : -1;  // (wave-uniform)
       const uint32_t word = (kin && row >= 0) ? a_bm[(size_t)row * Wk + (k >> 5)] : 0u;
       am24 |= ((word >> (k & 31)) & 1u) << r;
     }
 #pragma unroll
-    for (int q = 0; q < kBandT; ++q) {
+    for (int q = 0; q < kBandMaxT; ++q) {
       const uint32_t word = (kin && cj[q] >= 0) ? bt_bm[(size_t)cj[q] * Wk + (k >> 5)] : 0u;
       bm |= ((word >> (k & 31)) & 1u) << q;
     }
-    const unsigned amw = (am24 >> (kBandT * w)) & 7u;
+    const unsigned amw = (am24 >> (G.tr * w)) & trmask;
     const int ks = kin ? k_sizes[k] : 0;
     const bool main = ks == K;
     const int nbl = (main && am24 != 0u) ? __popc(bm) : 0;  // B copies of the tile at this k
@@ -120,11 +121,10 @@ band_lists(BandGeom G, const int* __restrict__ rows, const int* __restrict__ col
     }
     if (FILL && np > 0) {
       unsigned users = 0;
+      for (int q = 0; q < G.waves; ++q) users += ((am24 >> (G.tr * q)) & trmask) != 0u;
+      int64_t boff[kBandMaxT];
 #pragma unroll
-      for (int q = 0; q < kBandWaves; ++q) users += ((am24 >> (kBandT * q)) & 7u) != 0u;
-      int64_t boff[kBandT];
-#pragma unroll
-      for (int q = 0; q < kBandT; ++q) {
+      for (int q = 0; q < kBandMaxT; ++q) {
         boff[q] = 0;
         if ((bm >> q) & 1u) {
           const int j = cj[q];
@@ -136,7 +136,7 @@ band_lists(BandGeom G, const int* __restrict__ rows, const int* __restrict__ col
       const unsigned sq = seq + (unsigned)(inc_b - my_b);
       const int last_ti = 31 - __clz((int)amw);
 #pragma unroll
-      for (int ti = 0; ti < kBandT; ++ti) {
+      for (int ti = 0; ti < kBandMaxT; ++ti) {
         if (!((amw >> ti) & 1u)) continue;
         const int row = ri[ti];
         const uint32_t aw = a_bm[(size_t)row * Wk + (k >> 5)];
@@ -144,18 +144,18 @@ band_lists(BandGeom G, const int* __restrict__ rows, const int* __restrict__ col
         bool first = true;
         unsigned jj = 0;
 #pragma unroll
-        for (int tj = 0; tj < kBandT; ++tj) {
+        for (int tj = 0; tj < kBandMaxT; ++tj) {
           if (!((bm >> tj) & 1u)) continue;
           const int64_t b = boff[tj];
           const uint32_t hi = ((uint32_t)(((uint64_t)a >> 32) & 0xffu) << 16) | ((uint32_t)(((uint64_t)b >> 32) & 0xffu) << 24);
-          const uint32_t slot = (uint32_t)(kBandT * ti + tj);
+          const uint32_t slot = (uint32_t)(G.tc * ti + tj);
           if (main) {
             BandEntry e;
             e.a_lo = (uint32_t)a;
             e.b_lo = (uint32_t)b;
             const uint32_t kq = (uint32_t)(k >> G.kshift);
             e.w = slot | (first ? kBandNewA : 0u) | (ti == last_ti ? kBandLastB : 0u) | ((kq & 255u) << 8) | hi;
-            e.s = ((sq + jj) & 0xffffffu) | (users << 24) | ((kq >> 8) << 28);
+            e.s = ((sq + jj) & 0x7fffffu) | (users << 23) | ((kq >> 8) << 28);
             entries[at++] = e;
           } else {
             BandRem e;

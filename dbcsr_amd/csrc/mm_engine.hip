@@ -268,8 +268,9 @@ struct Engine {
   // DBCSR_AMD_MM_BAND_DEPTH = slots of the ring (12 | 16 | 20 | 22); DBCSR_AMD_MM_BAND_BPOL = 1: B copies with the nt hint;
   // DBCSR_AMD_MM_BAND_KNOBS bit 0: where the waves' time goes (printed by dbcsr_amd_mm_band_stats)
   // DBCSR_AMD_MM_BAND_WINDOW = k window of an XCD's waves (inner blocks; 0: no throttle)
-  int use_band = 0, band_depth = 20, band_bpol = 0, band_knobs = 0, band_window = 96;
-  BandGeom band_geom = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  // DBCSR_AMD_MM_BAND_SHAPE: 0 = 8 waves x (3 x 3 C blocks), 1 = 16 waves x (2 x 2)
+  int use_band = 0, band_shape = 1, band_depth = 20, band_bpol = 0, band_knobs = 0, band_window = 384;
+  BandGeom band_geom = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   DevBuf<unsigned> band_prog;
   int64_t band_nlist = 0, band_nrem = 0;
   DevBuf<BandDesc> band_descs_buf;
@@ -496,13 +497,13 @@ static int run_band_f64(Engine* E, hipStream_t st, const dbcsr_amd_bcsr* a, cons
     ACC_CHECK(hipGetDevice(&dev));
     ACC_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
   }
-  if (band_lds_bytes(S_, S_, S_, E->band_depth) == 0) return 1;
+  if (band_lds_bytes(S_, S_, S_, E->band_shape, E->band_depth) == 0) return 1;
   BandGeom G;
   G.nfr = E->hot_cnt_m;
   G.nfc = E->hot_cnt_n;
-  if (G.nfr <= 0 || G.nfc <= 0) return 1;
-  G.nBR = (G.nfr + kBandRows - 1) / kBandRows;
-  G.nBC = (G.nfc + kBandT - 1) / kBandT;
+  if (G.nfr <= 0 || G.nfc <= 0 || !band_shape(E->band_shape, &G.waves, &G.tr, &G.tc)) return 1;
+  G.nBR = (G.nfr + G.waves * G.tr - 1) / (G.waves * G.tr);
+  G.nBC = (G.nfc + G.tc - 1) / G.tc;
   if ((int64_t)G.nBR * G.nBC > 0x3fffffff) return 1;
   G.ntiles = G.nBR * G.nBC;
   G.cu_per_xcd = std::min(32, std::max(1, n_cu / 8));
@@ -513,11 +514,11 @@ static int run_band_f64(Engine* E, hipStream_t st, const dbcsr_amd_bcsr* a, cons
   G.kspan = (nbk >> G.kshift) + 1;
   if ((int64_t)(G.max_i + 1) * G.kspan >= 0x7ff00000ll) return 1;  // sweep positions would overflow: not a band case
   const int nwg = 8 * G.cu_per_xcd;
-  const int64_t nsub = (int64_t)kBandWaves * G.ntiles, npl = (int64_t)nwg * kBandWaves * G.max_i, nps = (int64_t)nwg * G.max_i;
-  const bool reuse = E->plan_hit && E->plan_numeric && E->band_built;
-  if (E->band_flags.ensure(4) || E->band_prog.ensure(8 * 256)) return -1;
+  const int64_t nsub = (int64_t)G.waves * G.ntiles, npl = (int64_t)nwg * G.waves * G.max_i, nps = (int64_t)nwg * G.max_i;
+  const bool reuse = E->plan_hit && E->plan_numeric && E->band_built && E->band_geom.waves == G.waves && E->band_geom.ntiles == G.ntiles;
+  if (E->band_flags.ensure(4) || E->band_prog.ensure(8 * 512)) return -1;
   ACC_CHECK(hipMemsetAsync(E->band_flags.p, 0, sizeof(int) * 4, st));
-  ACC_CHECK(hipMemsetAsync(E->band_prog.p, 0, sizeof(unsigned) * 8 * 256, st));
+  ACC_CHECK(hipMemsetAsync(E->band_prog.p, 0, sizeof(unsigned) * 8 * 512, st));
   if (!reuse) {
     E->band_built = false;
     if (E->a_bm.ensure((size_t)nbr * Wk + 1) || E->a_pre.ensure((size_t)nbr * Wk + 1) || E->bt_bm.ensure((size_t)nbc * Wk + 1) ||
@@ -553,7 +554,7 @@ static int run_band_f64(Engine* E, hipStream_t st, const dbcsr_amd_bcsr* a, cons
     E->band_nlist = E->host_scalars[8];
     E->band_nrem = E->host_scalars[9];
     const int max_seq = *reinterpret_cast<const int*>(E->host_scalars + 10);
-    if (max_seq >= (1 << 24) - 64) return 1;  // the entries carry 24 bits of the sequence number: not a band case
+    if (max_seq >= (1 << 23) - 64) return 1;  // the entries carry 23 bits of the sequence number: not a band case
     if (E->band_entries.ensure((size_t)E->band_nlist + 1) || E->band_rem.ensure((size_t)E->band_nrem + 1)) return -1;
     hipLaunchKernelGGL((band_lists<true>), grid_for(nsub * 64), dim3(256), 0, st, G, E->tile_rows.p, E->tile_cols.p, nbk, Wk, E->a_bm.p, E->a_pre.p,
                        a->row_p, a->blk_p, E->bt_bm.p, W, E->b_bm.p, E->b_pre.p, b->row_p, b->blk_p, a->col_blk_size, S_, (int*)nullptr,
@@ -584,7 +585,7 @@ static int run_band_f64(Engine* E, hipStream_t st, const dbcsr_amd_bcsr* a, cons
     P.times = E->band_times.p;
   }
   ACC_CHECK(hipEventRecord(E->ev[1], st));  // the timed numeric launch starts here (the index work above counts as fill time)
-  if (band_launch(S_, S_, S_, E->band_depth, E->band_bpol, (unsigned)nwg, st, P)) return -1;
+  if (band_launch(S_, S_, S_, E->band_shape, E->band_depth, E->band_bpol, (unsigned)nwg, st, P)) return -1;
   if (E->band_nrem > 0 &&
       band_launch_remainder(S_, S_, st, nsub, E->band_descs_buf.p, E->band_rem_start.p, E->band_rem.p, P.a_data, P.b_data, P.c_out, alpha))
     return -1;
@@ -643,6 +644,7 @@ int dbcsr_amd_mm_create(void** handle) {
   if (const char* k = getenv("DBCSR_AMD_MM_BAND_BPOL")) E->band_bpol = atoi(k) == 1 ? 1 : 0;
   if (const char* k = getenv("DBCSR_AMD_MM_BAND_KNOBS")) E->band_knobs = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_BAND_WINDOW")) E->band_window = atoi(k);
+  if (const char* k = getenv("DBCSR_AMD_MM_BAND_SHAPE")) E->band_shape = atoi(k) == 0 ? 0 : 1;
   if (const char* k = getenv("DBCSR_AMD_MM_HOT")) E->use_hot = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_TINY")) E->use_tiny = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_LDS_PAD")) E->lds_pad = atoi(k);
@@ -1765,10 +1767,10 @@ int dbcsr_amd_mm_band_stats(void* handle, int* waits_gave_up, int* list_mismatch
     fprintf(stderr,
             "dbcsr_amd band kernel, mean per wave [ms]: total %.3f = window waits %.3f + issue and waits for A %.3f + waits for B %.3f + multiplies %.3f + "
             "epilogues %.3f + rest %.3f (%llu waves; %llu of %lld products waited for their B block, %llu fetched it themselves at the last moment; %llu "
-            "fetches waited for the window, %llu reads of the team's counters, %d waves switched the throttle off; %lld list entries, ring of %d, window %d)\n",
+            "fetches waited for the window, %llu reads of the team's counters, %d waves switched the throttle off; %lld list entries, shape %d, ring of %d, window %d)\n",
             t[0] / w * 1e-5, t[8] / w * 1e-5, t[1] / w * 1e-5, t[2] / w * 1e-5, t[3] / w * 1e-5, t[4] / w * 1e-5,
             ((double)t[0] - t[1] - t[2] - t[3] - t[4] - t[8]) / w * 1e-5, t[5], t[7], (long long)E->nproducts, t[6], t[9], t[10], h[3], (long long)E->band_nlist,
-            E->band_depth, E->band_window);
+            E->band_shape, E->band_depth, E->band_window);
   }
   return 0;
 }

@@ -22,7 +22,7 @@ MANY = (23 * 170 + 16, 23 * 150 + 16, 23 * 160 + 16, 0.9, 0.9, 0.9, [1, 23], [1,
 TAILS = (23 * 40 + 16 + 7, 23 * 44 + 9, 23 * 42 + 16 + 5, 0.7, 0.7, 0.8, [20, 23, 1, 16, 1, 7], [22, 23, 1, 9], [21, 23, 1, 16, 1, 5])
 WIDE = (23 * 30, 23 * 40, 23 * 700, 0.85, 0.85, 0.9, [1, 23], [1, 23], [1, 23])                      # 2 bands x 234 column triples: long sweeps per workgroup
 
-ENV_KEYS = ("DBCSR_AMD_MM_BAND", "DBCSR_AMD_MM_BAND_WINDOW", "DBCSR_AMD_MM_BAND_DEPTH", "DBCSR_AMD_MM_BAND_BPOL", "DBCSR_AMD_MM_BAND_KNOBS", "DBCSR_AMD_MM_TILE", "DBCSR_AMD_MM_KERNEL",
+ENV_KEYS = ("DBCSR_AMD_MM_BAND", "DBCSR_AMD_MM_BAND_SHAPE", "DBCSR_AMD_MM_BAND_WINDOW", "DBCSR_AMD_MM_BAND_DEPTH", "DBCSR_AMD_MM_BAND_BPOL", "DBCSR_AMD_MM_BAND_KNOBS", "DBCSR_AMD_MM_TILE", "DBCSR_AMD_MM_KERNEL",
             "DBCSR_AMD_MM_HOT", "DBCSR_AMD_MM_CLASSES", "DBCSR_AMD_MM_DBG", "DBCSR_AMD_MM_WG_WAVES", "DBCSR_AMD_MM_HOT_PERSISTENT")
 
 
@@ -51,31 +51,40 @@ def run(monkeypatch, env, case, alpha=0.7, beta=1.3, reps=1):
         assert rel_err(out.data, ref.data) <= 1e-10
 
 
+# shape 0: 8 waves per workgroup, 3 x 3 C blocks per wave, two A slots; shape 1: 16 waves, 2 x 2, one A slot (mm_band.h)
+SHAPES = ["0", "1"]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
 @pytest.mark.parametrize("case", [H2O, DENSE, SPARSE_C, MANY, TAILS, WIDE], ids=["h2o", "dense", "sparse_c", "many_tiles", "tails", "wide"])
-def test_band_kernel_matches_oracle(monkeypatch, case):
-    run(monkeypatch, {}, case)
+def test_band_kernel_matches_oracle(monkeypatch, case, shape):
+    run(monkeypatch, {"DBCSR_AMD_MM_BAND_SHAPE": shape}, case)
 
 
+@pytest.mark.parametrize("shape", SHAPES)
 @pytest.mark.parametrize("depth", ["12", "16", "20", "22"])
-def test_band_kernel_any_ring_depth(monkeypatch, depth):
-    run(monkeypatch, {"DBCSR_AMD_MM_BAND_DEPTH": depth}, MANY)
-    run(monkeypatch, {"DBCSR_AMD_MM_BAND_DEPTH": depth}, DENSE)
+def test_band_kernel_any_ring_depth(monkeypatch, depth, shape):
+    run(monkeypatch, {"DBCSR_AMD_MM_BAND_DEPTH": depth, "DBCSR_AMD_MM_BAND_SHAPE": shape}, MANY)
+    run(monkeypatch, {"DBCSR_AMD_MM_BAND_DEPTH": depth, "DBCSR_AMD_MM_BAND_SHAPE": shape}, DENSE)
 
 
+@pytest.mark.parametrize("shape", SHAPES)
 @pytest.mark.parametrize("window", ["0", "1", "8", "64", "100000"])
-def test_band_kernel_any_window(monkeypatch, window):
+def test_band_kernel_any_window(monkeypatch, window, shape):
     # the k window of an XCD's waves is a speed knob: a window of one inner block serialises them, none lets every wave run free
-    run(monkeypatch, {"DBCSR_AMD_MM_BAND_WINDOW": window}, MANY)
-    run(monkeypatch, {"DBCSR_AMD_MM_BAND_WINDOW": window}, SPARSE_C)
+    run(monkeypatch, {"DBCSR_AMD_MM_BAND_WINDOW": window, "DBCSR_AMD_MM_BAND_SHAPE": shape}, MANY)
+    run(monkeypatch, {"DBCSR_AMD_MM_BAND_WINDOW": window, "DBCSR_AMD_MM_BAND_SHAPE": shape}, SPARSE_C)
 
 
-def test_band_kernel_streaming_b_copies_and_timing_knob(monkeypatch):
-    run(monkeypatch, {"DBCSR_AMD_MM_BAND_BPOL": "1"}, MANY)
-    run(monkeypatch, {"DBCSR_AMD_MM_BAND_KNOBS": "1"}, H2O)
+@pytest.mark.parametrize("shape", SHAPES)
+def test_band_kernel_streaming_b_copies_and_timing_knob(monkeypatch, shape):
+    run(monkeypatch, {"DBCSR_AMD_MM_BAND_BPOL": "1", "DBCSR_AMD_MM_BAND_SHAPE": shape}, MANY)
+    run(monkeypatch, {"DBCSR_AMD_MM_BAND_KNOBS": "1", "DBCSR_AMD_MM_BAND_SHAPE": shape}, H2O)
 
 
-def test_band_kernel_plan_reuse(monkeypatch):
-    run(monkeypatch, {}, MANY, reps=3)
+@pytest.mark.parametrize("shape", SHAPES)
+def test_band_kernel_plan_reuse(monkeypatch, shape):
+    run(monkeypatch, {"DBCSR_AMD_MM_BAND_SHAPE": shape}, MANY, reps=3)
 
 
 def test_band_kernel_beta_zero_and_new_c(monkeypatch):

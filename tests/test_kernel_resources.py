@@ -75,3 +75,7 @@ def test_no_scratch_and_exact_kernels_keep_their_occupancy(tmp_path):
     tile = {pretty[n]: k["vgpr_count"] for n, k in ks.items() if "mm_numeric_f64_tile<" in pretty[n]}
     wg_waves = lambda n: int(re.search(r"tile<\d+, \d+, \d+, \d+, \d+, \d+, (\d+),", n).group(1))
     assert tile and all(v <= (256 if wg_waves(n) == 8 else 512) for n, v in tile.items()), tile
+    # the band kernels (mm_band.hip): 8 waves per workgroup (two per SIMD) in 256 registers, 16 waves (four per SIMD) in 128
+    band = {pretty[n]: k["vgpr_count"] for n, k in ks.items() if "mm_numeric_f64_band<" in pretty[n]}
+    band_waves = lambda n: int(re.search(r"band<\d+, \d+, \d+, \d+, \d+, (\d+),", n).group(1))
+    assert band and all(v <= (256 if band_waves(n) == 8 else 128) for n, v in band.items()), band
