@@ -430,14 +430,14 @@ __global__ void __launch_bounds__(64 * WAVES) mm_numeric_f64_band(BandArgs P) {
         const double* pa = reinterpret_cast<const double*>(ringa + (ASL == 2 ? aslot : 0) * BK::SA) + la;
         const double* pb = reinterpret_cast<const double*>(ringb + slot * BK::SB) + lb;
         switch (cur.w & 15u) {
-#define DBCSR_BAND_CASE(S_)                                                             \
-  case S_:                                                                              \
-    if constexpr (S_ < SLOTS - 1) band_multiply<M, N, K>(acc[S_], pa, pb, ktail_dead);  \
+#define DBCSR_BAND_CASE(S_)                                                         \
+  case S_:                                                                          \
+    if constexpr (S_ < SLOTS) band_multiply<M, N, K>(acc[S_], pa, pb, ktail_dead);  \
     break;
           DBCSR_BAND_CASE(0) DBCSR_BAND_CASE(1) DBCSR_BAND_CASE(2) DBCSR_BAND_CASE(3) DBCSR_BAND_CASE(4) DBCSR_BAND_CASE(5)
-          DBCSR_BAND_CASE(6) DBCSR_BAND_CASE(7)
+          DBCSR_BAND_CASE(6) DBCSR_BAND_CASE(7) DBCSR_BAND_CASE(8)
 #undef DBCSR_BAND_CASE
-          default: band_multiply<M, N, K>(acc[SLOTS - 1], pa, pb, ktail_dead); break;
+          default: break;
         }
         // (6) last product of this wave with the block: one user less
         if (cur.w & kBandLastB) st_add(slot, 0xffffffffu);
