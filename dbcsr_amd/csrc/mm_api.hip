@@ -33,6 +33,7 @@ struct Owned {
     m.blk_p = nullptr;
     m.data = nullptr;
     m.nblks = 0;
+    m.index_stamp = 0;
   }
   void release() {
     if (!live) return;

@@ -257,6 +257,7 @@ struct Engine {
   // synchronisation): for callers that own their operands' index and never write it in place
   bool plan_trusted = false;
   const void* plan_ptrs[12] = {nullptr};
+  uint64_t plan_stamps[3] = {0, 0, 0};  // index_stamp of A, B, C_in when the plan was saved (0: unknown generation, never trusted)
   DevBuf<int32_t> plan_words, plan_c_col_i;
   DevBuf<int64_t> plan_c_blk_p;
   DevBuf<int> plan_flag;
@@ -353,7 +354,9 @@ static int plan_matches(Engine* E, const dbcsr_amd_bcsr* a, const dbcsr_amd_bcsr
   const void* ptr[12];
   long long n[12];
   plan_segments(a, b, c_in, ptr, n);
-  if (E->plan_trusted) {
+  if (E->plan_trusted && a->index_stamp && b->index_stamp && c_in->index_stamp && a->index_stamp == E->plan_stamps[0] &&
+      b->index_stamp == E->plan_stamps[1] && c_in->index_stamp == E->plan_stamps[2]) {
+    // same generation of the same arrays: the address test only guards against a caller that stamps carelessly
     bool same = true;
     for (int i = 0; i < 12; ++i) same = same && ptr[i] == E->plan_ptrs[i];
     if (same) return 1;
@@ -400,6 +403,7 @@ static int plan_save(Engine* E, const dbcsr_amd_bcsr* a, const dbcsr_amd_bcsr* b
   E->plan_canonical = E->canonical_c;
   E->plan_counts = counts;
   for (int i = 0; i < 12; ++i) E->plan_ptrs[i] = ptr[i];
+  E->plan_stamps[0] = a->index_stamp, E->plan_stamps[1] = b->index_stamp, E->plan_stamps[2] = c_in->index_stamp;
   E->plan_saved = true;
   return 0;
 }

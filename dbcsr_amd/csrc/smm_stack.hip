@@ -13,6 +13,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <map>
 #include <mutex>
 
@@ -403,22 +404,38 @@ __global__ void __launch_bounds__(256) smm_stack_f64_mixed(const int* __restrict
 }
 
 // device copy of the host records, one buffer per stream (calls on one stream are ordered; the host calls from several OpenMP
-// threads with their own streams)
+// threads with their own streams), and a PINNED staging buffer of the library's own next to it: the host reuses its stack right
+// after the call returns, and only a copy from pageable memory has read its source by then -- a host that pins or registers its
+// stack buffers (the reference pins stackbuf%hostmem; a CP2K build may hipHostRegister) would get a truly asynchronous copy and
+// silently wrong products.  So the records are copied on the host into the staging buffer first; an event says when the device
+// has taken them over from there.
 struct MixedScratch {
   std::mutex mu;
-  std::map<hipStream_t, std::pair<int*, size_t>> buf;  // stream -> (device buffer, capacity in ints)
-  int* get(hipStream_t st, size_t nints) {
+  struct Slot {
+    int* dev = nullptr;
+    int* pinned = nullptr;
+    size_t cap = 0;  // ints
+    hipEvent_t taken = nullptr;
+    bool pending = false;
+  };
+  std::map<hipStream_t, Slot> buf;
+  Slot* get(hipStream_t st, size_t nints) {
     std::lock_guard<std::mutex> lk(mu);
-    auto& e = buf[st];
-    if (e.second < nints) {
-      if (e.first) (void)hipFree(e.first);  // (hipFree waits for the device: the old buffer is no longer in use)
-      e.first = nullptr;
-      e.second = 0;
+    Slot& e = buf[st];
+    if (!e.taken && hipEventCreateWithFlags(&e.taken, hipEventDisableTiming) != hipSuccess) return nullptr;
+    if (e.cap < nints) {
+      if (e.pending) (void)hipEventSynchronize(e.taken);
+      e.pending = false;
+      if (e.dev) (void)hipFree(e.dev);  // (hipFree waits for the device: the old buffer is no longer in use)
+      if (e.pinned) (void)hipHostFree(e.pinned);
+      e.dev = e.pinned = nullptr;
+      e.cap = 0;
       const size_t want = nints + nints / 4 + 1024;
-      if (hipMalloc(reinterpret_cast<void**>(&e.first), want * sizeof(int)) != hipSuccess) return nullptr;
-      e.second = want;
+      if (hipMalloc(reinterpret_cast<void**>(&e.dev), want * sizeof(int)) != hipSuccess) return nullptr;
+      if (hipHostMalloc(reinterpret_cast<void**>(&e.pinned), want * sizeof(int), hipHostMallocDefault) != hipSuccess) return nullptr;
+      e.cap = want;
     }
-    return e.first;
+    return &e;  // (std::map nodes do not move: the pointer stays valid; one stream is used by one host thread at a time)
   }
 };
 static MixedScratch g_mixed;
@@ -426,12 +443,14 @@ static MixedScratch g_mixed;
 int process_stack_f64_mixed(const int* host_params, int nstack, const double* a, const double* b, double* c, int max_dim, hipStream_t st) {
   if (nstack <= 0) return 0;
   if (!host_params) return -1;
-  int* dev = g_mixed.get(st, (size_t)7 * nstack);
-  if (!dev) return -1;
-  // (the records live in ordinary host memory that the host reuses after this call: a copy from pageable memory has read its
-  // source when the call returns)
-  ACC_CHECK(hipMemcpyAsync(dev, host_params, sizeof(int) * 7 * (size_t)nstack, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(smm_stack_f64_mixed, dim3((nstack + 3) / 4), dim3(256), 0, st, dev, nstack, a, b, c, max_dim);
+  MixedScratch::Slot* e = g_mixed.get(st, (size_t)7 * nstack);
+  if (!e) return -1;
+  if (e->pending) ACC_CHECK(hipEventSynchronize(e->taken));  // the previous stack of this stream has left the staging buffer
+  memcpy(e->pinned, host_params, sizeof(int) * 7 * (size_t)nstack);
+  ACC_CHECK(hipMemcpyAsync(e->dev, e->pinned, sizeof(int) * 7 * (size_t)nstack, hipMemcpyHostToDevice, st));
+  ACC_CHECK(hipEventRecord(e->taken, st));
+  e->pending = true;
+  hipLaunchKernelGGL(smm_stack_f64_mixed, dim3((nstack + 3) / 4), dim3(256), 0, st, e->dev, nstack, a, b, c, max_dim);
   return dbcsr_amd::check(hipGetLastError(), "smm_stack_f64_mixed launch", __FILE__, __LINE__);
 }
 
@@ -482,7 +501,8 @@ int libsmm_acc_process(const int* host_param_stack, const int* dev_param_stack, 
   (void)c_stream;
   if (def_mnk != 1) {
     // inhomogeneous stack: on the device from the host's own records for fp64 (see smm_stack_f64_mixed), host path otherwise
-    if (datatype != dbcsr_type_real_8 || !host_param_stack || getenv("DBCSR_AMD_SMM_MIXED_ON_HOST")) return -1;
+    static const bool mixed_on_host = getenv("DBCSR_AMD_SMM_MIXED_ON_HOST") != nullptr;  // (read once: this is the call path of every OpenMP thread)
+    if (datatype != dbcsr_type_real_8 || !host_param_stack || mixed_on_host) return -1;
     return process_stack_f64_mixed(host_param_stack, stack_size, static_cast<const double*>(dev_a_data), static_cast<const double*>(dev_b_data),
                                    static_cast<double*>(dev_c_data), max_kernel_dim, stream_of(stack_stream));
   }

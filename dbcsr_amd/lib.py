@@ -28,7 +28,7 @@ LIBSMM_SYMBOLS = [
 ]
 MM_SYMBOLS = [
     "dbcsr_amd_mm_create", "dbcsr_amd_mm_destroy", "dbcsr_amd_mm_symbolic", "dbcsr_amd_mm_numeric", "dbcsr_amd_bcsr_transpose",
-    "dbcsr_amd_bcsr_checksum", "dbcsr_amd_bcsr_fill_random", "dbcsr_amd_mm_kernel_name", "dbcsr_amd_mm_last_kernel", "dbcsr_amd_mm_tile_stats", "dbcsr_amd_mm_band_stats", "dbcsr_amd_mm_plan_stats", "dbcsr_amd_mm_trust_plan", "dbcsr_amd_mm_stats", "dbcsr_amd_mm_timing", "dbcsr_amd_mm_init_c", "dbcsr_amd_bcsr_fill_random_dist",
+    "dbcsr_amd_bcsr_checksum", "dbcsr_amd_bcsr_fill_random", "dbcsr_amd_mm_kernel_name", "dbcsr_amd_mm_last_kernel", "dbcsr_amd_mm_tile_stats", "dbcsr_amd_mm_band_stats", "dbcsr_amd_fabric_probe", "dbcsr_amd_mm_plan_stats", "dbcsr_amd_mm_trust_plan", "dbcsr_amd_mm_stats", "dbcsr_amd_mm_timing", "dbcsr_amd_mm_init_c", "dbcsr_amd_bcsr_fill_random_dist",
     "dbcsr_amd_mm_symbolic_filtered", "dbcsr_amd_bcsr_filter_count", "dbcsr_amd_bcsr_filter_apply",
     "dbcsr_amd_bcsr_crop_count", "dbcsr_amd_bcsr_crop_apply", "dbcsr_amd_bcsr_scale_window",
     "dbcsr_amd_multiply", "dbcsr_amd_bcsr_release", "dbcsr_amd_bcsr_desymmetrize_count", "dbcsr_amd_bcsr_desymmetrize_apply",
@@ -49,7 +49,7 @@ class CommOp(C.Structure):
 class BcsrDesc(C.Structure):
     """struct dbcsr_amd_bcsr (include/dbcsr_amd_mm.h); device pointers."""
     _fields_ = [("nblkrows", C.c_int32), ("nblkcols", C.c_int32), ("row_blk_size", C.c_void_p), ("col_blk_size", C.c_void_p),
-                ("row_p", C.c_void_p), ("col_i", C.c_void_p), ("blk_p", C.c_void_p), ("data", C.c_void_p), ("nblks", C.c_int64)]
+                ("row_p", C.c_void_p), ("col_i", C.c_void_p), ("blk_p", C.c_void_p), ("data", C.c_void_p), ("nblks", C.c_int64), ("index_stamp", C.c_uint64)]
 
 
 class MnkStat(C.Structure):
@@ -153,6 +153,7 @@ def load_library():
     L.dbcsr_amd_mm_last_kernel.restype = C.c_char_p
     L.dbcsr_amd_mm_tile_stats.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     L.dbcsr_amd_mm_band_stats.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
+    L.dbcsr_amd_fabric_probe.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.dbcsr_amd_mm_plan_stats.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
     L.dbcsr_amd_mm_trust_plan.argtypes = [vp, C.c_int]
     _LIB = L

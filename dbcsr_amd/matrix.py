@@ -3,6 +3,8 @@
 one data area), 0-based, with every array living in HBM as a torch tensor.
 torch is only the allocator here; all arithmetic goes through the C-ABI."""
 import ctypes as C
+import itertools
+import weakref
 
 import numpy as np
 import torch
@@ -27,8 +29,31 @@ class StreamHandle:
         self.ptr = C.cast(C.pointer(self._slot), C.c_void_p)
 
 
+_SERIALS = {}   # id(index tensor) -> (weak reference, serial number); an entry goes when its tensor does
+_NEXT_SERIAL = itertools.count(1)
+
+
+def _serial(t):
+    """A number that identifies the tensor OBJECT for its lifetime: a tensor that is freed and another one allocated at the same
+    address (or with the same id) never share it (unlike data_ptr)."""
+    k = id(t)
+    ent = _SERIALS.get(k)
+    if ent is not None and ent[0]() is t:
+        return ent[1]
+    s = next(_NEXT_SERIAL)
+
+    def gone(ref, k=k):
+        cur = _SERIALS.get(k)
+        if cur is not None and cur[0] is ref:
+            del _SERIALS[k]
+
+    _SERIALS[k] = (weakref.ref(t, gone), s)
+    return s
+
+
 class DbcsrMatrix:
     def __init__(self, row_blk_size, col_blk_size, row_p, col_i, blk_p, data, name="", symmetry="N"):
+        self._generation = 0   # bumped whenever the library is handed this matrix as a destination (it writes the index arrays)
         self.row_blk_size, self.col_blk_size = row_blk_size, col_blk_size
         self.row_p, self.col_i, self.blk_p, self.data = row_p, col_i, blk_p, data
         self.name = name
@@ -72,10 +97,23 @@ class DbcsrMatrix:
     def dtype_code(self):
         return _dtype_code(self.data.dtype)
 
-    def desc(self):
+    def index_stamp(self):
+        """dbcsr_amd_bcsr.index_stamp: changes whenever one of the five index tensors is another object, has been written in place by
+        torch (its version counter) or by the library (desc(out=True)); never 0."""
+        h = 1469598103934665603
+        for t in (self.row_blk_size, self.col_blk_size, self.row_p, self.col_i, self.blk_p):
+            for v in (_serial(t), t._version):
+                h = ((h ^ v) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        h = ((h ^ self._generation) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        return h or 1
+
+    def desc(self, out=False):
+        """The C struct.  out=True: the library is about to write this matrix's index arrays (a destination)."""
+        if out:
+            self._generation += 1
         p = lambda t: t.data_ptr() if t is not None and t.numel() > 0 else None
         return _lib.BcsrDesc(self.nblkrows, self.nblkcols, p(self.row_blk_size), p(self.col_blk_size), self.row_p.data_ptr(),
-                             p(self.col_i), p(self.blk_p), p(self.data), self.nblks)
+                             p(self.col_i), p(self.blk_p), p(self.data), self.nblks, self.index_stamp())
 
     def to_host(self):
         """(row_blk_size, col_blk_size, row_p, col_i, blk_p, data) as numpy arrays."""

@@ -46,7 +46,7 @@ class MultiplyEngine:
         st = StreamHandle(stream)
         out = DbcsrMatrix(M.col_blk_size, M.row_blk_size, torch.empty(M.nblkcols + 1, dtype=torch.int32, device=M.data.device),
                           torch.empty_like(M.col_i), torch.empty_like(M.blk_p), torch.empty_like(M.data), M.name + "^T")
-        src, dst = M.desc(), out.desc()
+        src, dst = M.desc(), out.desc(out=True)
         rc = self.L.dbcsr_amd_bcsr_transpose(self.h, M.dtype_code, C.byref(src), C.byref(dst), st.ptr)
         if rc != 0:
             raise RuntimeError("dbcsr_amd_bcsr_transpose failed (%d)" % rc)
@@ -176,7 +176,7 @@ class MultiplyEngine:
         out = DbcsrMatrix(Cm.row_blk_size, Cm.col_blk_size, row_p, torch.empty(counts.c_nblks, dtype=torch.int32, device=dev),
                           torch.empty(counts.c_nblks, dtype=torch.int64, device=dev),
                           torch.empty(counts.c_nze, dtype=dtype, device=dev), Cm.name)
-        cin, cout = Cm.desc(), out.desc()
+        cin, cout = Cm.desc(), out.desc(out=True)
         rc = self.L.dbcsr_amd_mm_init_c(self.h, _lib.dbcsr_type_real_8 if dtype == torch.float64 else _lib.dbcsr_type_real_4,
                                         float(beta), C.byref(cin), C.byref(cout), st.ptr)
         if rc != 0:
@@ -211,7 +211,7 @@ class MultiplyEngine:
         out = DbcsrMatrix(Cm.row_blk_size, Cm.col_blk_size, row_p, torch.empty(counts.c_nblks, dtype=torch.int32, device=dev),
                           torch.empty(counts.c_nblks, dtype=torch.int64, device=dev),
                           out_data if out_data is not None else torch.empty(counts.c_nze, dtype=dtype, device=dev), Cm.name)
-        a, b, cin, cout = A.desc(), B.desc(), Cm.desc(), out.desc()
+        a, b, cin, cout = A.desc(), B.desc(), Cm.desc(), out.desc(out=True)
         rc = self.L.dbcsr_amd_mm_numeric(self.h, out.dtype_code, float(alpha), C.byref(a), C.byref(b), float(beta), C.byref(cin),
                                          C.byref(cout), st.ptr)
         if rc != 0:
@@ -233,7 +233,7 @@ class MultiplyEngine:
             return M
         out = DbcsrMatrix(M.row_blk_size, M.col_blk_size, row_p, torch.empty(nb.value, dtype=torch.int32, device=dev),
                           torch.empty(nb.value, dtype=torch.int64, device=dev), torch.empty(nz.value, dtype=M.dtype, device=dev), M.name)
-        dst = out.desc()
+        dst = out.desc(out=True)
         rc = self.L.dbcsr_amd_bcsr_filter_apply(self.h, M.dtype_code, C.byref(src), C.byref(dst), st.ptr)
         if rc != 0:
             raise RuntimeError("dbcsr_amd_bcsr_filter_apply failed (%d)" % rc)
@@ -256,7 +256,7 @@ class MultiplyEngine:
         dev = M.row_p.device
         out = DbcsrMatrix(M.row_blk_size, M.col_blk_size, row_p, torch.empty(nb.value, dtype=torch.int32, device=dev),
                           torch.empty(nb.value, dtype=torch.int64, device=dev), torch.empty(nz.value, dtype=M.dtype, device=dev), M.name)
-        d = out.desc()
+        d = out.desc(out=True)
         rc = self.L.dbcsr_amd_bcsr_desymmetrize_apply(self.h, M.dtype_code, C.byref(src), 1 if M.symmetry == "A" else 0, C.byref(d), st.ptr)
         if rc != 0:
             raise RuntimeError("dbcsr_amd_bcsr_desymmetrize_apply failed (%d)" % rc)
@@ -276,7 +276,7 @@ class MultiplyEngine:
             raise RuntimeError("dbcsr_amd_bcsr_twin_count failed (%d)" % rc)
         out = DbcsrMatrix(M.row_blk_size, M.col_blk_size, row_p, torch.empty(nb.value, dtype=torch.int32, device=dev),
                           torch.empty(nb.value, dtype=torch.int64, device=dev), torch.empty(nz.value, dtype=M.dtype, device=dev), M.name)
-        d = out.desc()
+        d = out.desc(out=True)
         rc = self.L.dbcsr_amd_bcsr_twin_apply(self.h, M.dtype_code, C.byref(src), mode, 1 if symmetry == "A" else 0, C.byref(d), st.ptr)
         if rc != 0:
             raise RuntimeError("dbcsr_amd_bcsr_twin_apply failed (%d)" % rc)
@@ -307,7 +307,7 @@ class MultiplyEngine:
             raise RuntimeError("dbcsr_amd_bcsr_crop_count failed (%d)" % rc)
         out = DbcsrMatrix(M.row_blk_size, M.col_blk_size, row_p, torch.empty(nb.value, dtype=torch.int32, device=dev),
                           torch.empty(nb.value, dtype=torch.int64, device=dev), torch.empty(nz.value, dtype=M.dtype, device=dev), M.name)
-        dst = out.desc()
+        dst = out.desc(out=True)
         rc = self.L.dbcsr_amd_bcsr_crop_apply(self.h, M.dtype_code, C.byref(src), C.byref(dst), st.ptr)
         if rc != 0:
             raise RuntimeError("dbcsr_amd_bcsr_crop_apply failed (%d)" % rc)
@@ -319,7 +319,7 @@ class MultiplyEngine:
         out = DbcsrMatrix(M.row_blk_size, M.col_blk_size, M.row_p, M.col_i, M.blk_p, M.data.clone(), M.name)
         r0, r1 = (-1, -1) if row_bounds is None else (int(row_bounds[0]), int(row_bounds[1]))
         c0, c1 = (-1, -1) if col_bounds is None else (int(col_bounds[0]), int(col_bounds[1]))
-        d = out.desc()
+        d = out.desc(out=True)
         rc = self.L.dbcsr_amd_bcsr_scale_window(self.h, M.dtype_code, C.byref(d), float(beta), r0, r1, c0, c1, st.ptr)
         if rc != 0:
             raise RuntimeError("dbcsr_amd_bcsr_scale_window failed (%d)" % rc)
@@ -379,7 +379,7 @@ class MultiplyEngine:
         out = DbcsrMatrix(Cm.row_blk_size, Cm.col_blk_size, row_p, torch.empty(counts.c_nblks, dtype=torch.int32, device=dev),
                           torch.empty(counts.c_nblks, dtype=torch.int64, device=dev),
                           torch.empty(counts.c_nze, dtype=A.dtype, device=dev), Cm.name)
-        cout = out.desc()
+        cout = out.desc(out=True)
         rc = self.L.dbcsr_amd_mm_numeric(self.h, A.dtype_code, float(alpha), C.byref(a), C.byref(b), float(beta), C.byref(cin),
                                          C.byref(cout), st.ptr)
         if rc != 0:

@@ -42,6 +42,9 @@ typedef struct dbcsr_amd_bcsr {
   int64_t* blk_p;              /* [nblks], element offset of each block in data */
   void* data;                  /* fp64 or fp32 elements */
   int64_t nblks;
+  uint64_t index_stamp;        /* generation of the index arrays above: 0 = unknown; a caller that owns them may set a value that it
+                                  changes whenever it writes, frees or re-allocates one of them (see dbcsr_amd_mm_trust_plan).  Set to
+                                  0 by the library in every matrix it hands out. */
 } dbcsr_amd_bcsr;
 
 typedef struct dbcsr_amd_mm_counts {
@@ -205,9 +208,11 @@ const char* dbcsr_amd_mm_last_kernel(void* handle);
  * call's index arrays and compares the incoming ones on the device (one small kernel, one flag).  Multiplies with filter_eps > 0
  * never reuse (their pattern depends on the values).  DBCSR_AMD_MM_PLAN=0 switches it off.  Counters since the handle was made: */
 /* Plan reuse without the comparison: while `on`, operands whose twelve index arrays (row_p / col_i / blk_p of A, B, C_in, the three
-   block-size arrays) sit at the ADDRESSES the saved plan saw are taken as unchanged -- no comparison kernel, no synchronisation of
-   the stream in dbcsr_amd_mm_symbolic.  For callers that own these arrays and never write them in place (the panels of a
-   distributed multiply: dbcsr_amd/cannon.py); anything at another address is compared as always. */
+   block-size arrays) sit at the ADDRESSES the saved plan saw AND carry the non-zero index_stamp values the plan was saved with are
+   taken as unchanged -- no comparison kernel, no synchronisation of the stream in dbcsr_amd_mm_symbolic.  The stamp is what makes the
+   address test safe: an operand that was freed and allocated again at the same addresses with another pattern has another stamp (or
+   none: 0 is never trusted) and is compared on the device as always.  For callers that own these arrays (the panels of a distributed
+   multiply, dbcsr_amd/cannon.py; the benchmark's operands). */
 int dbcsr_amd_mm_trust_plan(void* handle, int on);
 int dbcsr_amd_mm_plan_stats(void* handle, int64_t* reused, int64_t* built);
 
@@ -220,6 +225,11 @@ int dbcsr_amd_mm_tile_stats(void* handle, int* waves_gave_up, int* list_mismatch
  * gave up (must be 0: a block was used before it had landed), (tile, wave) lists that disagreed with the per-block product counts
  * (must be 0).  Returns 1 when the last dbcsr_amd_mm_numeric of this handle did not run the band kernel.  Synchronises the device. */
 int dbcsr_amd_mm_band_stats(void* handle, int* waits_gave_up, int* list_mismatches);
+
+/* Measurement helper (bench.py, roofline.fabric): what the L2 <-> Infinity-Cache fabric of the current device delivers, in TB/s -- a
+ * plain streaming read of a 160 MB window by all CUs, and the block gather of the block-product dataflow (4232-byte blocks from
+ * pseudo-random places of the window into LDS, whole 128-byte lines counted).  Takes well under a second; synchronises the device. */
+int dbcsr_amd_fabric_probe(double* stream_tb_per_s, double* gather_tb_per_s);
 
 #if defined(__cplusplus)
 }

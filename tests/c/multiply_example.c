@@ -64,6 +64,7 @@ static int upload(const host_bcsr* h, const int32_t* dsizes, dbcsr_amd_bcsr* d) 
   d->nblkrows = d->nblkcols = NB;
   d->row_blk_size = d->col_blk_size = dsizes;
   d->nblks = h->nblks;
+  d->index_stamp = 0; /* unknown generation: plans are compared on the device */
   CHECK(c_dbcsr_acc_dev_mem_allocate((void**)&d->row_p, sizeof(h->row_p)));
   CHECK(c_dbcsr_acc_dev_mem_allocate((void**)&d->col_i, sizeof(int32_t) * (size_t)(h->nblks + 1)));
   CHECK(c_dbcsr_acc_dev_mem_allocate((void**)&d->blk_p, sizeof(int64_t) * (size_t)(h->nblks + 1)));

@@ -14,6 +14,7 @@ MODULE dbcsr_amd_c_abi
       INTEGER(C_INT32_T) :: nblkrows, nblkcols
       TYPE(C_PTR)        :: row_blk_size, col_blk_size, row_p, col_i, blk_p, data
       INTEGER(C_INT64_T) :: nblks
+      INTEGER(C_INT64_T) :: index_stamp = 0
    END TYPE
    INTERFACE
       FUNCTION acc_init() RESULT(istat) BIND(C, name="c_dbcsr_acc_init")

@@ -125,3 +125,60 @@ def test_trusted_plan_reuses_by_address_and_compares_everything_else(monkeypatch
     ref3, _ = O.multiply("N", "N", 0.7, O.Bcsr(A.row_sizes, A.col_sizes, A.row_p, A.col_i, A.blk_p, A.data * 2.0), B, 1.3, C3)
     run(dA, dB2, to_dev(C3), 0.7, 1.3, ref3)
     assert eng.plan_stats() == (3, 2)
+
+
+def test_trusted_plan_is_not_fooled_by_a_reallocation_at_the_same_address(monkeypatch):
+    """An operand that is freed and allocated again AT THE SAME ADDRESSES with the same block counts and another pattern: trust by
+    address alone would multiply it with the old plan.  The index stamp of the new matrix differs, so its index is
+    compared on the device and a fresh plan is built; a matrix whose index the library has just rewritten in place gets a new stamp too."""
+    monkeypatch.delenv("DBCSR_AMD_MM_PLAN", raising=False)
+    eng = MultiplyEngine()
+    eng.trust_plan(True)
+    A, B, Cm = O.perf_case(*H2O)
+    # A' = A with its block columns mirrored inside every block row: the same number of blocks per row (row_p identical), the same block sizes
+    # (uniform columns except the tail, which stays where it is), another pattern
+    nbc = len(A.col_sizes)
+    perm = np.arange(nbc)
+    perm[:nbc - 1] = perm[:nbc - 1][::-1]
+    col2 = A.col_i.copy()
+    for r in range(len(A.row_sizes)):
+        seg = np.sort(perm[A.col_i[A.row_p[r]:A.row_p[r + 1]]])
+        col2[A.row_p[r]:A.row_p[r + 1]] = seg
+    blk2 = np.zeros_like(A.blk_p)
+    off = 0
+    for r in range(len(A.row_sizes)):
+        for ib in range(A.row_p[r], A.row_p[r + 1]):
+            blk2[ib] = off
+            off += int(A.row_sizes[r]) * int(A.col_sizes[col2[ib]])
+    assert not np.array_equal(col2, A.col_i)
+    A2 = O.Bcsr(A.row_sizes, A.col_sizes, A.row_p, col2, blk2, np.resize(A.data, off) if off > A.data.size else A.data[:off].copy())
+    ref1, _ = O.multiply("N", "N", 1.0, A, B, 1.0, Cm)
+    ref2, _ = O.multiply("N", "N", 1.0, A2, B, 1.0, Cm)
+    dB, dC = to_dev(B), to_dev(Cm)
+    dA = to_dev(A)
+    ptrs = (dA.row_p.data_ptr(), dA.col_i.data_ptr(), dA.blk_p.data_ptr())
+    stamp1 = dA.index_stamp()
+
+    def run(a, expect):
+        out, _ = eng.multiply_local(1.0, a, dB, 1.0, dC)
+        torch.cuda.synchronize()
+        got = dev_to_bcsr(out)
+        assert np.array_equal(got.col_i, expect.col_i) and rel_err(got.data, expect.data) <= 1e-10
+
+    run(dA, ref1)
+    run(dA, ref1)
+    assert eng.plan_stats() == (1, 1)
+    del dA
+    torch.cuda.synchronize()
+    dA2 = to_dev(A2)   # torch's caching allocator hands the freed blocks out again
+    if (dA2.row_p.data_ptr(), dA2.col_i.data_ptr(), dA2.blk_p.data_ptr()) != ptrs:
+        pytest.skip("the allocator did not reuse the addresses (nothing to be fooled by)")
+    assert dA2.index_stamp() != stamp1
+    run(dA2, ref2)
+    assert eng.plan_stats() == (1, 2)   # compared on the device, found different: a fresh plan
+    run(dA2, ref2)
+    assert eng.plan_stats() == (2, 2)   # and THAT plan is reused by address
+    # torch writes an index tensor in place: the stamp moves with its version counter
+    s = dA2.index_stamp()
+    dA2.col_i.add_(0)
+    assert dA2.index_stamp() != s
