@@ -295,7 +295,8 @@ class CannonMultiply:
         self.transport = "torch"
         if share_comm_with is not None:   # a second plan of the same job (another grid / schedule): the first one's communicator
             self.comm, self.transport = share_comm_with.comm, share_comm_with.transport
-        elif transport in ("native", "auto") and dist.is_initialized() and dist.get_world_size() > 1 and torch.cuda.is_available():
+        elif transport in ("native", "auto") and dist.is_initialized() and torch.cuda.is_available() and \
+                (dist.get_world_size() > 1 or transport == "native"):   # (a one-rank job takes the native path only when told to: tests)
             import sys
             err = None
             try:

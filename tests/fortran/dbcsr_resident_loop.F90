@@ -20,7 +20,7 @@ PROGRAM dbcsr_resident_loop
    USE dbcsr_machine, ONLY: m_walltime
    USE dbcsr_methods, ONLY: dbcsr_get_num_blocks, dbcsr_release
    USE dbcsr_mp_methods, ONLY: dbcsr_mp_new, dbcsr_mp_release
-   USE dbcsr_mpiwrap, ONLY: mp_cart_create, mp_cart_rank, mp_comm_free, mp_comm_type, mp_environ, &
+   USE dbcsr_mpiwrap, ONLY: mp_cart_create, mp_cart_rank, mp_comm_free, mp_comm_type, mp_environ, mp_max, mp_sum, mp_sync, &
                             mp_world_finalize, mp_world_init
    USE dbcsr_multiply_api, ONLY: dbcsr_multiply
    USE dbcsr_operations, ONLY: dbcsr_copy
@@ -29,7 +29,7 @@ PROGRAM dbcsr_resident_loop
    IMPLICIT NONE
 
    CHARACTER(len=100) :: arg
-   INTEGER :: m, bs, nrep, check, irep, numnodes, mynode, npdims(2), myploc(2), row, col
+   INTEGER :: m, bs, nrep, check, irep, numnodes, mynode, npdims(2), myploc(2), row, col, nblk_c
    REAL(real_8) :: sparsity, alpha, beta, t0, t1, t_ref, t_up, t_loop, t_down, cs_ref, cs_dev, csp_ref, csp_dev
    REAL(real_8), ALLOCATABLE :: t_rep(:)
    INTEGER(int_8) :: flop, flop_total
@@ -96,10 +96,12 @@ PROGRAM dbcsr_resident_loop
 
    ! upload once ...
    t0 = m_walltime()
-   CALL dbcsr_amd_dev_create(ma, da, ok)
-   IF (ok) CALL dbcsr_amd_dev_create(mb, db, ok)
-   IF (ok) CALL dbcsr_amd_dev_create(mc, dc, ok)
+   ! (several ranks: A also brings the blocks of its process row to this rank's device, B those of its process column -- once)
+   CALL dbcsr_amd_dev_create(ma, da, ok, role='A')
+   IF (ok) CALL dbcsr_amd_dev_create(mb, db, ok, role='B')
+   IF (ok) CALL dbcsr_amd_dev_create(mc, dc, ok, role='C')
    IF (.NOT. ok) STOP "dbcsr_resident_loop: upload failed"
+   CALL mp_sync(group)
    t_up = m_walltime() - t0
    ! ... multiply in HBM ...
    flop_total = 0
@@ -110,7 +112,9 @@ PROGRAM dbcsr_resident_loop
       CALL dbcsr_amd_dev_multiply('N', 'N', alpha, da, db, beta, dc, ok, flop=flop)
       IF (.NOT. ok) STOP "dbcsr_resident_loop: device multiply failed"
       CALL dbcsr_amd_dev_sync()
+      CALL mp_sync(group)   ! (a multiply is over when the slowest rank's is)
       t_rep(irep) = m_walltime() - t1
+      CALL mp_sum(flop, group)
       flop_total = flop_total + flop
    END DO
    t_loop = m_walltime() - t0
@@ -119,11 +123,16 @@ PROGRAM dbcsr_resident_loop
    CALL dbcsr_copy(mc_dev, mc)
    CALL dbcsr_amd_dev_download(dc, mc_dev, ok)
    IF (.NOT. ok) STOP "dbcsr_resident_loop: download failed"
+   CALL mp_sync(group)
    t_down = m_walltime() - t0
    cs_dev = dbcsr_checksum(mc_dev); csp_dev = dbcsr_checksum(mc_dev, pos=.TRUE.)
+   nblk_c = dbcsr_get_num_blocks(mc_dev)
+   CALL mp_sum(nblk_c, group)
 
-   WRITE (*, '(A,I0,A,F6.3,A,I0,A,I0)') " resident_loop: M ", m, "  sparsity ", sparsity, "  block ", bs, "  multiplies ", nrep
-   WRITE (*, '(A,I0,A,I0)') " resident_loop: blocks of C ", dbcsr_get_num_blocks(mc_dev), "  flop ", flop_total
+   IF (mynode == 0) THEN
+   WRITE (*, '(A,I0,A,F6.3,A,I0,A,I0,A,I0,A,I0,A,I0)') " resident_loop: M ", m, "  sparsity ", sparsity, "  block ", bs, "  multiplies ", nrep, &
+      "  ranks ", numnodes, " = ", npdims(1), " x ", npdims(2)
+   WRITE (*, '(A,I0,A,I0)') " resident_loop: blocks of C ", nblk_c, "  flop ", flop_total
    WRITE (*, '(A,F10.5,A,F10.5,A,F10.5)') " resident_loop: upload once [s] ", t_up, "  download once [s] ", t_down, &
       "  per multiply [s] ", t_loop/REAL(nrep, real_8)
    WRITE (*, '(A,F12.3)') " resident_loop: GFLOP/s of the multiplies in HBM ", REAL(flop_total, real_8)/t_loop*1.0E-9_real_8
@@ -140,6 +149,7 @@ PROGRAM dbcsr_resident_loop
       WRITE (*, '(A,2(1X,ES23.15E3))') " resident_loop: checksums resident  ", cs_dev, csp_dev
       WRITE (*, '(A,ES10.3)') " resident_loop: relative difference ", MAX(ABS(cs_dev - cs_ref)/MAX(ABS(cs_ref), 1.0E-300_real_8), &
                                                                     ABS(csp_dev - csp_ref)/MAX(ABS(csp_ref), 1.0E-300_real_8))
+   END IF
    END IF
 
    CALL dbcsr_amd_dev_release(da); CALL dbcsr_amd_dev_release(db); CALL dbcsr_amd_dev_release(dc)

@@ -161,3 +161,33 @@ def test_resident_multi_rank_filtered_multiply_matches_the_reference(name, nrank
     out = run_dump_and_compare_with_fixture("host_resident_mpi", name, nranks, tmp_path, dict(ENV, DBCSR_AMD_RESIDENT="1v"))
     ranks = set(int(m) for m in re.findall(r"dbcsr_amd_resident: rank\s+(\d+) of", out))
     assert ranks == set(range(nranks)), "not every rank multiplied on the device:\n" + out[-2500:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nranks", [2, 4])
+@pytest.mark.parametrize("args", [("2316", "0.8", "23", "5"), ("1500", "0.5", "32", "4")], ids=["23", "32"])
+def test_matrices_stay_on_the_device_under_a_multi_rank_fortran_host(args, nranks, tmp_path):
+    """tests/fortran/dbcsr_resident_loop.F90 on several MPI ranks (sharing the box's GPU): dbcsr_amd_dev_create gathers the row panel of
+    A and the column panel of B ONCE (MPI) and keeps them in HBM with this rank's tile of C, dbcsr_amd_dev_multiply then multiplies
+    nrep times without moving anything between the ranks, dbcsr_amd_dev_download brings every rank's tile back once.  The checksums of
+    the build's own dbcsr_multiply loop must come out (1e-10), on every grid MPI_Dims_create picks."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "host_resident_mpi", "dbcsr_resident_loop")
+    if not (os.path.exists(exe) and os.path.exists(MPIEXEC)):
+        pytest.skip("host_resident_mpi or mpiexec not available")
+    r = subprocess.run([MPIEXEC, "-n", str(nranks), exe, *args, "1"], cwd=tmp_path, env=dict(ENV, DBCSR_AMD_RESIDENT="0"), capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert re.search(r"ranks\s+%d\b" % nranks, r.stdout), r.stdout[-2000:]
+    d = re.search(r"relative difference\s+([0-9.E+-]+)", r.stdout)
+    assert d and float(d.group(1)) <= 1e-10, r.stdout[-2000:]
+    assert re.search(r"steady state \(third multiply on\) per multiply \[s\]\s+[0-9.]+", r.stdout), r.stdout[-2000:]
+
+
+@pytest.mark.gpu
+def test_resident_rccl_request_falls_back_when_ranks_share_a_device(tmp_path):
+    """DBCSR_AMD_RESIDENT_RCCL=1 with two ranks on the box's one GPU: RCCL cannot serve two ranks of a communicator on one device; the
+    glue must notice on every rank (fewer devices than ranks), agree, and move the panels through MPI -- same results, no hang"""
+    out = run_perf("host_resident_mpi", "test_square_sparse.perf", 2, tmp_path, dict(ENV, DBCSR_AMD_RESIDENT="1v", DBCSR_AMD_RESIDENT_RCCL="1"))
+    assert "panels travel over RCCL" not in out
+    ranks = set(int(m) for m in re.findall(r"dbcsr_amd_resident: rank\s+(\d+) of", out))
+    assert ranks == {0, 1}, out[-2500:]

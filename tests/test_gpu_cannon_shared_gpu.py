@@ -32,3 +32,29 @@ def test_cannon_hip_engine_ranks_share_one_gpu(world, mode):
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "-> OK" in r.stdout, r.stdout[-2000:]
+
+
+@pytest.mark.parametrize("mode", ["gather", "ticks", "colpipe", "gather+dist"])
+def test_cannon_native_transport_on_a_one_rank_communicator(mode):
+    """every schedule with transport="native" on the one GPU of the box: librccl is loaded, a one-rank RCCL communicator is made, its
+    self-test runs, the ranks' agreement on the transport goes through torch's communicator, and the schedule's exchange code runs with
+    the native communicator in place (no peer to talk to: the posts are empty) -- the path a multi-GPU node takes first"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tools", "run_dist_check.py"), "nccl", mode, "native"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "-> OK" in r.stdout and "transport=native" in r.stdout, r.stdout[-2000:]
+
+
+@pytest.mark.parametrize("mode", ["gather", "colpipe"])
+def test_cannon_auto_transport_falls_back_when_rccl_refuses_the_shared_device(mode):
+    """two ranks on ONE device ask for transport="auto": RCCL cannot serve them (two ranks of a communicator on one GPU), every rank
+    must notice, all must agree on torch.distributed, and nobody may hang -- what happens on a node where the native exchange cannot be
+    set up on some rank"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tools", "run_dist_check.py"), "gloo", mode, "auto"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "-> OK" in r.stdout and "transport=torch" in r.stdout, r.stdout[-2000:]

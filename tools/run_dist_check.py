@@ -16,6 +16,7 @@ import torch.distributed as dist
 def main():
     backend = sys.argv[1] if len(sys.argv) > 1 else "nccl"
     mode = sys.argv[2] if len(sys.argv) > 2 else "gather"
+    transport = sys.argv[3] if len(sys.argv) > 3 else "torch"   # torch | native | auto (dbcsr_amd.cannon.CannonMultiply)
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
     dist.init_process_group(backend, rank=rank, world_size=world)
@@ -39,10 +40,10 @@ def main():
             z = np.zeros(0, np.int32)
             return cannon.DistBlocks(rows[mine] if mine else z, Mx.col_i[mine] if mine else z, torch.from_numpy(data).cuda())
 
-        plan = cannon.CannonMultiply(dtype=torch.float64, engine=MultiplyEngine(), mode=mode.split("+")[0],
+        plan = cannon.CannonMultiply(dtype=torch.float64, engine=MultiplyEngine(), mode=mode.split("+")[0], transport=transport,
                                      distributed=((part(A, 1), part(B, 2), part(Cm, 3)), (A.row_sizes, A.col_sizes, B.col_sizes)))
     else:
-        plan = cannon.CannonMultiply(M, N, K, sp, [1, 23], dtype=torch.float64, engine=MultiplyEngine(), mode=mode)
+        plan = cannon.CannonMultiply(M, N, K, sp, [1, 23], dtype=torch.float64, engine=MultiplyEngine(), mode=mode, transport=transport)
     for _ in range(2):
         Cout, counts = plan.multiply(0.5, 2.0, filter_eps=eps) if eps else plan.multiply(0.5, 2.0)
     torch.cuda.synchronize()
@@ -75,8 +76,8 @@ def main():
                 break
             err = max(err, float(np.max(np.abs(g - exp) / np.maximum(np.abs(exp), 1e-300))))
         ok = ok and err <= 1e-10
-        print("dist check mode=%s world=%d grid=%dx%d nvirt=%d blocks=%d max_rel_err=%.2e flop_ok=%s -> %s" %
-              (mode, world, plan.grid.nprows, plan.grid.npcols, plan.grid.nvirt, ref.nblks, err, int(fl.item()) == info["flop"],
+        print("dist check mode=%s world=%d grid=%dx%d nvirt=%d blocks=%d transport=%s max_rel_err=%.2e flop_ok=%s -> %s" %
+              (mode, world, plan.grid.nprows, plan.grid.npcols, plan.grid.nvirt, ref.nblks, plan.transport, err, int(fl.item()) == info["flop"],
                "OK" if ok else "FAIL"))
     dist.destroy_process_group()
     sys.exit(0 if ok else 1)
