@@ -106,8 +106,9 @@ class MultiplyEngine:
         print(" " + "-" * 79, file=f)
 
     def last_kernel(self):
-        """name of the block-product kernel the last numeric call launched (dbcsr_amd_mm_last_kernel)"""
-        v = self.L.dbcsr_amd_mm_last_kernel(self.h)
+        """name of the block-product kernel the last numeric call launched (dbcsr_amd_mm_last_kernel; with k passes: the last pass's)"""
+        eng = getattr(self, "_last_pass_engine", None) if getattr(self, "last_kchunks", 1) > 1 else None
+        v = self.L.dbcsr_amd_mm_last_kernel((eng or self).h)
         return v.decode() if v else ""
 
     def plan_stats(self):
@@ -140,8 +141,7 @@ class MultiplyEngine:
             raise RuntimeError("dbcsr_amd_mm_band_stats failed (%d)" % rc)
         return None if rc else (a.value, b.value)
 
-    def last_timing(self):
-        """(ms_fill, ms_numeric) of the last numeric call, from HIP events on its stream."""
+    def _last_timing(self):
         f, n = C.c_float(), C.c_float()
         rc = self.L.dbcsr_amd_mm_timing(self.h, C.byref(f), C.byref(n))
         if rc != 0:
@@ -344,6 +344,41 @@ class MultiplyEngine:
             return 1
         return int(min(8, math.ceil(row_bytes / 2 ** 20)))
 
+    def _kpass_views(self, A, B, n):
+        """[(A's block columns [k0, k1), B's block rows [k0, k1), an engine of its own)] for n ranges of inner blocks of about equal
+        element count: index arrays over the operands' own data areas."""
+        off = torch.cumsum(A.col_blk_size.to(torch.int64), 0).cpu()
+        total = int(off[-1])
+        bounds = [0]
+        for i in range(1, n):   # block boundary nearest to i / n of the elements
+            bounds.append(int(torch.searchsorted(off, torch.tensor(round(i * total / n), dtype=torch.int64))) + 1)
+        bounds.append(A.nblkcols)
+        bounds = sorted(set(min(max(b, 0), A.nblkcols) for b in bounds))
+        nbr = A.nblkrows
+        rows = torch.repeat_interleave(torch.arange(nbr, device=A.row_p.device), torch.diff(A.row_p.to(torch.int64)))
+        views = []
+        for k0, k1 in zip(bounds[:-1], bounds[1:]):
+            if k1 <= k0:
+                continue
+            keep = (A.col_i >= k0) & (A.col_i < k1)
+            cnt = torch.bincount(rows[keep], minlength=nbr)
+            row_p = torch.zeros(nbr + 1, dtype=torch.int32, device=A.row_p.device)
+            row_p[1:] = torch.cumsum(cnt, 0).to(torch.int32)
+            Ac = DbcsrMatrix(A.row_blk_size, A.col_blk_size[k0:k1].contiguous(), row_p, (A.col_i[keep] - k0).to(torch.int32).contiguous(),
+                             A.blk_p[keep].contiguous(), A.data, A.name)
+            lo, hi = int(B.row_p[k0]), int(B.row_p[k1])
+            Bc = DbcsrMatrix(B.row_blk_size[k0:k1].contiguous(), B.col_blk_size, (B.row_p[k0:k1 + 1] - lo).to(torch.int32).contiguous(),
+                             B.col_i[lo:hi].contiguous(), B.blk_p[lo:hi].contiguous(), B.data, B.name)
+            e = type(self)()
+            e.trust_plan(True)   # the views are this object's own and never written again
+            views.append((Ac, Bc, e))
+        return views
+
+    def last_timing(self):
+        """(ms_fill, ms_numeric) of the last numeric call, from HIP events on its stream (with k passes: of the last pass)."""
+        eng = getattr(self, "_last_pass_engine", None) if getattr(self, "last_kchunks", 1) > 1 else None
+        return MultiplyEngine._last_timing(eng or self)
+
     def multiply_local(self, alpha, A, B, beta, Cm, retain_sparsity=False, stream=None, filter_eps=0.0, kchunks=None):
         """C_out = beta*Cm + alpha*A*B for already-oriented operands; returns (C_out, counts)."""
         n = self._auto_kchunks(A, filter_eps) if kchunks is None else int(kchunks)
@@ -353,18 +388,29 @@ class MultiplyEngine:
             # structure once (symbolic product of the whole operands, C = beta*Cm on it), then one in-place pass per k range
             row_p, total = self.symbolic(A, B, Cm, retain_sparsity=retain_sparsity, stream=stream)
             out = self.init_c(beta, Cm, row_p, total, A.dtype, stream=stream)
-            off = torch.cumsum(A.col_blk_size.to(torch.int64), 0)
-            cuts = [0] + [int(off[round(i * A.nblkcols / n) - 1]) for i in range(1, n)] + [int(off[-1])]
+            # The passes' operands are VIEWS: the block columns [k0, k1) of A and the block rows [k0, k1) of B as index arrays of their own
+            # over the operands' own data areas (a block's offset does not care which index names it) -- no copy of 2 x 13.7 GB per
+            # multiply at config 5 --, built once per operand pattern and kept with one engine per pass, whose plan (symbolic product,
+            # product lists, launch order of THAT pass) is then reused by every later multiply of the same operands.  C's index arrays are
+            # kept too, so that the passes see the same arrays every time.  (Round 3 cropped both operands and ran a full symbolic phase
+            # per pass and multiply: 150 ms of config 5's 2018 ms, profiles/r04_config5_step_breakdown.txt.)
+            key = (A.index_stamp(), B.index_stamp(), Cm.index_stamp(), n, bool(retain_sparsity))
+            if getattr(self, "_kpass_key", None) != key:
+                self._kpass_key, self._kpass = key, self._kpass_views(A, B, n)
+                self._kpass_cidx = None
+            if self._kpass_cidx is not None and self._kpass_cidx[1].numel() == out.col_i.numel():
+                rp, ci, bp = self._kpass_cidx   # (same pattern by construction: the whole-operand plan was reused)
+                out = DbcsrMatrix(out.row_blk_size, out.col_blk_size, rp, ci, bp, out.data, out.name)
+            else:
+                self._kpass_cidx = (out.row_p, out.col_i, out.blk_p)
             flop = nprod = 0
-            for c in range(n):
-                if cuts[c + 1] <= cuts[c]:
-                    continue
-                kb = (cuts[c], cuts[c + 1] - 1)
-                cnt = self.accumulate(alpha, self.cropped(A, None, kb, stream=stream), self.cropped(B, kb, None, stream=stream), out,
-                                      stream=stream)
+            for Ac, Bc, eng_c in self._kpass:
+                Ac.data, Bc.data = A.data, B.data   # (the values may be new ones: same arrays or not, the views follow)
+                cnt = eng_c.accumulate(alpha, Ac, Bc, out, stream=stream)
                 flop += cnt.flop
                 nprod += cnt.nproducts
                 self.last_launch_flop, self.last_kchunks = cnt.flop, n  # what last_timing() refers to
+                self._last_pass_engine = eng_c
             total.flop, total.nproducts = flop, nprod
             return out, total
         st = StreamHandle(stream)

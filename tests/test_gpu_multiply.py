@@ -232,6 +232,36 @@ def test_k_chunked_passes_match_oracle(nchunks):
     assert np.all(np.abs(got.data - ref.data) <= 1e-10 * np.maximum(np.abs(ref.data), 1.0))
 
 
+def test_k_chunked_passes_reuse_their_views_and_plans():
+    """the passes' operands are index views over the operands' data areas, one engine per pass keeps its plan: repeated multiplies of
+    the same matrices (and of new VALUES in the same arrays) reuse both and stay correct; another pattern rebuilds them"""
+    A, B, Cm = O.perf_case(23 * 30 + 16, 23 * 28 + 16, 23 * 34 + 16, 0.6, 0.6, 0.7, [1, 23], [1, 23], [1, 23])
+    ref, info = O.multiply("N", "N", 0.5, A, B, 1.5, Cm)
+    E = MultiplyEngine()
+    E.trust_plan(True)
+    dA, dB, dC = to_dev(A), to_dev(B), to_dev(Cm)
+    for rep in range(3):
+        out, counts = E.multiply_local(0.5, dA, dB, 1.5, dC, kchunks=4)
+        torch.cuda.synchronize()
+        got = dev_to_bcsr(out)
+        assert np.array_equal(got.col_i, ref.col_i) and np.array_equal(got.blk_p, ref.blk_p) and counts.flop == info["flop"]
+        assert np.all(np.abs(got.data - ref.data) <= 1e-10 * np.maximum(np.abs(ref.data), 1.0))
+    built = [e.plan_stats() for _, _, e in E._kpass]
+    assert all(b == (2, 1) for b in built), built   # every pass: one plan built, reused twice
+    dA.data.mul_(-2.0)   # new values in the same arrays: same views, same plans
+    ref2, _ = O.multiply("N", "N", 0.5, O.Bcsr(A.row_sizes, A.col_sizes, A.row_p, A.col_i, A.blk_p, A.data * -2.0), B, 1.5, Cm)
+    out, _ = E.multiply_local(0.5, dA, dB, 1.5, dC, kchunks=4)
+    torch.cuda.synchronize()
+    assert np.all(np.abs(dev_to_bcsr(out).data - ref2.data) <= 1e-10 * np.maximum(np.abs(ref2.data), 1.0))
+    assert all(e.plan_stats() == (3, 1) for _, _, e in E._kpass)
+    A3, B3, C3 = O.perf_case(23 * 30 + 16, 23 * 28 + 16, 23 * 34 + 16, 0.5, 0.7, 0.6, [1, 23], [1, 23], [1, 23])
+    ref3, _ = O.multiply("N", "N", 0.5, A3, B3, 1.5, C3)
+    out, _ = E.multiply_local(0.5, to_dev(A3), to_dev(B3), 1.5, to_dev(C3), kchunks=4)
+    torch.cuda.synchronize()
+    got = dev_to_bcsr(out)
+    assert np.array_equal(got.col_i, ref3.col_i) and np.all(np.abs(got.data - ref3.data) <= 1e-10 * np.maximum(np.abs(ref3.data), 1.0))
+
+
 @pytest.mark.parametrize("size", list(range(9, 33)))
 def test_exact_size_kernels_every_cube_with_tails(size):
     """Uniform size s (one exact-size kernel per cube 9..32) with a ragged tail block in every dimension: the tail row / column /
