@@ -472,7 +472,7 @@ class CannonMultiply:
             return self.eng
         e = self._engines.get(key)
         if e is None:
-            e = self._engines[key] = type(self.eng)()
+            e = self._engines[key] = type(self.eng)(lab=self.eng.lab) if hasattr(self.eng, 'lab') else type(self.eng)()
             if hasattr(e, "trust_plan"):
                 e.trust_plan(True)   # the plan's operands are this object's own and their index is never written again
         return e

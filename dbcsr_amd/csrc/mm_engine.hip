@@ -42,9 +42,16 @@
 #include "mm_numeric_f64.h"
 #include "mm_numeric_f32.h"
 #include "mm_aux.h"
+// The library comes in two builds (Makefile): the SHIPPING one holds what a multiply can run by itself -- the kernels listed above, their
+// symbolic phases, plan reuse -- and the LAB one (-DDBCSR_AMD_EXPERIMENTS, libdbcsr_acc_amd_lab.so) adds every dataflow and variant that
+// was built, made parity-green and measured but does not win: the LDS-DMA ring kernels (mm_dma.h), XCD-wide C tiles (mm_tile.*), CU-wide
+// C tiles with B shared in LDS (mm_band.*), the persistent form and the ablation / keep-alive variants of the exact-size kernel, the
+// G-block bodies and stream spreading of the class kernels, the occupancy and row-group knobs.  Their switches exist in the lab build only.
+#ifdef DBCSR_AMD_EXPERIMENTS
 #include "mm_dma.h"
 #include "mm_tile_index.h"
 #include "mm_band_index.h"
+#endif
 namespace dbcsr_amd {
 
 // ---- plan reuse ------------------------------------------------------------------------------------------------------
@@ -122,6 +129,7 @@ static bool launch_hot_f64(int m, int n, int k, dim3 grid, size_t lds_bytes, hip
                            double alpha, double beta, int lds_a, int lds_wave, int dbg, const int* order, const Work* work, int wg_waves,
                            double* norms, int variant) {
   if (m != n || m != k) return false;
+#ifdef DBCSR_AMD_EXPERIMENTS
   // profiling variants exist for the benchmark's block size only (ablation switches; unpaired fragment reads)
   if (m == 23 && variant >= 1 && variant <= 4) {
 #define DBCSR_HOT_VARIANT(V_)                                                                                                              \
@@ -136,6 +144,9 @@ static bool launch_hot_f64(int m, int n, int k, dim3 grid, size_t lds_bytes, hip
 #undef DBCSR_HOT_VARIANT
     return true;
   }
+#else
+  (void)variant;
+#endif
   switch (m) {
 #define DBCSR_HOT_CASE(S_)                                                                                                      \
   case S_:                                                                                                                      \
@@ -148,6 +159,7 @@ static bool launch_hot_f64(int m, int n, int k, dim3 grid, size_t lds_bytes, hip
   }
 }
 
+#ifdef DBCSR_AMD_EXPERIMENTS
 // LDS-DMA variant of the exact-size kernel (mm_dma.h): S ring slots per wave, one wave per workgroup
 template <int S_>
 static bool launch_dma_f64_s(int m, int n, int k, unsigned npos, hipStream_t st, const Desc* descs, int64_t nblk, const Entry* entries,
@@ -175,6 +187,7 @@ static bool launch_dma_f64(int S, int m, int n, int k, unsigned npos, hipStream_
     default: return false;
   }
 }
+#endif
 
 static bool launch_hot_f32(int m, int n, int k, dim3 grid, int wg_waves, hipStream_t st, const Desc* descs, int64_t nblk, const Entry* entries,
                            const float* a_data, const float* b_data, float* c_out, const float* c_in, float alpha, float beta,
@@ -246,8 +259,10 @@ struct Engine {
   DevBuf<unsigned long long> tile_times;
   DevBuf<int> a_pre, tile_rows, tile_cols, tile_cnt, tile_flags;
   DevBuf<int64_t> tile_start;
+#ifdef DBCSR_AMD_EXPERIMENTS
   DevBuf<TileDesc> tdescs;
   DevBuf<TileEntry> tentries;
+#endif
   // plan reuse (plan_compare): device copies of the index arrays the last symbolic phase saw, C's index as the numeric phase emitted it
   int use_plan = 1;  // DBCSR_AMD_MM_PLAN=0: every multiply runs its symbolic phase
   bool plan_saved = false, plan_hit = false, plan_numeric = false;
@@ -264,19 +279,23 @@ struct Engine {
   int* plan_host_flag = nullptr;  // pinned
   dbcsr_amd_mm_counts plan_counts = {0, 0, 0, 0};
   bool work_built = false, tile_built = false, band_built = false;
+#ifdef DBCSR_AMD_EXPERIMENTS
   TileGeom tile_geom = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
   // CU-wide C tiles, B shared in an LDS ring (mm_band.h): DBCSR_AMD_MM_BAND = 0 never, 1 automatic, 2 whenever the sizes allow;
   // DBCSR_AMD_MM_BAND_DEPTH = slots of the ring (12 | 16 | 20 | 22); DBCSR_AMD_MM_BAND_BPOL = 1: B copies with the nt hint;
   // DBCSR_AMD_MM_BAND_KNOBS bit 0: where the waves' time goes (printed by dbcsr_amd_mm_band_stats)
   // DBCSR_AMD_MM_BAND_WINDOW = k window of an XCD's waves (inner blocks; 0: no throttle)
   // DBCSR_AMD_MM_BAND_SHAPE: 0 = 8 waves x (3 x 3 C blocks), 1 = 16 waves x (2 x 2)
   int use_band = 0, band_shape = 1, band_depth = 20, band_bpol = 0, band_knobs = 0, band_window = 384;
-  BandGeom band_geom = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  DevBuf<unsigned> band_prog;
   int64_t band_nlist = 0, band_nrem = 0;
+  DevBuf<unsigned> band_prog;
+#ifdef DBCSR_AMD_EXPERIMENTS
+  BandGeom band_geom = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   DevBuf<BandDesc> band_descs_buf;
   DevBuf<BandEntry> band_entries;
   DevBuf<BandRem> band_rem;
+#endif
   DevBuf<int> band_cnt_list, band_cnt_b, band_cnt_rem, band_sub_cnt, band_flags;
   DevBuf<int64_t> band_list_off, band_seq_off, band_rem_start;
   DevBuf<unsigned long long> band_times;
@@ -408,6 +427,7 @@ static int plan_save(Engine* E, const dbcsr_amd_bcsr* a, const dbcsr_amd_bcsr* b
   return 0;
 }
 
+#ifdef DBCSR_AMD_EXPERIMENTS
 // The tile dataflow (mm_tile.h) for the C blocks of the dominant size: index work (bitmaps of A and of B transposed, sub-tile
 // descriptors, k-sorted product lists), the persistent tile kernel, the products with inner blocks of another size.  The caller
 // then runs the exact-size kernel over the C blocks of the other sizes.  descs[] and C_out's index are already filled.
@@ -595,6 +615,7 @@ static int run_band_f64(Engine* E, hipStream_t st, const dbcsr_amd_bcsr* a, cons
     return -1;
   return check(hipGetLastError(), "run_band_f64", __FILE__, __LINE__);
 }
+#endif  // DBCSR_AMD_EXPERIMENTS
 
 }  // namespace dbcsr_amd
 
@@ -614,7 +635,9 @@ int dbcsr_amd_mm_create(void** handle) {
   if (const char* k = getenv("DBCSR_AMD_MM_KERNEL")) {
     E->use_lds = strcmp(k, "direct") != 0;
     E->use_pipe = strcmp(k, "pipe") == 0 ? 1 : (strcmp(k, "lds1") == 0 ? 0 : -1);
+#ifdef DBCSR_AMD_EXPERIMENTS
     if (strncmp(k, "dma", 3) == 0 && k[3] >= '2' && k[3] <= '4') E->dma_stages = k[3] - '0';
+#endif
   }
   if (const char* k = getenv("DBCSR_AMD_MM_PIPE_G")) E->pipe_g = std::max(1, atoi(k));
   if (const char* k = getenv("DBCSR_AMD_MM_CLASSES")) E->use_classes = atoi(k);
@@ -623,19 +646,28 @@ int dbcsr_amd_mm_create(void** handle) {
     const int w = atoi(k);
     if (w == 1 || w == 2 || w == 4) E->wg_waves = w;
   }
+  if (hipHostMalloc(reinterpret_cast<void**>(&E->cls_host_hist), 3 * 33 * sizeof(int), hipHostMallocDefault) != hipSuccess ||
+      hipHostMalloc(reinterpret_cast<void**>(&E->cls_host_lens), (2 * kNumClasses + 1) * sizeof(int64_t), hipHostMallocDefault) != hipSuccess)
+    return -1;
+  if (const char* k = getenv("DBCSR_AMD_MM_PLAN")) E->use_plan = atoi(k);
+  if (hipHostMalloc(reinterpret_cast<void**>(&E->plan_host_flag), sizeof(int), hipHostMallocDefault) != hipSuccess) return -1;
+  if (const char* k = getenv("DBCSR_AMD_MM_HOT")) E->use_hot = atoi(k);
+  if (const char* k = getenv("DBCSR_AMD_MM_TINY")) E->use_tiny = atoi(k);
+  if (const char* k = getenv("DBCSR_AMD_MM_SYMBOLIC")) {
+    E->force_word_kernels = strcmp(k, "word") == 0;
+    E->force_symbolic = strcmp(k, "word") == 0 ? 1 : (strcmp(k, "grid") == 0 ? 2 : (strcmp(k, "rows") == 0 ? 3 : 0));
+  }
+  if (const char* k = getenv("DBCSR_AMD_MM_PANEL_MB")) E->panel_bytes = (int64_t)atoll(k) << 20;
+#ifdef DBCSR_AMD_EXPERIMENTS
+  // ---- the lab build's switches (every one selects something that was measured and does not win; see the top of this file) ----
   if (const char* k = getenv("DBCSR_AMD_MM_CLASS_G")) {
     const int g = atoi(k);
     E->class_g = (g == 2 || g == 4 || g == 8) ? g : 1;
   }
-  if (hipHostMalloc(reinterpret_cast<void**>(&E->cls_host_hist), 3 * 33 * sizeof(int), hipHostMallocDefault) != hipSuccess ||
-      hipHostMalloc(reinterpret_cast<void**>(&E->cls_host_lens), (2 * kNumClasses + 1) * sizeof(int64_t), hipHostMallocDefault) != hipSuccess)
-    return -1;
   if (const char* k = getenv("DBCSR_AMD_MM_DBG")) E->dbg = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_HOT_VARIANT")) E->hot_variant = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_HOT_PERSISTENT")) E->hot_persistent = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_HOT_XCDS")) E->hot_xcd_mask = (unsigned)strtoul(k, nullptr, 0) & 0xffu;
-  if (const char* k = getenv("DBCSR_AMD_MM_PLAN")) E->use_plan = atoi(k);
-  if (hipHostMalloc(reinterpret_cast<void**>(&E->plan_host_flag), sizeof(int), hipHostMallocDefault) != hipSuccess) return -1;
   if (const char* k = getenv("DBCSR_AMD_MM_TILE")) E->use_tile = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_TILE_WINDOW")) E->tile_window = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_TILE_RDV")) E->tile_rdv = atoi(k);
@@ -649,16 +681,10 @@ int dbcsr_amd_mm_create(void** handle) {
   if (const char* k = getenv("DBCSR_AMD_MM_BAND_KNOBS")) E->band_knobs = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_BAND_WINDOW")) E->band_window = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_BAND_SHAPE")) E->band_shape = atoi(k) == 0 ? 0 : 1;
-  if (const char* k = getenv("DBCSR_AMD_MM_HOT")) E->use_hot = atoi(k);
-  if (const char* k = getenv("DBCSR_AMD_MM_TINY")) E->use_tiny = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_LDS_PAD")) E->lds_pad = atoi(k);
-  if (const char* k = getenv("DBCSR_AMD_MM_SYMBOLIC")) {
-    E->force_word_kernels = strcmp(k, "word") == 0;
-    E->force_symbolic = strcmp(k, "word") == 0 ? 1 : (strcmp(k, "grid") == 0 ? 2 : (strcmp(k, "rows") == 0 ? 3 : 0));
-  }
   if (const char* k = getenv("DBCSR_AMD_MM_CLASS_STREAMS")) E->class_streams = std::min(4, std::max(1, atoi(k)));
-  if (const char* k = getenv("DBCSR_AMD_MM_PANEL_MB")) E->panel_bytes = (int64_t)atoll(k) << 20;
   if (const char* k = getenv("DBCSR_AMD_MM_ROW_GROUP")) E->row_group = atoi(k);
+#endif
   for (int i = 0; i < 3; ++i) {
     e = hipEventCreate(&E->ev[i]);
     if (e != hipSuccess) return check(e, "hipEventCreate", __FILE__, __LINE__);
@@ -692,8 +718,11 @@ int dbcsr_amd_mm_destroy(void* handle) {
   E->norms64.release(); E->a_norms.release(); E->b_norms.release(); E->keep.release();
   E->hot_counters.release();
   E->a_bm.release(); E->bt_bm.release(); E->tile_prog.release(); E->a_pre.release(); E->tile_rows.release(); E->tile_cols.release();
-  E->tile_cnt.release(); E->tile_flags.release(); E->tile_start.release(); E->tdescs.release(); E->tentries.release();
-  E->band_descs_buf.release(); E->band_entries.release(); E->band_rem.release(); E->band_cnt_list.release(); E->band_cnt_b.release();
+  E->tile_cnt.release(); E->tile_flags.release(); E->tile_start.release();
+#ifdef DBCSR_AMD_EXPERIMENTS
+  E->tdescs.release(); E->tentries.release(); E->band_descs_buf.release(); E->band_entries.release(); E->band_rem.release();
+#endif
+  E->band_cnt_list.release(); E->band_cnt_b.release();
   E->band_cnt_rem.release(); E->band_sub_cnt.release(); E->band_flags.release(); E->band_list_off.release(); E->band_seq_off.release();
   E->band_rem_start.release(); E->band_times.release(); E->band_prog.release();
   if (E->host_scalars) (void)hipHostFree(E->host_scalars);
@@ -1189,9 +1218,10 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
                      (size_t)ww * lds_wave * sizeof(double) + (size_t)E->lds_pad, st, E->descs.p, nblk, E->entries.p,     \
                      static_cast<const double*>(a->data), static_cast<const double*>(b->data), static_cast<double*>(c_out->data), \
                      static_cast<const double*>(c_in->data), alpha, beta, lds_a, lds_wave, E->dbg | (skip_empty ? 32 : 0), E->order.p)
+      int tile_rc = 1;
+#ifdef DBCSR_AMD_EXPERIMENTS
       // XCD-wide C tiles (mm_tile.h): one dominant cube size the tile kernel is built for, a C dense enough that sub-tiles of
       // 3 x 3 blocks have long product lists, no on-the-fly filter, no in-place accumulation, no symmetric product
-      int tile_rc = 1;
       if (E->use_tile > 0 && hot_work && E->use_hot && E->use_pipe != 1 && E->dma_stages == 0 && E->hot_m == 23 && E->hot_n == 23 && E->hot_k == 23 &&
           !E->filter.a_norms && !skip_empty && !E->canonical_c && !epi_norms && !(E->dbg & ~32) &&
           (E->use_tile > 1 || (E->nproducts >= 8 * nblk && nblk >= 200000)))
@@ -1207,6 +1237,7 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
       }
       // measured: the pipelined kernel wins when C blocks have few products (config 3: 3.7 per block, 10.4 vs 11.8 ms) and
       // loses when they have many (config 2: 14.4 per block, 32 vs 22 ms)
+#endif
       if (tile_rc == 0 || tile_rc == 2) {
         // the tile / band kernel computed the C blocks of the dominant size (products with inner blocks of another size included);
         // this launch: the exact-size kernel over the blocks of the other sizes only
@@ -1216,6 +1247,7 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
                        hot_work, ww, nullptr, 0);
         snprintf(E->last_kernel, sizeof E->last_kernel, tile_rc == 2 ? "mm_numeric_f64_band<%d,%d,%d>" : "mm_numeric_f64_tile<%d,%d,%d>", E->hot_m, E->hot_n,
                  E->hot_k);
+#ifdef DBCSR_AMD_EXPERIMENTS
       } else if (E->use_hot && E->use_pipe != 1 && E->hot_m > 0 && E->dma_stages > 0 &&
           launch_dma_f64(E->dma_stages, E->hot_m, E->hot_n, E->hot_k, (unsigned)(8 * E->order_len), st, E->descs.p, nblk, E->entries.p,
                          static_cast<const double*>(a->data), static_cast<const double*>(b->data), static_cast<double*>(c_out->data),
@@ -1243,6 +1275,7 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
           E->norms_nblks = nblk;
         }
         snprintf(E->last_kernel, sizeof E->last_kernel, "mm_numeric_f64_hot_persistent<%d,%d,%d>", E->hot_m, E->hot_n, E->hot_k);
+#endif
       } else if (E->use_hot && E->use_pipe != 1 && E->hot_m > 0 &&
           launch_hot_f64(E->hot_m, E->hot_n, E->hot_k, dim3((unsigned)(8 * E->order_len / ww)),
                          (size_t)ww * lds_wave * sizeof(double) + (size_t)E->lds_pad, st, E->descs.p, nblk, E->entries.p,

@@ -5,6 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
+_LIB_LAB = None
 
 # DBCSR data type codes (reference src/data/dbcsr_data_types.F:122-133)
 dbcsr_type_real_4 = 1
@@ -60,15 +61,24 @@ class MmCounts(C.Structure):
     _fields_ = [("c_nblks", C.c_int64), ("c_nze", C.c_int64), ("nproducts", C.c_int64), ("flop", C.c_int64)]
 
 
-def library_path():
-    return os.path.join(_HERE, "libdbcsr_acc_amd.so")
+def library_path(lab=False):
+    """The shipping build, or the lab build (dbcsr_amd/csrc/Makefile: the same library plus the dataflows and variants that were built,
+    parity-tested and measured but do not win -- what the DBCSR_AMD_MM_TILE / _BAND / _HOT_VARIANT ... switches select)."""
+    return os.path.join(_HERE, "libdbcsr_acc_amd_lab.so" if lab else "libdbcsr_acc_amd.so")
 
 
-def load_library():
-    global _LIB
-    if _LIB is not None:
+def want_lab():
+    """DBCSR_AMD_LAB=1: engines made from now on use the lab build (the tests of the experimental kernels, profiling sessions)."""
+    return os.environ.get("DBCSR_AMD_LAB", "0") not in ("", "0")
+
+
+def load_library(lab=False):
+    global _LIB, _LIB_LAB
+    if lab and _LIB_LAB is not None:
+        return _LIB_LAB
+    if not lab and _LIB is not None:
         return _LIB
-    path = library_path()
+    path = library_path(lab)
     # PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64.  The HIP runtime that is loaded FIRST wins
     # (same SONAME); if this library were loaded before torch, two different runtimes could end up in one process and
     # device pointers allocated by torch would be foreign to the one this library talks to.  So when torch is
@@ -156,5 +166,8 @@ def load_library():
     L.dbcsr_amd_fabric_probe.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.dbcsr_amd_mm_plan_stats.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
     L.dbcsr_amd_mm_trust_plan.argtypes = [vp, C.c_int]
-    _LIB = L
+    if lab:
+        _LIB_LAB = L
+    else:
+        _LIB = L
     return L

@@ -23,8 +23,10 @@ dbcsr_conjugate_transpose = "C"
 class MultiplyEngine:
     """Owns the native workspace (bitmaps, product lists) across calls."""
 
-    def __init__(self):
-        self.L = _lib.load_library()
+    def __init__(self, lab=None):
+        # lab: the build with the experimental dataflows (default: DBCSR_AMD_LAB=1 in the environment); both builds may live in one process
+        self.lab = _lib.want_lab() if lab is None else bool(lab)
+        self.L = _lib.load_library(self.lab)
         self.h = C.c_void_p()
         rc = self.L.dbcsr_amd_mm_create(C.byref(self.h))
         if rc != 0:
@@ -369,7 +371,7 @@ class MultiplyEngine:
             lo, hi = int(B.row_p[k0]), int(B.row_p[k1])
             Bc = DbcsrMatrix(B.row_blk_size[k0:k1].contiguous(), B.col_blk_size, (B.row_p[k0:k1 + 1] - lo).to(torch.int32).contiguous(),
                              B.col_i[lo:hi].contiguous(), B.blk_p[lo:hi].contiguous(), B.data, B.name)
-            e = type(self)()
+            e = type(self)(lab=self.lab)
             e.trust_plan(True)   # the views are this object's own and never written again
             views.append((Ac, Bc, e))
         return views

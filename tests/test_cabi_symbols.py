@@ -63,6 +63,9 @@ def test_get_ndevices_before_init_without_gpu(native):
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from dbcsr_amd import lib
     monkeypatch.setattr(lib, "_LIB", None)
-    monkeypatch.setattr(lib, "library_path", lambda: str(tmp_path / "nope.so"))
+    monkeypatch.setattr(lib, "_LIB_LAB", None)
+    monkeypatch.setattr(lib, "library_path", lambda lab=False: str(tmp_path / "nope.so"))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         lib.load_library()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        lib.load_library(lab=True)

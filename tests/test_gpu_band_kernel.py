@@ -29,6 +29,7 @@ ENV_KEYS = ("DBCSR_AMD_MM_BAND", "DBCSR_AMD_MM_BAND_SHAPE", "DBCSR_AMD_MM_BAND_W
 def run(monkeypatch, env, case, alpha=0.7, beta=1.3, reps=1):
     for k in ENV_KEYS:
         monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("DBCSR_AMD_LAB", "1")   # the build with the experimental dataflows (dbcsr_amd/csrc/Makefile)
     monkeypatch.setenv("DBCSR_AMD_MM_BAND", "2")
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -96,6 +97,7 @@ def test_band_kernel_beta_zero_and_new_c(monkeypatch):
 def test_band_kernel_not_chosen_for_small_retained_or_filtered(monkeypatch):
     for k in ENV_KEYS:
         monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("DBCSR_AMD_LAB", "1")
     monkeypatch.setenv("DBCSR_AMD_MM_BAND", "1")   # automatic: the case is far below the threshold
     eng = MultiplyEngine()
     A, B, Cm = O.perf_case(*H2O)

@@ -83,12 +83,18 @@ VARIANTS = [
 ]
 
 
+LAB_SWITCHES = ("DBCSR_AMD_MM_HOT_VARIANT", "DBCSR_AMD_MM_HOT_PERSISTENT", "DBCSR_AMD_MM_HOT_XCDS", "DBCSR_AMD_MM_CLASS_G", "DBCSR_AMD_MM_CLASS_STREAMS",
+                "DBCSR_AMD_MM_DBG", "DBCSR_AMD_MM_LDS_PAD", "DBCSR_AMD_MM_ROW_GROUP")
+
+
 def run_case(monkeypatch, env, case, dtype, tol, expect, alpha=0.7, beta=1.3, retain=False, in_place_twice=False):
     for k in ("DBCSR_AMD_MM_KERNEL", "DBCSR_AMD_MM_HOT", "DBCSR_AMD_MM_TINY", "DBCSR_AMD_MM_PIPE_G", "DBCSR_AMD_MM_SYMBOLIC", "DBCSR_AMD_MM_CLASSES", "DBCSR_AMD_MM_CLASS_G", "DBCSR_AMD_MM_WORK", "DBCSR_AMD_MM_WG_WAVES", "DBCSR_AMD_MM_CLASS_STREAMS", "DBCSR_AMD_MM_HOT_VARIANT", "DBCSR_AMD_MM_HOT_PERSISTENT", "DBCSR_AMD_MM_HOT_XCDS"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
-    eng = MultiplyEngine()  # reads the switches now
+    # the switches of the experimental variants exist in the lab build only (dbcsr_amd/csrc/Makefile); everything else runs on the shipping one
+    lab = any(k in LAB_SWITCHES for k in env) or env.get("DBCSR_AMD_MM_KERNEL", "").startswith("dma")
+    eng = MultiplyEngine(lab=lab)  # reads the switches now
     A, B, Cm = O.perf_case(*case)
     ref, info = O.multiply("N", "N", alpha, A, B, beta, Cm, retain_sparsity=retain)
     cast = lambda M: O.Bcsr(M.row_sizes, M.col_sizes, M.row_p, M.col_i, M.blk_p, M.data.astype(dtype))

@@ -35,7 +35,7 @@ def test_same_index_reuses_plan_and_reproduces(monkeypatch, case, env):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
-    eng = MultiplyEngine()
+    eng = MultiplyEngine(lab="DBCSR_AMD_MM_TILE" in env)   # (the tile dataflow lives in the lab build)
     A, B, Cm = O.perf_case(*case)
     first = check(eng, A, B, Cm)
     assert eng.plan_stats() == (0, 1)

@@ -26,6 +26,7 @@ ENV_KEYS = ("DBCSR_AMD_MM_TILE", "DBCSR_AMD_MM_TILE_SHAPE", "DBCSR_AMD_MM_TILE_W
 def run(monkeypatch, env, case, alpha=0.7, beta=1.3, retain=False):
     for k in ENV_KEYS:
         monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("DBCSR_AMD_LAB", "1")   # the build with the experimental dataflows (dbcsr_amd/csrc/Makefile)
     monkeypatch.setenv("DBCSR_AMD_MM_TILE", "2")
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -98,6 +99,7 @@ def test_tile_kernel_beta_zero_and_new_c(monkeypatch):
 def test_tile_kernel_not_chosen_for_small_or_filtered(monkeypatch):
     for k in ENV_KEYS:
         monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("DBCSR_AMD_LAB", "1")
     monkeypatch.setenv("DBCSR_AMD_MM_TILE", "1")   # automatic: the case is far below the threshold
     eng = MultiplyEngine()
     A, B, Cm = O.perf_case(*H2O)

@@ -10,17 +10,18 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB = os.path.join(ROOT, "dbcsr_amd", "libdbcsr_acc_amd.so")
+LIB = os.path.join(ROOT, "dbcsr_amd", "libdbcsr_acc_amd.so")          # the shipping build
+LAB = os.path.join(ROOT, "dbcsr_amd", "libdbcsr_acc_amd_lab.so")      # + the experimental dataflows (dbcsr_amd/csrc/Makefile)
 LLVM = "/opt/rocm/lib/llvm/bin"
 MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 
 
-def kernels_of_library(tmp_path):
+def kernels_of_library(tmp_path, lib=LIB):
     objcopy, bundler, readelf = (os.path.join(LLVM, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf"))
-    if not (os.path.exists(LIB) and all(os.path.exists(t) for t in (objcopy, bundler, readelf))):
+    if not (os.path.exists(lib) and all(os.path.exists(t) for t in (objcopy, bundler, readelf))):
         pytest.skip("library or LLVM binutils not available")
     fat = tmp_path / "fat.bin"
-    subprocess.check_call([objcopy, "--dump-section", ".hip_fatbin=%s" % fat, LIB, str(tmp_path / "unused.so")])
+    subprocess.check_call([objcopy, "--dump-section", ".hip_fatbin=%s" % fat, lib, str(tmp_path / "unused.so")])
     blob = fat.read_bytes()
     starts = [m.start() for m in re.finditer(re.escape(MAGIC), blob)]
     out = {}
@@ -69,6 +70,24 @@ def test_no_scratch_and_exact_kernels_keep_their_occupancy(tmp_path):
     too_big = {n: v for n, v in hot64.items() if v > (128 if size_of(n) <= 24 else 184)}
     assert not too_big, too_big
     assert all(v <= 96 for v in hot32.values()), hot32
+
+
+def test_shipping_build_holds_no_experiment(tmp_path):
+    """the library bench.py and the hosts load carries the production kernels only: no tile / band / LDS-DMA ring / persistent kernels and no
+    ablation or keep-alive variant of the exact-size kernel (what ships must be auditable)"""
+    ks = kernels_of_library(tmp_path)
+    pretty = demangle(sorted(ks))
+    lab_only = [v for v in pretty.values() if re.search(r"mm_numeric_f64_(tile|band|dma|hot_persistent)<", v) or
+                re.search(r"mm_numeric_f64_hot<\d+, \d+, \d+, [1-9]>", v) or re.search(r"\b(tile|band)_(lists|descs|remainder|select)", v)]
+    assert not lab_only, lab_only
+    assert sum("mm_numeric_f64_hot<" in v for v in pretty.values()) == 24
+
+
+def test_lab_build_kernels_fit_their_occupancy(tmp_path):
+    ks = kernels_of_library(tmp_path, LAB)
+    pretty = demangle(sorted(ks))
+    spilled = {pretty[n]: k["private_segment_fixed_size"] for n, k in ks.items() if k["private_segment_fixed_size"] > 0}
+    assert not spilled, "kernels using scratch memory: %s" % spilled
     # the tile kernels (mm_tile.hip), no scratch (what -mllvm -structurizecfg-skip-uniform-regions is there for, see the Makefile):
     # shape 0 (8 waves per workgroup, two per SIMD) 81 accumulators per lane and everything else in 256 registers; shape 1 (4 waves per
     # workgroup, one per SIMD) 108 accumulators in the 512

@@ -1,6 +1,7 @@
 #!/bin/bash
 # round 4, GPU session 1: the band dataflow (mm_band.h) -- parity, then config 2 against the production kernel on the same box
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}"
+export DBCSR_AMD_LAB=1   # the band dataflow lives in the lab build (dbcsr_amd/csrc/Makefile)
 O=gpurun_out/r04_s01; mkdir -p $O
 timeout 900 python -m pytest tests/test_gpu_band_kernel.py -x -q 2>&1 | tail -15 | tee $O/pytest.txt
 B="python bench.py --steps 5 --warmup 1 --cpu-seconds 0 --no-pmc"

@@ -1,6 +1,7 @@
 #!/bin/bash
 # round 4, GPU session 2: the band dataflow with the XCD's k window and the B copies published two boundaries later -- parity, window sweep
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}"
+export DBCSR_AMD_LAB=1   # the band dataflow lives in the lab build (dbcsr_amd/csrc/Makefile)
 O=gpurun_out/r04_s02; mkdir -p $O
 timeout 900 python -m pytest tests/test_gpu_band_kernel.py -x -q 2>&1 | tail -15 | tee $O/pytest.txt
 B="python bench.py --steps 5 --warmup 1 --cpu-seconds 0 --no-pmc"
