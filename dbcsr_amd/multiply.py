@@ -346,9 +346,16 @@ class MultiplyEngine:
             return 1
         return int(min(8, math.ceil(row_bytes / 2 ** 20)))
 
-    def _kpass_views(self, A, B, n):
+    def _kpass_views(self, A, B, n, counts):
         """[(A's block columns [k0, k1), B's block rows [k0, k1), an engine of its own)] for n ranges of inner blocks of about equal
-        element count: index arrays over the operands' own data areas."""
+        element count: index arrays over the operands' own data areas.  An engine per pass keeps that pass's product lists between
+        multiplies (12 bytes per block product: 33 GB for config 5); when the device is short of that, the passes share ONE engine,
+        whose plan is then rebuilt pass by pass as in round 3."""
+        need = 12 * int(counts.nproducts) + 200 * int(counts.c_nblks) * n
+        free, _total = torch.cuda.mem_get_info(A.data.device)
+        shared = None
+        if need > 0.4 * free:
+            shared = type(self)(lab=self.lab)
         off = torch.cumsum(A.col_blk_size.to(torch.int64), 0).cpu()
         total = int(off[-1])
         bounds = [0]
@@ -371,8 +378,10 @@ class MultiplyEngine:
             lo, hi = int(B.row_p[k0]), int(B.row_p[k1])
             Bc = DbcsrMatrix(B.row_blk_size[k0:k1].contiguous(), B.col_blk_size, (B.row_p[k0:k1 + 1] - lo).to(torch.int32).contiguous(),
                              B.col_i[lo:hi].contiguous(), B.blk_p[lo:hi].contiguous(), B.data, B.name)
-            e = type(self)(lab=self.lab)
-            e.trust_plan(True)   # the views are this object's own and never written again
+            e = shared
+            if e is None:
+                e = type(self)(lab=self.lab)
+                e.trust_plan(True)   # the views are this object's own and never written again
             views.append((Ac, Bc, e))
         return views
 
@@ -398,7 +407,8 @@ class MultiplyEngine:
             # per pass and multiply: 150 ms of config 5's 2018 ms, profiles/r04_config5_step_breakdown.txt.)
             key = (A.index_stamp(), B.index_stamp(), Cm.index_stamp(), n, bool(retain_sparsity))
             if getattr(self, "_kpass_key", None) != key:
-                self._kpass_key, self._kpass = key, self._kpass_views(A, B, n)
+                self._kpass = None   # (the old passes' engines and their work areas go first)
+                self._kpass_key, self._kpass = key, self._kpass_views(A, B, n, total)
                 self._kpass_cidx = None
             if self._kpass_cidx is not None and self._kpass_cidx[1].numel() == out.col_i.numel():
                 rp, ci, bp = self._kpass_cidx   # (same pattern by construction: the whole-operand plan was reused)

@@ -246,6 +246,7 @@ def test_k_chunked_passes_reuse_their_views_and_plans():
         got = dev_to_bcsr(out)
         assert np.array_equal(got.col_i, ref.col_i) and np.array_equal(got.blk_p, ref.blk_p) and counts.flop == info["flop"]
         assert np.all(np.abs(got.data - ref.data) <= 1e-10 * np.maximum(np.abs(ref.data), 1.0))
+    assert len(set(id(e) for _, _, e in E._kpass)) == len(E._kpass), "plenty of memory here: one engine per pass"
     built = [e.plan_stats() for _, _, e in E._kpass]
     assert all(b == (2, 1) for b in built), built   # every pass: one plan built, reused twice
     dA.data.mul_(-2.0)   # new values in the same arrays: same views, same plans
