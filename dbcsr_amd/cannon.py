@@ -667,14 +667,21 @@ class CannonMultiply:
             side.wait_stream(main)   # the symbolic phases' results, and whatever used the output buffer's memory before
             # (no record_stream on the output buffer: the first stream waits for the second below, before anybody can free it --
             #  and a recorded buffer of several GB is not reusable by the next step's allocation, which then goes to hipMalloc)
+        a_landed = None
         for q in range(nch):
             row_p, cnt = sym[q]
             eng = self.last_engine = engines[q]
             kw = {}
             if out_all is not None and getattr(eng, "accepts_out_data", False):
                 kw["out_data"] = out_all[mg["off"][q]:mg["off"][q] + cnt.c_nze]
-            with torch.cuda.stream(side if (side is not None and q % 2 == 1) else main) if main is not None else contextlib.nullcontext():
+            on_side = side is not None and q % 2 == 1
+            with torch.cuda.stream(side if on_side else main) if main is not None else contextlib.nullcontext():
+                if on_side and a_landed is not None:
+                    side.wait_event(a_landed)   # grids with several process columns: the A images came with batch 0, which the first stream took in
                 self._arrived(*posted[q])
+                if q == 0 and side is not None and g.npcols > 1:
+                    a_landed = torch.cuda.Event()
+                    a_landed.record(main)
                 parts.append(eng.numeric_after_symbolic(alpha, self.A_panel, self._Bc[q], beta, self._Cc[q], row_p, cnt, self.dtype, **kw))
             flop += cnt.flop
             nprod += cnt.nproducts
