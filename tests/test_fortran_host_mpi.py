@@ -191,3 +191,54 @@ def test_resident_rccl_request_falls_back_when_ranks_share_a_device(tmp_path):
     assert "panels travel over RCCL" not in out
     ranks = set(int(m) for m in re.findall(r"dbcsr_amd_resident: rank\s+(\d+) of", out))
     assert ranks == {0, 1}, out[-2500:]
+
+
+# cases of tests/golden/ref_dump.json with op(), symmetric / antisymmetric operands or limits (product matrices without symmetry)
+OP_CASES = ["alpha_beta_mixed_TN", "mixed_NT", "mixed_TT", "symm_a_S", "symm_a_A", "symm_a_S_T", "symm_ab_S", "symm_b_A_T", "symm_b_S",
+            "limits_T", "limits_beta0", "limits_beta0_k", "limits_cut_new", "limits_retain"]
+
+
+@pytest.mark.parametrize("nranks", [2, 4])
+@pytest.mark.parametrize("name", ["mixed_TT", "symm_a_A", "limits_T"])
+def test_reference_mpi_op_symmetry_limits_equal_the_single_rank_fixture(name, nranks, tmp_path):
+    """what the GPU test below relies on: the reference itself, on several ranks, gives the block set and the values of its single-rank run"""
+    run_dump_and_compare_with_fixture("host_cpu_mpi", name, nranks, tmp_path, ENV)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nranks", [2, 4])
+@pytest.mark.parametrize("name", OP_CASES)
+def test_resident_multi_rank_op_symmetry_and_limits_on_the_device(name, nranks, tmp_path):
+    """Transposed, symmetric / antisymmetric operands and submatrix limits under a multi-rank Fortran host (round 3: they fell through to
+    the reference's CPU path): every rank sends its blocks of op(desym(A)) / op(desym(B)) to the process row / column that needs them
+    (gather_panel_general: make_m2s' redistribution, src/mm/dbcsr_mm_cannon.F:146-258), the device multiplies the panels and crops by the
+    limits as under one rank.  Block set and values of the reference's single-rank result, every rank on the device path."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from tests import ref_dump_util as R
+    out = run_dump_and_compare_with_fixture("host_resident_mpi", name, nranks, tmp_path, dict(ENV, DBCSR_AMD_RESIDENT="1v"))
+    ranks = set(int(m) for m in re.findall(r"dbcsr_amd_resident: rank\s+(\d+) of", out))
+    assert ranks == set(range(nranks)), "not every rank multiplied on the device:\n" + out[-2500:]
+    p = R.RefResult(name).params
+    if p["transa"] != "N" or p["transb"] != "N" or p["symm_a"] != "N" or p["symm_b"] != "N":
+        assert "general gather" in out, out[-2500:]
+    if any(p["limits"]):
+        assert "[limits]" in out, out[-2500:]
+
+
+@pytest.mark.gpu
+def test_reference_unit_tests_take_the_device_path_on_two_ranks(tmp_path):
+    """the reference's multiply unit tests (tests/dbcsr_unittest1.F: every combination of transposes, symmetries, limits, retain_sparsity,
+    types) on two ranks of the patched host: all pass, and the multiplies with op() / symmetric operands / limits are counted on the
+    device path (what is left to the reference path: complex data, product matrices with symmetry)"""
+    exe = os.path.join(ROOT, "oracle", "_ref", "host_resident_mpi", "dbcsr_unittest1")
+    if not (os.path.exists(exe) and os.path.exists(MPIEXEC)):
+        pytest.skip("host_resident_mpi or mpiexec not available")
+    r = subprocess.run([MPIEXEC, "-n", "2", exe], cwd=tmp_path, env=dict(ENV, DBCSR_AMD_RESIDENT="1v"), capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " FAILED !" not in r.stdout.upper() and r.stdout.upper().count("PASSED !") > 0, r.stdout[-3000:]
+    dev = len(re.findall(r"dbcsr_amd_resident: rank\s+0 of", r.stdout))
+    general = len(re.findall(r"dbcsr_amd_resident: rank\s+0 of.*general gather", r.stdout))
+    limited = len(re.findall(r"dbcsr_amd_resident: rank\s+0 of.*\[limits\]", r.stdout))
+    print("dbcsr_unittest1 on 2 ranks: %d multiplies on the device, %d of them through the general gather, %d with limits" % (dev, general, limited))
+    assert dev > 20 and general > 10 and limited > 0, (dev, general, limited)
