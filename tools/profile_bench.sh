@@ -8,7 +8,7 @@ cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-ARGS="--steps 3 --warmup 1 --cpu-seconds 0 $*"
+ARGS="--steps 3 --warmup 1 --cpu-seconds 0 --no-pmc --no-other-configs $*"
 # pass 1: kernel trace + stats
 ( cd /tmp && timeout 150 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace --output-format csv -- python "$OLDPWD/bench.py" $ARGS ) > "$OUT/trace.log" 2>&1
 # pass 2..: PMC counters, each in its own run (no tracing domains)
