@@ -1118,9 +1118,14 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
       // four positions never straddle two streams only if the stream length is a multiple of 16: the tail positions hold -1
       const unsigned nwg_t = (unsigned)((8 * E->order_len + 15) / 16);
       snprintf(E->last_kernel, sizeof E->last_kernel, "mm_numeric_f64_tiny");
-      hipLaunchKernelGGL(mm_numeric_f64_tiny, dim3(nwg_t), dim3(256), 0, st, E->descs.p, nblk, E->entries.p,
-                         static_cast<const double*>(a->data), static_cast<const double*>(b->data), static_cast<double*>(c_out->data),
-                         static_cast<const double*>(c_in->data), alpha, beta, skip_empty, E->order.p);
+      const double* ad = static_cast<const double*>(a->data);
+      const double* bd = static_cast<const double*>(b->data);
+      double* cd = static_cast<double*>(c_out->data);
+      const double* cid = static_cast<const double*>(c_in->data);
+      if (nwg_t > 0) {
+        auto tiny = E->max_k > 4 ? mm_numeric_f64_tiny<false> : mm_numeric_f64_tiny<true>;
+        hipLaunchKernelGGL(tiny, dim3(nwg_t), dim3(256), 0, st, E->descs.p, nblk, E->entries.p, ad, bd, cd, cid, alpha, beta, skip_empty, E->order.p);
+      }
     } else if (small && E->use_lds && E->cls_mode) {
       // one launch per (m, n) class on its segment of order[]: the run-time compiled exact-size kernel of the class
       // (mm_exact.h, mm_jit.hip), the generic LDS kernel for class 9 (other sizes) and for classes hiprtc could not serve

@@ -756,6 +756,16 @@ __global__ void __launch_bounds__(256) mode_of(const int* __restrict__ v, int n,
 // owns four C blocks, one per MFMA sub-block, each walking its own product list, and every lane fetches exactly the A and
 // B element it feeds (no LDS, no staging): per block product 2 element loads per lane and one MFMA per 4 of k.
 // Sub-block b of lane l: b = (l >> 2) & 3; operands A[i = l & 3][k = l >> 4], B[k = l >> 4][j = l & 3]; result C[i = l >> 4][j = l & 3].
+//
+// The kernel is a chain of memory round trips (order -> descriptor -> entry -> elements), not arithmetic: what sets its time is how
+// many of them a wave puts in flight at once.  The 16 lanes of a sub-block therefore read 16 ENTRIES of their list in one request
+// (192 contiguous bytes), hand them round with ds_bpermute, and request the elements of eight products (16 loads per lane) before the
+// first MFMA: a list of ten products costs 1 + 2 round trips instead of 11.  K4: every k extent is at most 4 (one MFMA per product).
+// Config 1 (4096^2, 10.8 M products): 0.53 -> 0.30 ms.  Measured and not kept (docs/LOG_r04.md, sessions 14-16): 16 products per batch
+// (0.37: two waves per SIMD fewer), persistent waves that pipeline order / descriptor / entries / elements of four successive quads into
+// one round trip per quad (0.33), B column panels of 1-4 MB for the XCD's L2 (-3 %).  At 0.30 ms the launch moves 1.43 GB over the
+// fabric (4.7 TB/s, 0.6 of its ceiling) in 33 M 128-byte L2 requests: a gather of 256 operand bytes per 128 flop, nothing to reuse.
+template <bool K4>
 __global__ void __launch_bounds__(256) mm_numeric_f64_tiny(const Desc* __restrict__ descs, int64_t nblk, const Entry* __restrict__ entries,
                                                            const double* __restrict__ a_data, const double* __restrict__ b_data,
                                                            double* __restrict__ c_out, const double* __restrict__ c_in, double alpha,
@@ -775,32 +785,60 @@ __global__ void __launch_bounds__(256) mm_numeric_f64_tiny(const Desc* __restric
   const int m = d.m, n = d.n;
   const Entry* e = entries + d.prod_start;
   const int cnt = live ? d.prod_cnt : 0;
+  const int t = x + 4 * kq;  // this lane's place among the 16 lanes of its sub-block
+  // C_in is requested now, ahead of the whole product walk
+  double cin = 0.0;
+  const bool mine_c = live && kq < m && x < n;
+  if (mine_c && d.cin_off >= 0) cin = c_in[d.cin_off + kq + m * x];
   double acc = 0.0;
-  Entry cur = Entry::make(0, 0, 0);
-  if (cnt > 0) cur = e[0];
-  for (int p = 0; __any(p < cnt); ++p) {
-    const bool on = p < cnt;
-    Entry nxt = cur;
-    if (p + 1 < cnt) nxt = e[p + 1];  // requested before this product's elements: one entry ahead
-    const int ks = on ? cur.ks() : 0;
-    const double* A = a_data + cur.a_off();
-    const double* B = b_data + cur.b_off();
-    for (int kb = 0; __any(kb < ks); kb += 4) {
-      const int k = kb + kq;
-      const bool kv = k < ks;
-      const double av = (kv && x < m) ? A[x + m * k] : 0.0;
-      const double bv = (kv && x < n) ? B[k + ks * x] : 0.0;
-      acc = __builtin_amdgcn_mfma_f64_4x4x4f64(av, bv, acc, 0, 0, 0);
+  constexpr int U = 8;
+  for (int c0 = 0; __any(c0 < cnt); c0 += 16) {
+    Entry own = Entry::make(0, 0, 0);  // k extent 0: a place past the end of the list feeds zeros
+    if (c0 + t < cnt) own = e[c0 + t];
+    const int left = cnt - c0;
+    for (int q0 = 0; q0 < 16 && __any(q0 < left); q0 += U) {
+      if constexpr (K4) {
+        double av[U], bv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int q = q0 + u;
+          const int src = (sub * 4 + (q & 3) + 16 * (q >> 2)) * 4;
+          Entry en;
+          en.a_lo = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)own.a_lo);
+          en.b_lo = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)own.b_lo);
+          en.w = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)own.w);
+          const int ks = en.ks();
+          const bool kv = kq < ks;
+          av[u] = (kv && x < m) ? a_data[en.a_off() + x + m * kq] : 0.0;
+          bv[u] = (kv && x < n) ? b_data[en.b_off() + kq + ks * x] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f64_4x4x4f64(av[u], bv[u], acc, 0, 0, 0);
+      } else {
+#pragma unroll 1
+        for (int u = 0; u < U; ++u) {
+          const int q = q0 + u;
+          const int src = (sub * 4 + (q & 3) + 16 * (q >> 2)) * 4;
+          Entry en;
+          en.a_lo = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)own.a_lo);
+          en.b_lo = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)own.b_lo);
+          en.w = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)own.w);
+          const int ks = en.ks();
+          const double* A = a_data + en.a_off();
+          const double* B = b_data + en.b_off();
+          for (int kb = 0; __any(kb < ks); kb += 4) {
+            const int k = kb + kq;
+            const bool kv = k < ks;
+            const double a = (kv && x < m) ? A[x + m * k] : 0.0;
+            const double b = (kv && x < n) ? B[k + ks * x] : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, acc, 0, 0, 0);
+          }
+        }
+      }
     }
-    cur = nxt;
   }
   if (!live || (skip_empty && cnt == 0)) return;
-  const int i = kq, j = x;
-  if (i < m && j < n) {
-    double v = alpha * acc;
-    if (d.cin_off >= 0) v += beta * c_in[d.cin_off + i + m * j];
-    c_out[d.c_off + i + m * j] = v;
-  }
+  if (mine_c) c_out[d.c_off + kq + m * x] = alpha * acc + (d.cin_off >= 0 ? beta * cin : 0.0);
 }
 
 }  // namespace dbcsr_amd

@@ -16,6 +16,8 @@ pytestmark = pytest.mark.gpu
 MIXED = (300, 280, 260, 0.5, 0.5, 0.6, [1, 13, 1, 23, 1, 32, 1, 7], [1, 23, 1, 5, 1, 32], [1, 13, 1, 32, 1, 9])
 H2O = (23 * 20 + 16, 23 * 18 + 16, 23 * 22 + 16, 0.6, 0.6, 0.7, [1, 23], [1, 23], [1, 23])
 TINY = (240, 240, 240, 0.7, 0.7, 0.7, [1, 4], [1, 4, 1, 3], [1, 4, 1, 2])
+TINY_K = (230, 250, 420, 0.6, 0.7, 0.7, [1, 4, 1, 2], [1, 3, 1, 1, 1, 4], [1, 7, 1, 4, 1, 13])  # C blocks of at most 4 x 4, k extents above 4
+TINY_FEW = (400, 400, 400, 0.9, 0.9, 0.93, [1, 4], [1, 4], [1, 4])  # lists of zero to a few products: mostly idle places in a chunk
 CONFIG3 = (68 * 9 + 24, 68 * 8 + 24, 68 * 10 + 24, 0.8, 0.8, 0.8, [1, 13, 1, 23, 1, 32], [1, 13, 1, 23, 1, 32], [1, 13, 1, 23, 1, 32])
 # config 3's regime at an oracle-friendly size: {13, 23, 32} blocks + tail 24, 200 block rows, fill 13.6 % -> 3.7 products per C block
 CONFIG3_37 = (68 * 66 + 24, 68 * 66 + 24, 68 * 66 + 24, 0.864, 0.864, 0.864, [1, 13, 1, 23, 1, 32], [1, 13, 1, 23, 1, 32], [1, 13, 1, 23, 1, 32])
@@ -44,6 +46,8 @@ VARIANTS = [
     ({"DBCSR_AMD_MM_KERNEL": "pipe", "DBCSR_AMD_MM_PIPE_G": "3"}, MIXED, "mm_numeric_f64_pipe<4>"),
     ({"DBCSR_AMD_MM_KERNEL": "direct"}, MIXED, "mm_numeric_f64"),
     ({}, TINY, "mm_numeric_f64_tiny"),
+    ({}, TINY_K, "mm_numeric_f64_tiny"),
+    ({}, TINY_FEW, "mm_numeric_f64_tiny"),
     ({"DBCSR_AMD_MM_TINY": "0", "DBCSR_AMD_MM_KERNEL": "lds1"}, TINY, "mm_numeric_f64_lds<1>"),
     ({"DBCSR_AMD_MM_TINY": "0", "DBCSR_AMD_MM_KERNEL": "pipe"}, TINY, "mm_numeric_f64_pipe<1>"),
     ({}, BIG, "mm_numeric_f64"),
