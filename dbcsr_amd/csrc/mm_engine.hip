@@ -665,6 +665,10 @@ int dbcsr_amd_mm_create(void** handle) {
     E->class_g = (g == 2 || g == 4 || g == 8) ? g : 1;
   }
   if (const char* k = getenv("DBCSR_AMD_MM_DBG")) E->dbg = atoi(k);
+  {
+    const char* k = getenv("DBCSR_AMD_MM_POISON");  // (process-wide: the engines created from now on)
+    g_devbuf_poison = k ? (atoi(k) & 255) : -1;
+  }
   if (const char* k = getenv("DBCSR_AMD_MM_HOT_VARIANT")) E->hot_variant = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_HOT_PERSISTENT")) E->hot_persistent = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_HOT_XCDS")) E->hot_xcd_mask = (unsigned)strtoul(k, nullptr, 0) & 0xffu;

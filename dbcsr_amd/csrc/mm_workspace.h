@@ -9,6 +9,10 @@ namespace dbcsr_amd {
 // ----------------------------------------------------------------------------
 // small utilities
 // ----------------------------------------------------------------------------
+// lab build, DBCSR_AMD_MM_POISON=<byte>: every work area is filled with that byte when it is allocated, so that a kernel reading a
+// word nobody wrote computes with garbage EVERY time instead of with whatever the allocation held before (tests/test_gpu_poison.py)
+static int g_devbuf_poison = -1;
+
 template <typename T>
 struct DevBuf {
   T* p = nullptr;
@@ -22,6 +26,7 @@ struct DevBuf {
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), want * sizeof(T));
     if (e != hipSuccess) return check(e, "hipMalloc(workspace)", __FILE__, __LINE__);
     cap = want;
+    if (g_devbuf_poison >= 0) (void)hipMemset(p, g_devbuf_poison, want * sizeof(T));
     return 0;
   }
   void release() {
