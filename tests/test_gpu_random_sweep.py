@@ -58,7 +58,8 @@ def test_random_multiply_matches_oracle(seed):
     run_case(make_case(1000 + seed))
 
 
-def run_case(c):
+def build_case(c):
+    """(A, B, C_in, reference result, reference info) of a case on the host -- everything the oracle contributes"""
     sm, sn, sk = O.make_block_sizes(c["M"], c["mix_m"]), O.make_block_sizes(c["N"], c["mix_n"]), O.make_block_sizes(c["K"], c["mix_k"])
     c0 = O.RANDMAT_SEED_INIT
     dt = c["dtype"]
@@ -69,17 +70,41 @@ def run_case(c):
     wide = lambda X: O.Bcsr(X.row_sizes, X.col_sizes, X.row_p, X.col_i, X.blk_p, X.data.astype(np.float64))
     ref, info = O.multiply(c["ta"], c["tb"], c["alpha"], wide(A), wide(B), c["beta"], wide(Cm), retain_sparsity=c["retain"], filter_eps=c["eps"],
                            c_symmetry=None if c["symm_c"] == "N" else c["symm_c"])
+    return A, B, Cm, ref, info
+
+
+def device_case(c, A, B, Cm):
+    """(result on the host, flop) of the case through the dbcsr_multiply mirror on a fresh engine"""
     dA, dB, dC = to_dev(A), to_dev(B), to_dev(Cm)
     dC.symmetry = c["symm_c"]
     flop = [0]
     dbcsr_multiply(c["ta"], c["tb"], c["alpha"], dA, dB, c["beta"], dC, retain_sparsity=c["retain"], filter_eps=c["eps"] or None, flop=flop,
                    engine=MultiplyEngine())
     torch.cuda.synchronize()
-    out = dev_to_bcsr(dC)
-    assert np.array_equal(out.row_p, ref.row_p) and np.array_equal(out.col_i, ref.col_i), c
-    assert flop[0] == info["flop"], c
+    return dev_to_bcsr(dC), flop[0]
+
+
+def compare_case(c, out, flop, ref, info):
+    """None when the device result equals the reference's by the bar of this file, else a dict that says what differs"""
+    if not (np.array_equal(out.row_p, ref.row_p) and np.array_equal(out.col_i, ref.col_i)):
+        return {"what": "index", "nblks_device": int(out.col_i.size), "nblks_oracle": int(ref.col_i.size)}
+    if flop != info["flop"]:
+        return {"what": "flop", "device": int(flop), "oracle": int(info["flop"])}
     if ref.data.size:
         scale = max(float(np.max(np.abs(ref.data))), 1e-300)
-        tol = 1e-10 if dt == np.float64 else 2e-5
-        assert out.data.size == ref.data.size
-        assert float(np.max(np.abs(out.data.astype(np.float64) - ref.data))) <= tol * scale, c
+        tol = 1e-10 if c["dtype"] == np.float64 else 2e-5
+        if out.data.size != ref.data.size:
+            return {"what": "data size", "device": int(out.data.size), "oracle": int(ref.data.size)}
+        err = np.abs(out.data.astype(np.float64) - ref.data)
+        worst = int(np.argmax(err))
+        if not float(err[worst]) <= tol * scale:    # (a NaN fails too)
+            return {"what": "values", "worst_element": worst, "device": float(out.data[worst]), "oracle": float(ref.data[worst]),
+                    "err_over_scale": float(err[worst]) / scale, "tol": tol, "count_above_tol": int(np.sum(~(err <= tol * scale)))}
+    return None
+
+
+def run_case(c):
+    A, B, Cm, ref, info = build_case(c)
+    out, flop = device_case(c, A, B, Cm)
+    bad = compare_case(c, out, flop, ref, info)
+    assert bad is None, (bad, c)
