@@ -40,6 +40,7 @@
 #include "mm_workspace.h"
 #include "mm_symbolic.h"
 #include "mm_numeric_f64.h"
+#include "mm_numeric_f64_big.h"
 #include "mm_numeric_f32.h"
 #include "mm_aux.h"
 // The library comes in two builds (Makefile): the SHIPPING one holds what a multiply can run by itself -- the kernels listed above, their
@@ -205,6 +206,42 @@ static bool launch_hot_f32(int m, int n, int k, dim3 grid, int wg_waves, hipStre
   }
 }
 
+// the direct form of the fp32 exact-size kernel (mm_numeric_f32.h, round 5): cubes whose k is a multiple of 8
+static bool launch_hot_f32_direct(int m, int n, int k, dim3 grid, int wg_waves, hipStream_t st, const Desc* descs, int64_t nblk, const Entry* entries,
+                                  const float* a_data, const float* b_data, float* c_out, const float* c_in, float alpha, float beta,
+                                  int skip_empty, const int* order) {
+  if (m != n || m != k) return false;
+  switch (m) {
+#define DBCSR_DIRECT_CASE(S_)                                                                                                  \
+  case S_:                                                                                                                     \
+    hipLaunchKernelGGL((mm_numeric_f32_direct<S_, S_, S_>), grid, dim3(64 * wg_waves), f32_lds_bytes(wg_waves), st, descs, nblk, entries, a_data, b_data, \
+                       c_out, c_in, alpha, beta, skip_empty, order);                                                           \
+    return true;
+    DBCSR_DIRECT_CASE(16) DBCSR_DIRECT_CASE(24) DBCSR_DIRECT_CASE(32)
+#undef DBCSR_DIRECT_CASE
+    default: return false;
+  }
+}
+
+// blocks of 33 ... 80: sub-blocks of TM x TN tiles per wave, 2 x 2 waves per C block (mm_numeric_f64_big.h)
+static bool launch_big_f64(int tm, int tn, unsigned npos, hipStream_t st, const Desc* descs, int64_t nblk, const Entry* entries, const double* a_data,
+                           const double* b_data, double* c_out, const double* c_in, double alpha, double beta, int skip_empty, const int* order) {
+  if (tm < 2 || tm > 5 || tn < 2 || tn > 5 || npos == 0) return false;
+  switch (tm * 8 + tn) {
+#define DBCSR_BIG_CASE(A_, B_)                                                                                                        \
+  case A_ * 8 + B_:                                                                                                                   \
+    hipLaunchKernelGGL((mm_numeric_f64_big<A_, B_>), dim3(npos), dim3(256), (size_t)big_lds_bytes(A_, B_), st, descs, nblk, entries, a_data, b_data, c_out, \
+                       c_in, alpha, beta, skip_empty, order);                                                                         \
+    return true;
+    DBCSR_BIG_CASE(2, 2) DBCSR_BIG_CASE(2, 3) DBCSR_BIG_CASE(2, 4) DBCSR_BIG_CASE(2, 5)
+    DBCSR_BIG_CASE(3, 2) DBCSR_BIG_CASE(3, 3) DBCSR_BIG_CASE(3, 4) DBCSR_BIG_CASE(3, 5)
+    DBCSR_BIG_CASE(4, 2) DBCSR_BIG_CASE(4, 3) DBCSR_BIG_CASE(4, 4) DBCSR_BIG_CASE(4, 5)
+    DBCSR_BIG_CASE(5, 2) DBCSR_BIG_CASE(5, 3) DBCSR_BIG_CASE(5, 4) DBCSR_BIG_CASE(5, 5)
+#undef DBCSR_BIG_CASE
+    default: return false;
+  }
+}
+
 struct Engine {
   DevBuf<uint32_t> b_bm, c_bm, cin_bm;
   DevBuf<int> b_pre, c_pre, cin_pre, row_nnz, prod_cnt, blk_nze, tmp_i32;
@@ -220,6 +257,8 @@ struct Engine {
   const void* norms_data = nullptr;  // norms64[] holds the block norms of the matrix with this data pointer (left by the numeric kernel)
   int64_t norms_nblks = 0;
   int canonical_c = 0;  // dbcsr_amd_mm_set_canonical_product: the product matrix has symmetry, its index is in canonical form
+  int use_big = 1;     // DBCSR_AMD_MM_BIG=0: blocks above 32 through the one-wave-per-block kernel of rounds 1-4 (mm_numeric_f64) instead of mm_numeric_f64_big
+  int f32_direct = 1;  // DBCSR_AMD_MM_F32_DIRECT=0: the fp32 exact-size kernel that stages both operands in LDS (rounds 1-4) instead of the direct form
   int wg_waves = 0;   // DBCSR_AMD_MM_WG_WAVES = 1 | 2 | 4: waves per workgroup of the one-wave-per-C-block kernels (0: by list length).  A workgroup's LDS is
                       // released when its LAST wave ends, so with product lists of uneven length fewer waves per workgroup keep
                       // more of the CU's wave slots busy (config 3: kernel 8.93 / 8.09 / 7.51 ms for 4 / 2 / 1, config 2: 23.6 / 22.7 /
@@ -653,6 +692,8 @@ int dbcsr_amd_mm_create(void** handle) {
   if (hipHostMalloc(reinterpret_cast<void**>(&E->plan_host_flag), sizeof(int), hipHostMallocDefault) != hipSuccess) return -1;
   if (const char* k = getenv("DBCSR_AMD_MM_HOT")) E->use_hot = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_TINY")) E->use_tiny = atoi(k);
+  if (const char* k = getenv("DBCSR_AMD_MM_F32_DIRECT")) E->f32_direct = atoi(k);
+  if (const char* k = getenv("DBCSR_AMD_MM_BIG")) E->use_big = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_SYMBOLIC")) {
     E->force_word_kernels = strcmp(k, "word") == 0;
     E->force_symbolic = strcmp(k, "word") == 0 ? 1 : (strcmp(k, "grid") == 0 ? 2 : (strcmp(k, "rows") == 0 ? 3 : 0));
@@ -1328,6 +1369,14 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
       }
       }
 #undef DBCSR_LAUNCH
+    } else if (E->use_big && E->use_lds && E->max_m <= 80 && E->max_n <= 80 && E->min_m >= 1 && E->min_n >= 1 && E->min_k >= 1 && !E->cls_mode &&
+               E->order_len > 0 &&
+               launch_big_f64(std::max(2, ((E->max_m + 7) / 8 + 1) / 2), std::max(2, ((E->max_n + 7) / 8 + 1) / 2), (unsigned)(8 * E->order_len), st,
+                              E->descs.p, nblk, E->entries.p, static_cast<const double*>(a->data), static_cast<const double*>(b->data),
+                              static_cast<double*>(c_out->data), static_cast<const double*>(c_in->data), alpha, beta, skip_empty, E->order.p)) {
+      // blocks of 33 ... 80 (or an inner dimension above 32): one workgroup per C block, operand slabs shared through LDS (mm_numeric_f64_big.h)
+      snprintf(E->last_kernel, sizeof E->last_kernel, "mm_numeric_f64_big<%d,%d>", std::max(2, ((E->max_m + 7) / 8 + 1) / 2),
+               std::max(2, ((E->max_n + 7) / 8 + 1) / 2));
     } else {
       snprintf(E->last_kernel, sizeof E->last_kernel, "mm_numeric_f64");
       hipLaunchKernelGGL(mm_numeric_f64, dim3(nwg), dim3(256), 0, st, E->descs.p, nblk, E->entries.p,
@@ -1346,7 +1395,12 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
       snprintf(E->last_kernel, sizeof E->last_kernel, "mm_numeric_f32_lds[per class segment]");
     } else if (small32 && E->use_lds) {
       const unsigned nwg_o = (unsigned)(8 * E->order_len / ww);
-      if (E->use_hot && E->hot_m > 0 &&
+      if (E->use_hot && E->hot_m > 0 && E->f32_direct &&
+          launch_hot_f32_direct(E->hot_m, E->hot_n, E->hot_k, dim3(nwg_o), ww, st, E->descs.p, nblk, E->entries.p, static_cast<const float*>(a->data),
+                                static_cast<const float*>(b->data), static_cast<float*>(c_out->data), static_cast<const float*>(c_in->data),
+                                (float)alpha, (float)beta, skip_empty, E->order.p)) {
+        snprintf(E->last_kernel, sizeof E->last_kernel, "mm_numeric_f32_direct<%d,%d,%d>", E->hot_m, E->hot_n, E->hot_k);
+      } else if (E->use_hot && E->hot_m > 0 &&
           launch_hot_f32(E->hot_m, E->hot_n, E->hot_k, dim3(nwg_o), ww, st, E->descs.p, nblk, E->entries.p, static_cast<const float*>(a->data),
                          static_cast<const float*>(b->data), static_cast<float*>(c_out->data), static_cast<const float*>(c_in->data),
                          (float)alpha, (float)beta, skip_empty, E->order.p)) {

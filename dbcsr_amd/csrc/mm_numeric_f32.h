@@ -182,6 +182,108 @@ __device__ __forceinline__ void cblock_f32_exact(const Desc& d, const Entry* __r
   }
 }
 
+// ---- exact-size fp32, A straight from global memory (round 5) --------------------------------------------------
+// What bounded cblock_f32_exact (0.60 of the fp32 peak also on cache-resident operands, profiles/r04_config5_kpass_views.txt) is the
+// LDS: per 32^3 product 4 ds_write_b128 + 16 ds_write_b32 + 32 ds_read_b32 = 180 LDS-pipe cycles per wave (MI355X_MICROARCH.md, LDS
+// table) against the 1024 cycles of its 16 MFMAs -- 0.7 of the LDS of a CU whose four SIMDs all multiply.  Here the wave computes the
+// TRANSPOSED tile, C^T = B^T A^T:
+//   * first MFMA operand (32 x 2, lane = output row) = B^T: lane (n, h) wants B[k][n] for the k of its half.  B is stored k x n with k
+//     contiguous, so the block goes to LDS AS IT IS -- 16-byte stores, row pitch K + 4 floats -- and ONE ds_read_b128 hands a lane four
+//     consecutive k of its column: 4 ds_write_b128 + 4 ds_read_b128 = 68 LDS-pipe cycles per product, no transposition, no scalar
+//     LDS traffic.  (Pitch K + 4: the 16 lanes of each ds_read_b128 lane group hit the 16 distinct four-bank groups for K = 16, 24, 32.)
+//   * second operand (2 x 32, lane = output column) = A^T: lane (m, h) wants A[m][k].  A is m x k with m contiguous: for a fixed k the
+//     32 lanes of a half read 128 consecutive bytes -- a plain dword load per k step, straight into the operand register, no LDS.
+//   * the order of the k sum is free: step j multiplies k = j (lanes 0-31) and k = K/2 + j (lanes 32-63), which is what makes a lane's
+//     four B values of one ds_read_b128 four successive steps' operands.
+// acc: register r of lane l = C[m = l & 31][n = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)]: for a fixed r a half-wave writes 128
+// consecutive bytes of C.  K must be a multiple of 8 (a half's k range a multiple of 4); the other sizes keep cblock_f32_exact.
+constexpr int F32D_ROWS = 32;
+static inline constexpr int f32d_pitch(int K) { return K + 4; }
+static inline constexpr int f32d_wave_floats(int K) { return F32D_ROWS * f32d_pitch(K); }
+
+template <int M, int N, int K>
+__device__ __forceinline__ void cblock_f32_direct(const Desc& d, const Entry* __restrict__ entries, const float* __restrict__ a_data,
+                                                  const float* __restrict__ b_data, float* __restrict__ c_out,
+                                                  const float* __restrict__ c_in, float alpha, float beta, int lane, float* lds_b) {
+  static_assert(K % 8 == 0 && K >= 8 && K <= 32 && M <= 32 && N <= 32, "cblock_f32_direct: K a multiple of 8, blocks of at most 32");
+  constexpr int PB = f32d_pitch(K), KH = K / 2, Q = KH / 4;
+  constexpr int CB = (K * N * 4 + 1023) / 1024;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  const Entry* e = entries + d.prod_start;
+  const int cnt = d.prod_cnt;
+  const int i = lane & 31, h = lane >> 5;
+  const int voff = lane * 16;
+  // where this lane's 16 bytes of chunk c go in the image: four consecutive k of one column (K is a multiple of 4)
+  int waddr[CB];
+#pragma unroll
+  for (int c = 0; c < CB; ++c) {
+    const int el = (c * 64 + lane) * 4;
+    waddr[c] = (el / K) * PB + (el % K);
+  }
+  const float* rb = lds_b + (i < N ? i : N - 1) * PB + KH * h;         // this lane's column of B, its half of k
+  const int a_voff = ((i < M ? i : M - 1) + KH * h * M) * 4;           // this lane's row of A, its half of k
+  u32x4 sb[CB];     // B block of the NEXT product on its way to LDS
+  float an[KH];     // A operand of the NEXT product
+  auto issue = [&](uint64_t a_off, uint64_t b_off) {
+    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)(b_data + b_off), 0, K * N * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)(a_data + a_off), 0, M * K * 4, 0x00020000);
+#pragma unroll
+    for (int c = 0; c < CB; ++c) sb[c] = __builtin_amdgcn_raw_buffer_load_b128(rsb, voff + c * 1024, 0, 0);
+#pragma unroll
+    for (int j = 0; j < KH; ++j) an[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsa, a_voff + j * M * 4, 0, 0));
+  };
+  int i0 = 0;
+  Entry e0 = e[0];
+  while (i0 < cnt && e0.ks() != K) {
+    ++i0;
+    e0 = e[i0 < cnt ? i0 : cnt - 1];
+  }
+  int i1 = i0 + 1;
+  Entry e1 = e[i1 < cnt ? i1 : cnt - 1];
+  if (i0 < cnt) issue(e0.a_off(), e0.b_off());
+  while (i0 < cnt) {
+#pragma unroll
+    for (int c = 0; c < CB; ++c) *reinterpret_cast<u32x4*>(lds_b + waddr[c]) = sb[c];
+    float ac[KH];
+#pragma unroll
+    for (int j = 0; j < KH; ++j) ac[j] = an[j];
+    while (i1 < cnt && e1.ks() != K) {
+      ++i1;
+      e1 = e[i1 < cnt ? i1 : cnt - 1];
+    }
+    if (i1 < cnt) issue(e1.a_off(), e1.b_off());
+    const Entry e2 = e[i1 + 1 < cnt ? i1 + 1 : cnt - 1];
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 bq[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) bq[q] = *reinterpret_cast<const f32x4*>(rb + 4 * q);
+#pragma unroll
+    for (int j = 0; j < KH; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[j >> 2][j & 3], ac[j], acc, 0, 0, 0);
+    i0 = i1;
+    e0 = e1;
+    i1 = i1 + 1;
+    e1 = e2;
+  }
+  for (int p = 0; p < cnt; ++p) {
+    const Entry ep = e[p];
+    if (ep.ks() != K) block_product_f32<false, true>(acc, a_data + ep.a_off(), b_data + ep.b_off(), M, N, ep.ks(), lane);
+  }
+  float* C = c_out + d.c_off;
+  const bool has_in = d.cin_off >= 0;
+  const float* Ci = c_in + (has_in ? d.cin_off : 0);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int col = (r & 3) + 8 * (r >> 2) + 4 * h;
+    if (i < M && col < N) {
+      float v = alpha * acc[r];
+      if (has_in) v += beta * Ci[i + (size_t)M * col];
+      C[i + (size_t)M * col] = v;
+    }
+  }
+}
+
 static inline size_t f32_lds_bytes(int wg_waves) { return ((size_t)wg_waves * F32_WAVE_FLOATS + 4) * sizeof(float); }
 #define DBCSR_F32_KERNEL_HEAD                                                                          \
   extern __shared__ __attribute__((aligned(16))) char smem_raw_[]; /* f32_lds_bytes(waves per workgroup) */ \
@@ -213,6 +315,20 @@ __global__ void __launch_bounds__(256) mm_numeric_f32_hot(const Desc* __restrict
   DBCSR_F32_KERNEL_HEAD
   if (d.m == M && d.n == N)
     cblock_f32_exact<M, N, K>(d, entries, a_data, b_data, c_out, c_in, alpha, beta, lane, lds_a, lds_bt);
+  else
+    cblock_f32_lds(d, entries, a_data, b_data, c_out, c_in, alpha, beta, lane, lds_a, lds_bt);
+}
+
+// the direct form: per wave only the image of B (f32d_wave_floats(K) floats); blocks of another size take the generic staged path in the
+// same slice when it is large enough for it, else the plain global-memory product
+template <int M, int N, int K>
+__global__ void __launch_bounds__(256) mm_numeric_f32_direct(const Desc* __restrict__ descs, int64_t nblk, const Entry* __restrict__ entries,
+                                                             const float* __restrict__ a_data, const float* __restrict__ b_data,
+                                                             float* __restrict__ c_out, const float* __restrict__ c_in, float alpha,
+                                                             float beta, int skip_empty, const int* __restrict__ order) {
+  DBCSR_F32_KERNEL_HEAD
+  if (d.m == M && d.n == N)
+    cblock_f32_direct<M, N, K>(d, entries, a_data, b_data, c_out, c_in, alpha, beta, lane, lds_a);
   else
     cblock_f32_lds(d, entries, a_data, b_data, c_out, c_in, alpha, beta, lane, lds_a, lds_bt);
 }

@@ -160,7 +160,9 @@ __device__ __forceinline__ void block_product_f64_lds(double (&acc)[MA][NC], con
 // result register r (0..15): col = l & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5).
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <bool BT>
+// SWAP: the operands change places in the instruction -- acc then holds the TRANSPOSED tile (register r of lane l: column
+// n = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), row m = l & 31), the layout of the kernels that feed A straight from global memory.
+template <bool BT, bool SWAP = false>
 __device__ __forceinline__ void block_product_f32(f32x16& acc, const float* __restrict__ A, const float* __restrict__ B, int m,
                                                   int n, int k, int lane, int row0 = 0, int col0 = 0) {
   const int i = lane & 31, kh = lane >> 5;
@@ -175,12 +177,13 @@ __device__ __forceinline__ void block_product_f32(f32x16& acc, const float* __re
     const float av = A[aoff], bv = B[boff];
     aoff += astep;
     boff += bstep;
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    acc = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(bv, av, acc, 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
   }
   if (kb < k) {
     const bool kv = kh == 0;
     const float a0 = A[kv ? aoff : 0], b0 = B[kv ? boff : 0];
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kv ? a0 : 0.0f, kv ? b0 : 0.0f, acc, 0, 0, 0);
+    const float az = kv ? a0 : 0.0f, bz = kv ? b0 : 0.0f;
+    acc = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(bz, az, acc, 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x2f32(az, bz, acc, 0, 0, 0);
   }
 }
 

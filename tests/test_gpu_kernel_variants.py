@@ -92,7 +92,7 @@ LAB_SWITCHES = ("DBCSR_AMD_MM_HOT_VARIANT", "DBCSR_AMD_MM_HOT_PERSISTENT", "DBCS
 
 
 def run_case(monkeypatch, env, case, dtype, tol, expect, alpha=0.7, beta=1.3, retain=False, in_place_twice=False):
-    for k in ("DBCSR_AMD_MM_KERNEL", "DBCSR_AMD_MM_HOT", "DBCSR_AMD_MM_TINY", "DBCSR_AMD_MM_PIPE_G", "DBCSR_AMD_MM_SYMBOLIC", "DBCSR_AMD_MM_CLASSES", "DBCSR_AMD_MM_CLASS_G", "DBCSR_AMD_MM_WORK", "DBCSR_AMD_MM_WG_WAVES", "DBCSR_AMD_MM_CLASS_STREAMS", "DBCSR_AMD_MM_HOT_VARIANT", "DBCSR_AMD_MM_HOT_PERSISTENT", "DBCSR_AMD_MM_HOT_XCDS"):
+    for k in ("DBCSR_AMD_MM_KERNEL", "DBCSR_AMD_MM_HOT", "DBCSR_AMD_MM_TINY", "DBCSR_AMD_MM_PIPE_G", "DBCSR_AMD_MM_SYMBOLIC", "DBCSR_AMD_MM_CLASSES", "DBCSR_AMD_MM_CLASS_G", "DBCSR_AMD_MM_WORK", "DBCSR_AMD_MM_WG_WAVES", "DBCSR_AMD_MM_CLASS_STREAMS", "DBCSR_AMD_MM_HOT_VARIANT", "DBCSR_AMD_MM_HOT_PERSISTENT", "DBCSR_AMD_MM_HOT_XCDS", "DBCSR_AMD_MM_F32_DIRECT", "DBCSR_AMD_MM_BIG"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -131,19 +131,30 @@ def test_fp64_variant_retain_and_in_place(monkeypatch, env, case, expect):
 
 
 F32 = (32 * 12, 32 * 11, 32 * 13, 0.6, 0.6, 0.6, [1, 32], [1, 32], [1, 32])
+F32_TAILS = (32 * 24 + 20, 32 * 22 + 7, 32 * 26 + 12, 0.6, 0.6, 0.6, [1, 32], [1, 32], [1, 32])
+F32_16 = (16 * 30 + 5, 16 * 28 + 9, 16 * 33 + 4, 0.6, 0.6, 0.6, [1, 16], [1, 16], [1, 16])
+F32_24 = (24 * 20 + 13, 24 * 18, 24 * 22 + 8, 0.6, 0.6, 0.6, [1, 24], [1, 24], [1, 24])
+F32_23 = (23 * 20 + 16, 23 * 18 + 16, 23 * 22 + 16, 0.6, 0.6, 0.7, [1, 23], [1, 23], [1, 23])
 F32_MIXED = (300, 280, 260, 0.5, 0.5, 0.6, [1, 13, 1, 32, 1, 7], [1, 23, 1, 32], [1, 13, 1, 32, 1, 9])
 
 
 @pytest.mark.parametrize("env,case,expect", [
-    ({}, F32, "mm_numeric_f32_hot<32,32,32>"),
+    ({}, F32, "mm_numeric_f32_direct<32,32,32>"),
+    ({}, F32_TAILS, "mm_numeric_f32_direct<32,32,32>"),   # tail blocks: C blocks of other sizes and products with another inner dimension
+    ({}, F32_16, "mm_numeric_f32_direct<16,16,16>"),
+    ({}, F32_24, "mm_numeric_f32_direct<24,24,24>"),
+    ({}, F32_23, "mm_numeric_f32_hot<23,23,23>"),         # k not a multiple of 8: the kernel that stages both operands
+    ({"DBCSR_AMD_MM_F32_DIRECT": "0"}, F32, "mm_numeric_f32_hot<32,32,32>"),
+    ({"DBCSR_AMD_MM_F32_DIRECT": "0"}, F32_TAILS, "mm_numeric_f32_hot<32,32,32>"),
     ({"DBCSR_AMD_MM_HOT": "0"}, F32, "mm_numeric_f32_lds"),
     ({"DBCSR_AMD_MM_KERNEL": "direct"}, F32, "mm_numeric_f32"),
     ({}, F32_MIXED, "mm_numeric_f32_lds"),
     ({"DBCSR_AMD_MM_KERNEL": "direct"}, F32_MIXED, "mm_numeric_f32"),
     ({}, BIG, "mm_numeric_f32"),
     ({"DBCSR_AMD_MM_CLASSES": "2"}, F32_MIXED, "mm_numeric_f32_lds[per class"),
-    ({"DBCSR_AMD_MM_WG_WAVES": "4"}, F32, "mm_numeric_f32_hot<32,32,32>"),
-    ({"DBCSR_AMD_MM_WG_WAVES": "1"}, F32, "mm_numeric_f32_hot<32,32,32>"),
+    ({"DBCSR_AMD_MM_WG_WAVES": "4"}, F32_TAILS, "mm_numeric_f32_direct<32,32,32>"),
+    ({"DBCSR_AMD_MM_WG_WAVES": "1"}, F32_TAILS, "mm_numeric_f32_direct<32,32,32>"),
+    ({"DBCSR_AMD_MM_WG_WAVES": "2"}, F32_16, "mm_numeric_f32_direct<16,16,16>"),
     ({"DBCSR_AMD_MM_WG_WAVES": "2"}, F32_MIXED, "mm_numeric_f32_lds"),
     ({"DBCSR_AMD_MM_WG_WAVES": "4", "DBCSR_AMD_MM_CLASSES": "2"}, F32_MIXED, "mm_numeric_f32_lds[per class"),
 ], ids=lambda v: "-".join("%s=%s" % (k[13:], x) for k, x in v.items()) if isinstance(v, dict) else None)
