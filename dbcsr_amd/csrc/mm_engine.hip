@@ -132,7 +132,7 @@ static bool launch_hot_f64(int m, int n, int k, dim3 grid, size_t lds_bytes, hip
   if (m != n || m != k) return false;
 #ifdef DBCSR_AMD_EXPERIMENTS
   // profiling variants exist for the benchmark's block size only (ablation switches; unpaired fragment reads)
-  if (m == 23 && variant >= 1 && variant <= 4) {
+  if (m == 23 && variant >= 1 && variant <= 6) {
 #define DBCSR_HOT_VARIANT(V_)                                                                                                              \
   hipLaunchKernelGGL((mm_numeric_f64_hot<23, 23, 23, V_>), grid, dim3(64 * wg_waves), lds_bytes, st, descs, nblk, entries, a_data, b_data, c_out, \
                      c_in, alpha, beta, lds_a, lds_wave, dbg, order, work, norms)
@@ -140,7 +140,9 @@ static bool launch_hot_f64(int m, int n, int k, dim3 grid, size_t lds_bytes, hip
       case 1: DBCSR_HOT_VARIANT(1); break;
       case 2: DBCSR_HOT_VARIANT(2); break;
       case 3: DBCSR_HOT_VARIANT(3); break;
-      default: DBCSR_HOT_VARIANT(4); break;
+      case 4: DBCSR_HOT_VARIANT(4); break;
+      case 5: DBCSR_HOT_VARIANT(5); break;
+      default: DBCSR_HOT_VARIANT(6); break;
     }
 #undef DBCSR_HOT_VARIANT
     return true;

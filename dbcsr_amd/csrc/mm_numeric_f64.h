@@ -269,20 +269,23 @@ __device__ __forceinline__ void cblock_f64_exact(const Desc& d, const Entry firs
     }
     if (i1 < cnt) issue(e1.a_off(), e1.b_off());
     const Entry e2 = e[i1 + 1 < cnt ? i1 + 1 : cnt - 1];
+    // VAR 5 / 6 (round 5): the wave raises its issue priority for the burst of MFMAs (and their fragment reads) of a
+    // product, so that the SIMD's other waves' copies and address arithmetic do not sit between two of its MFMAs; 6 = 5 + unpaired reads
+    if constexpr (VAR == 5 || VAR == 6) __builtin_amdgcn_s_setprio(2);
     if (!(dbg & 2))
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       double av[MA], bv[NC];
 #pragma unroll
       for (int a = 0; a < MA; ++a) {
-        if constexpr (VAR == 2)
+        if constexpr (VAR == 2 || VAR == 6)
           av[a] = *(lds_vd*)(pa[a] + s * 4 * M);
         else
           av[a] = pa[a][s * 4 * M];
       }
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
-        if constexpr (VAR == 2)
+        if constexpr (VAR == 2 || VAR == 6)
           bv[c] = (s == KS - 1 && (K & 3)) ? *(lds_vd*)(pbt[c]) : *(lds_vd*)(pb[c] + 4 * s);
         else
           bv[c] = (s == KS - 1 && (K & 3)) ? pbt[c][0] : pb[c][4 * s];
@@ -292,6 +295,7 @@ __device__ __forceinline__ void cblock_f64_exact(const Desc& d, const Entry firs
 #pragma unroll
         for (int c = 0; c < NC; ++c) acc[a][c] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[a], bv[c], acc[a][c], 0, 0, 0);
     }
+    if constexpr (VAR == 5 || VAR == 6) __builtin_amdgcn_s_setprio(0);
     i0 = i1;
     e0 = e1;
     i1 = i1 + 1;

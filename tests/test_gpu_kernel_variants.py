@@ -34,6 +34,9 @@ VARIANTS = [
     ({"DBCSR_AMD_MM_HOT_VARIANT": "2"}, H2O, "mm_numeric_f64_hot<23,23,23>"),
     ({"DBCSR_AMD_MM_HOT_VARIANT": "3"}, H2O, "mm_numeric_f64_hot<23,23,23>"),
     ({"DBCSR_AMD_MM_HOT_VARIANT": "4"}, H2O, "mm_numeric_f64_hot<23,23,23>"),
+    # raised issue priority for a product's MFMA burst (5), the same with unpaired fragment reads (6)
+    ({"DBCSR_AMD_MM_HOT_VARIANT": "5"}, H2O, "mm_numeric_f64_hot<23,23,23>"),
+    ({"DBCSR_AMD_MM_HOT_VARIANT": "6"}, H2O, "mm_numeric_f64_hot<23,23,23>"),
     # the same kernel as persistent waves with a work counter per XCD
     ({"DBCSR_AMD_MM_HOT_PERSISTENT": "1"}, H2O, "mm_numeric_f64_hot_persistent<23,23,23>"),
     ({"DBCSR_AMD_MM_HOT": "0", "DBCSR_AMD_MM_KERNEL": "lds1"}, H2O, "mm_numeric_f64_lds<3>"),
