@@ -629,6 +629,18 @@ class CannonMultiply:
             if isinstance(item, tuple):
                 item[1].copy_(item[0])
 
+    def _launched(self, eng, flop):
+        """Book-keeping of one local block-product launch of the step: what bench.py's roofline refers to.  With
+        collect_kernel_times set (bench.py's untimed roofline steps) the launch's HIP-event time is read back -- a synchronisation --
+        and kept in step_launches as (kernel ms, flop), so that a step's kernel time is the SUM over its chunks / ticks / parts."""
+        self.last_tick_flop = flop
+        if getattr(self, "collect_kernel_times", False):
+            passes = getattr(eng, "pass_launches", None) if getattr(eng, "last_kchunks", 1) > 1 else None
+            if passes:   # k passes: one launch per pass (multiply.py)
+                self.step_launches.extend(passes)
+            else:
+                self.step_launches.append((float(eng.last_timing()[1]), int(flop)))
+
     def _multiply_colpipe(self, alpha, beta):
         """world x 1 grid.  A's block rows are local; B's column panel is ALL of B, one k-image per rank.  It travels in column chunks
         -- chunk q of every image, from its owner to everybody, one batch per chunk, all batches posted at once and carried out in
@@ -690,7 +702,7 @@ class CannonMultiply:
                 parts.append(eng.numeric_after_symbolic(alpha, self.A_panel, self._Bc[q], beta, self._Cc[q], row_p, cnt, self.dtype, **kw))
             flop += cnt.flop
             nprod += cnt.nproducts
-            self.last_tick_flop = cnt.flop
+            self._launched(eng, cnt.flop)
         if side is not None:
             main.wait_stream(side)
             for Cq in parts[1::2]:   # made on the second stream, used by the caller on the first
@@ -796,27 +808,28 @@ class CannonMultiply:
             if auto_k is not None and auto_k(self.A_panel, 0.0) > 1:  # large A block-rows: passes over k (multiply.py)
                 arrived()
                 Cout, counts = eng.multiply_local(alpha, self.A_panel, self.B_panel, beta, self.C_in)
-                self.last_tick_flop = getattr(eng, "last_launch_flop", counts.flop)
+                self._launched(eng, getattr(eng, "last_launch_flop", counts.flop))
                 return Cout, counts
             row_p, counts = eng.symbolic(self.A_panel, self.B_panel, self.C_in, retain_sparsity=False)
             arrived()
             Cout = eng.numeric_after_symbolic(alpha, self.A_panel, self.B_panel, beta, self.C_in, row_p, counts, self.dtype)
-            self.last_tick_flop = counts.flop
+            self._launched(eng, counts.flop)
             return Cout, counts
         # local-first: the images owned on both sides are multiplied while the rest is still in flight
         C1, cnt1 = eng.multiply_local(alpha, s1[0], s1[1], beta, self.C_in)
+        self._launched(eng, getattr(eng, "last_launch_flop", cnt1.flop))
         eng = self.last_engine = self._engine("gather-2")   # the second part keeps its own plan
         auto_k = getattr(eng, "_auto_kchunks", None)
         if auto_k is not None and auto_k(s2[0], 0.0) > 1:  # large A block-rows: passes over k (multiply.py)
             arrived()
             Cout, cnt2 = eng.multiply_local(alpha, s2[0], s2[1], 1.0, C1)
-            self.last_tick_flop = getattr(eng, "last_launch_flop", cnt2.flop)
+            self._launched(eng, getattr(eng, "last_launch_flop", cnt2.flop))
         else:
             # the symbolic phase of the second part needs only the (replicated) index: it runs while the panels still travel
             row_p, cnt2 = eng.symbolic(s2[0], s2[1], C1, retain_sparsity=False)
             arrived()
             Cout = eng.numeric_after_symbolic(alpha, s2[0], s2[1], 1.0, C1, row_p, cnt2, self.dtype)
-            self.last_tick_flop = cnt2.flop
+            self._launched(eng, cnt2.flop)
         cnt2.flop += cnt1.flop
         cnt2.nproducts += cnt1.nproducts
         return Cout, cnt2
@@ -896,6 +909,7 @@ class CannonMultiply:
         (filter_eps / number of blocks of the WHOLE block row of A)^2 (the reference sums the row counts over the process row first,
         dbcsr_mm_cannon.F:1040-1113): such a multiply runs over the full row / column panels in one piece -- every rank then takes
         exactly the decisions a single rank would -- whatever the schedule of the plain products is."""
+        self.step_launches = []
         if retain_sparsity or (filter_eps is not None and filter_eps > 0.0):
             works, staged = self._post_all()
             for w in works:
@@ -905,7 +919,7 @@ class CannonMultiply:
                     item[1].copy_(item[0])
             Cout, counts = self.eng.multiply_local(alpha, self.A_panel, self.B_panel, beta, self.C_in, retain_sparsity=retain_sparsity,
                                                    filter_eps=filter_eps or 0.0)
-            self.last_tick_flop = getattr(self.eng, "last_launch_flop", counts.flop)
+            self._launched(self.eng, getattr(self.eng, "last_launch_flop", counts.flop))
             return Cout, counts
         if self.mode == "colpipe":
             if self._cbounds is None:
@@ -935,7 +949,7 @@ class CannonMultiply:
                 cnt = te.accumulate(alpha, A, B, Cout)
                 flop += cnt.flop
                 nprod += cnt.nproducts
-                self.last_tick_flop = cnt.flop
+                self._launched(te, cnt.flop)
         counts0.flop, counts0.nproducts = flop, nprod
         return Cout, counts0
 

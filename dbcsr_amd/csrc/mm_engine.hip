@@ -436,7 +436,12 @@ static int plan_matches(Engine* E, const dbcsr_amd_bcsr* a, const dbcsr_amd_bcsr
   hipLaunchKernelGGL(plan_compare, dim3(nb), dim3(256), 0, st, S, E->plan_flag.p);
   ACC_CHECK(hipMemcpyAsync(E->plan_host_flag, E->plan_flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
   ACC_CHECK(hipStreamSynchronize(st));
-  return *E->plan_host_flag == 0 ? 1 : 0;
+  if (*E->plan_host_flag != 0) return 0;
+  // equal arrays at (possibly) other addresses or of another generation: from now on THESE are the arrays the plan is known to fit, so a
+  // caller that keeps them (a loop that passes its previous result back in) gets the cheap test next time
+  for (int i = 0; i < 12; ++i) E->plan_ptrs[i] = ptr[i];
+  E->plan_stamps[0] = a->index_stamp, E->plan_stamps[1] = b->index_stamp, E->plan_stamps[2] = c_in->index_stamp;
+  return 1;
 }
 
 // keep device copies of the index arrays this symbolic phase saw, and of C's row pointer

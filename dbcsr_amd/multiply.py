@@ -344,6 +344,11 @@ class MultiplyEngine:
         row_bytes = A.data.numel() * A.data.element_size() / max(1, A.nblkrows)
         if row_bytes <= self.KCHUNK_ROW_BYTES or A.nblkcols < 64:
             return 1
+        if A.data.numel() > 1024 * max(1, A.nblks):
+            # blocks above 32 x 32 on average: the workgroup-per-C-block kernel (mm_numeric_f64_big.h) shares its operand slabs through LDS and
+            # re-reading and re-writing C per pass costs more than the passes save (72^3 at 30 % fill, 16384^2: 21.5 ms in one pass against
+            # 25.5 ms in three, gpurun_out/r05_s02/large_blocks_after.jsonl)
+            return 1
         return int(min(8, math.ceil(row_bytes / 2 ** 20)))
 
     def _kpass_views(self, A, B, n, counts):
@@ -405,20 +410,36 @@ class MultiplyEngine:
             # product lists, launch order of THAT pass) is then reused by every later multiply of the same operands.  C's index arrays are
             # kept too, so that the passes see the same arrays every time.  (Round 3 cropped both operands and ran a full symbolic phase
             # per pass and multiply: 150 ms of config 5's 2018 ms, profiles/r04_config5_step_breakdown.txt.)
-            key = (A.index_stamp(), B.index_stamp(), Cm.index_stamp(), n, bool(retain_sparsity))
+            # The views and the passes' engines depend on A and B only (with C's stamp in this key the usual in / out pattern --
+            # the previous result passed back as Cm, fresh index tensors every call -- never repeated a key, and every multiply rebuilt all
+            # views and made n new engines with work areas of tens of GB).  A new C pattern meets the old engines: their device-side plan
+            # comparison rebuilds a pass's plan in place only when the arrays really differ.
+            key = (A.index_stamp(), B.index_stamp(), n, bool(retain_sparsity))
             if getattr(self, "_kpass_key", None) != key:
                 self._kpass = None   # (the old passes' engines and their work areas go first)
                 self._kpass_key, self._kpass = key, self._kpass_views(A, B, n, total)
                 self._kpass_cidx = None
-            if self._kpass_cidx is not None and self._kpass_cidx[1].numel() == out.col_i.numel():
-                rp, ci, bp = self._kpass_cidx   # (same pattern by construction: the whole-operand plan was reused)
-                out = DbcsrMatrix(out.row_blk_size, out.col_blk_size, rp, ci, bp, out.data, out.name)
+            # What the passes accumulate into: ONE wrapper object over PRIVATE copies of C_out's index arrays, kept while C_in and the operands
+            # are the same generation of the same arrays -- the passes then see the same arrays with the same stamp every time and their
+            # trusted plans engage.  The copies are this cache's own: the matrix handed back to the caller keeps the index tensors init_c
+            # made for it, so nothing a caller does to a result can reach a later multiply (and the library's rewrite of the cached col_i /
+            # blk_p in every pass touches no earlier result).  The version counters guard against a torch-side edit all the same.
+            ckey = (Cm.index_stamp(), key, int(out.col_i.numel()))
+            c = getattr(self, "_kpass_cidx", None)
+            if c is not None and c["key"] == ckey and all(t._version == v for t, v in zip(c["tensors"], c["versions"])):
+                work = c["work"]
+                work.data = out.data
             else:
-                self._kpass_cidx = (out.row_p, out.col_i, out.blk_p)
+                work = DbcsrMatrix(out.row_blk_size, out.col_blk_size, out.row_p.clone(), out.col_i.clone(), out.blk_p.clone(), out.data, out.name)
+                tensors = (work.row_p, work.col_i, work.blk_p)
+                self._kpass_cidx = {"key": ckey, "work": work, "tensors": tensors, "versions": tuple(t._version for t in tensors)}
             flop = nprod = 0
+            self.pass_launches = []   # [(kernel ms, flop)] per pass, filled when collect_kernel_times is set (a synchronisation per pass)
             for Ac, Bc, eng_c in self._kpass:
                 Ac.data, Bc.data = A.data, B.data   # (the values may be new ones: same arrays or not, the views follow)
-                cnt = eng_c.accumulate(alpha, Ac, Bc, out, stream=stream)
+                cnt = eng_c.accumulate(alpha, Ac, Bc, work, stream=stream)
+                if getattr(self, "collect_kernel_times", False):
+                    self.pass_launches.append((float(MultiplyEngine._last_timing(eng_c)[1]), int(cnt.flop)))
                 flop += cnt.flop
                 nprod += cnt.nproducts
                 self.last_launch_flop, self.last_kchunks = cnt.flop, n  # what last_timing() refers to

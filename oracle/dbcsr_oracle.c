@@ -837,3 +837,13 @@ int orc_max_threads(void) {
   return 1;
 #endif
 }
+
+/* The default of one OpenMP thread per visible CPU oversubscribes a host whose cgroup grants fewer CPUs than it shows (a GPU
+ * box: 256 visible, quota 16): the front-end (oracle.py) sets the team size to what the quota allows. */
+void orc_set_threads(int n) {
+#if defined(_OPENMP)
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}

@@ -25,10 +25,29 @@ def build(force=False):
     return so
 
 
+def usable_cpus():
+    """CPUs this process may run on at once: visible CPUs, affinity mask, cgroup quota (cpu.max) -- whichever is smallest"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def lib():
     global _LIB
     if _LIB is None:
         L = C.CDLL(build())
+        if "OMP_NUM_THREADS" not in os.environ:   # (an explicit setting stands)
+            L.orc_set_threads.argtypes = [C.c_int]
+            L.orc_set_threads(usable_cpus())
         L.orc_dlarnv1.argtypes = [i32p, C.c_int64, f64p]
         L.orc_slarnv1.argtypes = [i32p, C.c_int64, f32p]
         L.orc_set_larnv_seed.argtypes = [C.c_int] * 5 + [i32p]
