@@ -146,7 +146,7 @@ int symbolic_numeric(void* h, libsmm_acc_data_t dt, double alpha, const dbcsr_am
 }
 
 // L2 blocking over k (see MultiplyEngine.multiply_local in dbcsr_amd/multiply.py for the measurements): when A's average block
-// row is larger than 1.5 MB neither operand stays L2-resident; the product is then formed as one symbolic product of the whole
+// row is larger than 1 MB neither operand stays L2-resident; the product is then formed as one symbolic product of the whole
 // operands (C's final structure, C = beta*C_in on it) followed by passes over k ranges that accumulate in place.
 int k_passes(void* h, libsmm_acc_data_t dt, const dbcsr_amd_bcsr* a, double filter_eps, void* stream) {
   if (filter_eps > 0.0) return 1;  // the on-the-fly filter counts the blocks of a whole A row
@@ -157,7 +157,8 @@ int k_passes(void* h, libsmm_acc_data_t dt, const dbcsr_amd_bcsr* a, double filt
   int64_t nb = 0, nz = 0;
   if (dbcsr_amd_bcsr_crop_count(h, dt, a, -1, -1, -1, -1, probe.m.row_p, &nb, &nz, stream)) return 1;
   const double row_bytes = (double)nz * (double)elem_size(dt) / (double)a->nblkrows;
-  if (row_bytes <= 1.5 * 1048576.0) return 1;
+  if (row_bytes <= 1.0 * 1048576.0) return 1;      // (round 5: 23 x 23 at 20 % fill, rows of 1.2 MB, gains 7 % from two passes)
+  if (nb > 0 && nz > 1024 * nb) return 1;           // blocks above 32 x 32 on average: the workgroup-per-C-block kernel shares its operands in LDS
   const int n = (int)std::ceil(row_bytes / 1048576.0);
   return n > 8 ? 8 : n;
 }

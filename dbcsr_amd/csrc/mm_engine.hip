@@ -41,6 +41,7 @@
 #include "mm_symbolic.h"
 #include "mm_numeric_f64.h"
 #include "mm_numeric_f64_big.h"
+#include "mm_group.h"
 #include "mm_numeric_f32.h"
 #include "mm_aux.h"
 // The library comes in two builds (Makefile): the SHIPPING one holds what a multiply can run by itself -- the kernels listed above, their
@@ -259,6 +260,11 @@ struct Engine {
   const void* norms_data = nullptr;  // norms64[] holds the block norms of the matrix with this data pointer (left by the numeric kernel)
   int64_t norms_nblks = 0;
   int canonical_c = 0;  // dbcsr_amd_mm_set_canonical_product: the product matrix has symmetry, its index is in canonical form
+  // fp32: a wave owns R C blocks of one block column and shares B among them (mm_numeric_f32_group.h).  DBCSR_AMD_MM_F32_GROUP = 0: off,
+  // 2 / 3 / 4: that R whenever the kernel applies, unset: R = 4 when C blocks have at least 16 products on average
+  int f32_group = -1, group_R = 0;
+  bool group_built = false, b_monotone = false;
+  DevBuf<int> groups, group_flag;
   int use_big = 1;     // DBCSR_AMD_MM_BIG=0: blocks above 32 through the one-wave-per-block kernel of rounds 1-4 (mm_numeric_f64) instead of mm_numeric_f64_big
   int f32_direct = 1;  // DBCSR_AMD_MM_F32_DIRECT=0: the fp32 exact-size kernel that stages both operands in LDS (rounds 1-4) instead of the direct form
   int wg_waves = 0;   // DBCSR_AMD_MM_WG_WAVES = 1 | 2 | 4: waves per workgroup of the one-wave-per-C-block kernels (0: by list length).  A workgroup's LDS is
@@ -393,6 +399,40 @@ static int exclusive_scan(Engine* E, const int* in, int64_t n, TO* out, int64_t*
 }
 
 static inline dim3 grid_for(int64_t nthreads) { return dim3((unsigned)((nthreads + 255) / 256)); }
+
+// fp32 group kernel: 0 = launched, 1 = does not apply here (the caller runs the one-wave-per-block kernel), < 0 = error
+static int run_group_f32(Engine* E, int R, bool reuse, hipStream_t st, const dbcsr_amd_bcsr* a, const dbcsr_amd_bcsr* b, const dbcsr_amd_bcsr* c_in,
+                         dbcsr_amd_bcsr* c_out, float alpha, float beta, int skip_empty) {
+  const int S = E->hot_m, nbr = E->nbr, nbc = b->nblkcols;
+  if (!(S == 16 || S == 24 || S == 32) || R < 2 || R > 4 || nbr <= 0 || nbc <= 0) return 1;
+  const int ng = (nbr + R - 1) / R, ngx = (ng + 7) / 8;
+  if ((int64_t)ngx * nbc >= (1ll << 30)) return 1;
+  if (!(reuse && E->group_built && E->group_R == R)) {
+    if (E->group_flag.ensure(4) || E->groups.ensure((size_t)ng * nbc * R + 1)) return -1;
+    ACC_CHECK(hipMemsetAsync(E->group_flag.p, 0, sizeof(int), st));
+    group_f32_check_ascending(st, static_cast<const int64_t*>(b->blk_p), (int64_t)b->nblks, E->group_flag.p);
+    int* hflag = reinterpret_cast<int*>(E->host_scalars + 12);
+    ACC_CHECK(hipMemcpyAsync(hflag, E->group_flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    ACC_CHECK(hipStreamSynchronize(st));
+    E->b_monotone = *hflag == 0;
+    E->group_R = R;
+    E->group_built = true;
+    if (E->b_monotone) group_f32_build_table(st, c_out->row_p, c_out->col_i, E->descs.p, nbr, nbc, R, S, E->groups.p);
+  }
+  if (!E->b_monotone) return 1;
+  GroupGeom G;
+  G.nbc = nbc, G.ng = ng, G.ngx = ngx;
+  const int64_t b_bytes = (int64_t)b->nblks * S * S * (int64_t)sizeof(float);
+  int np = (int)std::min<int64_t>(std::max<int64_t>(1, (b_bytes + E->panel_bytes - 1) / E->panel_bytes), (int64_t)nbc);
+  G.pw = (nbc + np - 1) / np;
+  G.np = (nbc + G.pw - 1) / G.pw;
+  const unsigned nwg = 8u * (unsigned)(((int64_t)ngx * nbc + 3) / 4);
+  const float* ad = static_cast<const float*>(a->data);
+  const float* bd = static_cast<const float*>(b->data);
+  float* cd = static_cast<float*>(c_out->data);
+  const float* cid = static_cast<const float*>(c_in->data);
+  return group_f32_launch(S, R, nwg, st, E->descs.p, E->entries.p, ad, bd, cd, cid, alpha, beta, skip_empty, E->groups.p, G);
+}
 
 static inline void plan_invalidate(Engine* E) { E->plan_saved = E->plan_hit = E->plan_numeric = false; }
 
@@ -701,6 +741,10 @@ int dbcsr_amd_mm_create(void** handle) {
   if (const char* k = getenv("DBCSR_AMD_MM_TINY")) E->use_tiny = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_F32_DIRECT")) E->f32_direct = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_BIG")) E->use_big = atoi(k);
+  if (const char* k = getenv("DBCSR_AMD_MM_F32_GROUP")) {
+    const int r = atoi(k);
+    E->f32_group = (r >= 2 && r <= 4) ? r : (r == 0 ? 0 : -1);
+  }
   if (const char* k = getenv("DBCSR_AMD_MM_SYMBOLIC")) {
     E->force_word_kernels = strcmp(k, "word") == 0;
     E->force_symbolic = strcmp(k, "word") == 0 ? 1 : (strcmp(k, "grid") == 0 ? 2 : (strcmp(k, "rows") == 0 ? 3 : 0));
@@ -1097,7 +1141,7 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
   if (nblk == 0) return 0;
   // plan reuse: product lists, descriptors and launch order of the previous multiply stand; C's index is copied from the saved one
   const bool reuse = E->plan_hit && E->plan_numeric;
-  if (!reuse) E->work_built = E->tile_built = E->band_built = false;
+  if (!reuse) E->work_built = E->tile_built = E->band_built = E->group_built = false;
   if (E->entries.ensure((size_t)E->nproducts + 1) || E->descs.ensure((size_t)nblk + 1)) return -1;
   ACC_CHECK(hipEventRecord(E->ev[0], st));
   if (reuse) {
@@ -1402,7 +1446,20 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
       snprintf(E->last_kernel, sizeof E->last_kernel, "mm_numeric_f32_lds[per class segment]");
     } else if (small32 && E->use_lds) {
       const unsigned nwg_o = (unsigned)(8 * E->order_len / ww);
-      if (E->use_hot && E->hot_m > 0 && E->f32_direct &&
+      int grp_rc = 1;
+      if (E->use_hot && E->hot_m > 0 && E->hot_m == E->hot_n && E->hot_m == E->hot_k && E->f32_direct && E->f32_group != 0 && E->min_k == E->max_k &&
+          E->max_k == E->hot_k && (E->f32_group > 0 || (E->nproducts >= 16 * nblk && nblk >= 1024))) {
+        grp_rc = run_group_f32(E, E->f32_group > 0 ? E->f32_group : 4, reuse, st, a, b, c_in, c_out, (float)alpha, (float)beta, skip_empty);
+        if (grp_rc < 0) return -1;
+      }
+      if (grp_rc == 0) {
+        // the C blocks of other sizes (tail block row / column): the one-wave-per-block kernel, told to leave the dominant size alone
+        if (E->hot_cnt_m < nbr || E->hot_cnt_n < b->nblkcols)
+          launch_hot_f32_direct(E->hot_m, E->hot_n, E->hot_k, dim3(nwg_o), ww, st, E->descs.p, nblk, E->entries.p, static_cast<const float*>(a->data),
+                                static_cast<const float*>(b->data), static_cast<float*>(c_out->data), static_cast<const float*>(c_in->data),
+                                (float)alpha, (float)beta, skip_empty | 2, E->order.p);
+        snprintf(E->last_kernel, sizeof E->last_kernel, "mm_numeric_f32_group<%d,%d,%d;%d>", E->hot_m, E->hot_n, E->hot_k, E->group_R);
+      } else if (E->use_hot && E->hot_m > 0 && E->f32_direct &&
           launch_hot_f32_direct(E->hot_m, E->hot_n, E->hot_k, dim3(nwg_o), ww, st, E->descs.p, nblk, E->entries.p, static_cast<const float*>(a->data),
                                 static_cast<const float*>(b->data), static_cast<float*>(c_out->data), static_cast<const float*>(c_in->data),
                                 (float)alpha, (float)beta, skip_empty, E->order.p)) {

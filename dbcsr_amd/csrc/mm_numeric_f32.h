@@ -197,9 +197,7 @@ __device__ __forceinline__ void cblock_f32_exact(const Desc& d, const Entry* __r
 //     four B values of one ds_read_b128 four successive steps' operands.
 // acc: register r of lane l = C[m = l & 31][n = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)]: for a fixed r a half-wave writes 128
 // consecutive bytes of C.  K must be a multiple of 8 (a half's k range a multiple of 4); the other sizes keep cblock_f32_exact.
-constexpr int F32D_ROWS = 32;
-static inline constexpr int f32d_pitch(int K) { return K + 4; }
-static inline constexpr int f32d_wave_floats(int K) { return F32D_ROWS * f32d_pitch(K); }
+// (F32D_ROWS, f32d_pitch, f32d_wave_floats: mm_group.h, shared with the group form)
 
 template <int M, int N, int K>
 __device__ __forceinline__ void cblock_f32_direct(const Desc& d, const Entry* __restrict__ entries, const float* __restrict__ a_data,
@@ -295,7 +293,7 @@ static inline size_t f32_lds_bytes(int wg_waves) { return ((size_t)wg_waves * F3
   const int64_t cb = order[pos];                                                                       \
   if (cb < 0 || cb >= nblk) return;                                                                    \
   const Desc d = descs[cb];                                                                            \
-  if (skip_empty && d.prod_cnt == 0) return;                                                           \
+  if ((skip_empty & 1) && d.prod_cnt == 0) return;                                                     \
   float* lds_a = smem + (size_t)wid * F32_WAVE_FLOATS;                                                 \
   float* lds_bt = lds_a + F32_A_FLOATS;
 
@@ -327,6 +325,7 @@ __global__ void __launch_bounds__(256) mm_numeric_f32_direct(const Desc* __restr
                                                              float* __restrict__ c_out, const float* __restrict__ c_in, float alpha,
                                                              float beta, int skip_empty, const int* __restrict__ order) {
   DBCSR_F32_KERNEL_HEAD
+  if ((skip_empty & 2) && d.m == M && d.n == N) return;  // the group kernel (mm_numeric_f32_group.h) computed the blocks of the dominant size
   if (d.m == M && d.n == N)
     cblock_f32_direct<M, N, K>(d, entries, a_data, b_data, c_out, c_in, alpha, beta, lane, lds_a);
   else
@@ -342,7 +341,7 @@ __global__ void __launch_bounds__(256) mm_numeric_f32(const Desc* __restrict__ d
   const int64_t cb = __builtin_amdgcn_readfirstlane(wg * 4 + (int)(threadIdx.x >> 6));
   if (cb >= nblk) return;
   const Desc d = descs[cb];
-  if (skip_empty && d.prod_cnt == 0) return;
+  if ((skip_empty & 1) && d.prod_cnt == 0) return;
   const int m = d.m, n = d.n;
   const Entry* e = entries + d.prod_start;
   const bool has_in = d.cin_off >= 0;

@@ -333,7 +333,8 @@ class MultiplyEngine:
     # the A row and the B panel are 1/n of their size (measured on config 5, one GPU: 2761 ms in one pass, 2147 ms in 4
     # passes, 2357 ms in 8, tools/kchunk_probe.py).  The price -- C re-read and re-written per pass -- is why this is not
     # done for small A rows.
-    KCHUNK_ROW_BYTES = 1.5 * 2 ** 20
+    # (round 5, gpurun_out/r05_s03/sweeps.jsonl: 32768^2 of 23 x 23 at 20 % fill, A rows of 1.2 MB: 83.0 ms in one pass, 77.2 in two)
+    KCHUNK_ROW_BYTES = 1.0 * 2 ** 20
 
     def _auto_kchunks(self, A, filter_eps):
         if filter_eps and filter_eps > 0:  # the on-the-fly filter counts the blocks of a whole A row (dbcsr_mm_cannon.F:1100-1110)
