@@ -8,7 +8,7 @@ cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-( cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace --output-format csv -- "$@" ) > "$OUT/trace.log" 2>&1
+( cd /tmp && timeout 240 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace --output-format csv -- "$@" ) > "$OUT/trace.log" 2>&1
 i=0
 for PMC in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" \
            "FETCH_SIZE TCC_HIT_sum TCC_MISS_sum" "WRITE_SIZE TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" \
@@ -16,7 +16,7 @@ for PMC in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_W
            "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" \
            "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TA_BUSY_avr SQ_ACTIVE_INST_MISC SQ_BUSY_CU_CYCLES"; do
   i=$((i+1))
-  ( cd /tmp && timeout 200 rocprofv3 --pmc $PMC -d "$OUT/pmc$i" -o pmc --output-format csv -- "$@" ) > "$OUT/pmc$i.log" 2>&1
+  ( cd /tmp && timeout 240 rocprofv3 --pmc $PMC -d "$OUT/pmc$i" -o pmc --output-format csv -- "$@" ) > "$OUT/pmc$i.log" 2>&1
 done
 python3 - "$OUT" <<'PY'
 import csv, glob, os, sys, collections
