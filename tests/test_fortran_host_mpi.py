@@ -184,6 +184,25 @@ def test_matrices_stay_on_the_device_under_a_multi_rank_fortran_host(args, nrank
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nranks", [2, 4])
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_resident_products_out_of_place_and_as_operands_on_several_ranks(mode, nranks, tmp_path):
+    """round 5: a purification-style loop on several ranks.  Mode 1: C_in = the original C in every multiply, the product goes to a second
+    resident matrix; mode 2: X_{n+1} = beta C + alpha X_n B -- the product (this rank's TILE) becomes the left operand of the next multiply
+    through dbcsr_amd_dev_as_operand, which gathers its row panel from the peers' tiles (make_m2s' job, src/mm/dbcsr_mm_cannon.F:146-258)
+    without a download / dbcsr_type / create round trip.  The checksums of the same loop through dbcsr_multiply must come out (1e-10)."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "host_resident_mpi", "dbcsr_resident_loop")
+    if not (os.path.exists(exe) and os.path.exists(MPIEXEC)):
+        pytest.skip("host_resident_mpi or mpiexec not available")
+    r = subprocess.run([MPIEXEC, "-n", str(nranks), exe, "2316", "0.8", "23", "4", "1", mode], cwd=tmp_path, env=dict(ENV, DBCSR_AMD_RESIDENT="0"),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert re.search(r"ranks\s+%d\b" % nranks, r.stdout) and "resident_loop: mode %s" % mode in r.stdout, r.stdout[-2000:]
+    d = re.search(r"relative difference\s+([0-9.E+-]+)", r.stdout)
+    assert d and float(d.group(1)) <= 1e-10, r.stdout[-2000:]
+
+
+@pytest.mark.gpu
 def test_resident_rccl_request_falls_back_when_ranks_share_a_device(tmp_path):
     """DBCSR_AMD_RESIDENT_RCCL=1 with two ranks on the box's one GPU: RCCL cannot serve two ranks of a communicator on one device; the
     glue must notice on every rank (fewer devices than ranks), agree, and move the panels through MPI -- same results, no hang"""

@@ -203,3 +203,20 @@ def test_fortran_host_keeps_matrices_on_the_device(args, tmp_path):
     t_dev = float(re.search(r"per multiply \[s\]\s+([0-9.]+)", r.stdout).group(1))
     t_ref = float(re.search(r"dbcsr_multiply of this build, per multiply \[s\]\s+([0-9.]+)", r.stdout).group(1))
     assert t_dev < t_ref, r.stdout[-2000:]
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(HOST_RES, "dbcsr_resident_loop")), reason="patched reference host not built (tools/build_dbcsr_host.py resident)")
+@pytest.mark.parametrize("mode", ["1", "2"])
+@pytest.mark.parametrize("args", [("2316", "0.8", "23", "5"), ("1500", "0.5", "32", "4")], ids=["23", "32"])
+def test_fortran_host_out_of_place_products_and_product_as_operand(args, mode, tmp_path):
+    """round 5: mode 1 -- every multiply starts from the ORIGINAL C and writes its product to a second resident
+    matrix (dbcsr_amd_dev_multiply, c_out): A, B and C_in are the same generation of the same device arrays in every call, so the engine
+    reuses its plan by address (dbcsr_amd_resident.F stamps every index array it owns); mode 2 -- the product of one multiply is the
+    LEFT operand of the next (dbcsr_amd_dev_as_operand), nothing goes through a dbcsr_type in between.  Checksums of the same loops
+    through the library's own dbcsr_multiply, 1e-10."""
+    r = subprocess.run([os.path.join(HOST_RES, "dbcsr_resident_loop"), *args, "1", mode], cwd=tmp_path, env=dict(ENV, DBCSR_AMD_RESIDENT="0"),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "resident_loop: mode %s" % mode in r.stdout, r.stdout[-2000:]
+    d = re.search(r"relative difference\s+([0-9.E+-]+)", r.stdout)
+    assert d and float(d.group(1)) <= 1e-10, r.stdout[-2000:]
