@@ -260,9 +260,11 @@ struct Engine {
   const void* norms_data = nullptr;  // norms64[] holds the block norms of the matrix with this data pointer (left by the numeric kernel)
   int64_t norms_nblks = 0;
   int canonical_c = 0;  // dbcsr_amd_mm_set_canonical_product: the product matrix has symmetry, its index is in canonical form
-  // fp32: a wave owns R C blocks of one block column and shares B among them (mm_numeric_f32_group.h).  DBCSR_AMD_MM_F32_GROUP = 0: off,
-  // 2 / 3 / 4: that R whenever the kernel applies, unset: R = 4 when C blocks have at least 16 products on average
-  int f32_group = -1, group_R = 0;
+  // fp32: a wave owns R C blocks of one block column and shares B among them (mm_group.h).  DBCSR_AMD_MM_F32_GROUP = 2 / 3 / 4: that R
+  // whenever the kernel applies; -1: R = 4 when C blocks have at least 16 products on average; 0 / unset: off -- measured (gpurun_out/r05_s04:
+  // 32768^2 at 20 % fill 32.1 ms against 28.6 for one wave per block, config 5 2125 against 1836 ms) it trades B blocks over the fabric for
+  // A rows that no longer fit the XCD's L2 and for occupancy (3 waves per SIMD instead of 5), and loses
+  int f32_group = 0, group_R = 0;
   bool group_built = false, b_monotone = false;
   DevBuf<int> groups, group_flag;
   int use_big = 1;     // DBCSR_AMD_MM_BIG=0: blocks above 32 through the one-wave-per-block kernel of rounds 1-4 (mm_numeric_f64) instead of mm_numeric_f64_big
@@ -743,7 +745,7 @@ int dbcsr_amd_mm_create(void** handle) {
   if (const char* k = getenv("DBCSR_AMD_MM_BIG")) E->use_big = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_F32_GROUP")) {
     const int r = atoi(k);
-    E->f32_group = (r >= 2 && r <= 4) ? r : (r == 0 ? 0 : -1);
+    E->f32_group = (r >= 2 && r <= 4) ? r : (r < 0 ? -1 : 0);
   }
   if (const char* k = getenv("DBCSR_AMD_MM_SYMBOLIC")) {
     E->force_word_kernels = strcmp(k, "word") == 0;

@@ -153,11 +153,18 @@ def test_group_kernel_stands_back(monkeypatch):
     check(dev_to_bcsr(dC), ref)
 
 
-def test_group_kernel_is_chosen_by_itself(monkeypatch):
-    """no switch: long lists (at least 16 products per C block on average, 1024 blocks) take R = 4, short ones the one-wave-per-block kernel"""
+def test_group_kernel_automatic_choice(monkeypatch):
+    """DBCSR_AMD_MM_F32_GROUP=-1: long lists (at least 16 products per C block on average, 1024 blocks) take R = 4, short ones the
+    one-wave-per-block kernel; unset: the one-wave-per-block kernel always (the group kernel does not win on MI355X, see mm_engine.hip)"""
     for k in ENV:
         monkeypatch.delenv(k, raising=False)
     A, B, Cm = build((32 * 36, 32 * 34, 32 * 120, 0.6, 0.6, 0.5, 32))   # 120 * 0.16 = 19 products per block
+    eng = MultiplyEngine()
+    dA, dB, dC = to_dev(A), to_dev(B), to_dev(Cm)
+    dbcsr_multiply("N", "N", 1.0, dA, dB, 1.0, dC, engine=eng)
+    torch.cuda.synchronize()
+    assert eng.last_kernel() == "mm_numeric_f32_direct<32,32,32>", eng.last_kernel()
+    monkeypatch.setenv("DBCSR_AMD_MM_F32_GROUP", "-1")
     ref, _ = O.multiply("N", "N", 1.0, wide(A), wide(B), 1.0, wide(Cm))
     eng = MultiplyEngine()
     dA, dB, dC = to_dev(A), to_dev(B), to_dev(Cm)
