@@ -152,15 +152,32 @@ int k_passes(void* h, libsmm_acc_data_t dt, const dbcsr_amd_bcsr* a, double filt
   if (filter_eps > 0.0) return 1;  // the on-the-fly filter counts the blocks of a whole A row
   if (const char* f = getenv("DBCSR_AMD_MM_KCHUNKS")) return atoi(f) > 1 ? atoi(f) : 1;
   if (a->nblkcols < 64 || a->nblkrows < 1) return 1;
+  // The probe below runs on the engine and costs it its plan (it shares the symbolic phase's work areas): a loop that multiplies the
+  // same resident operand again and again (dbcsr_amd_dev_multiply) would pay a full symbolic phase per call for it -- 1.6 of config 2's
+  // 20.3 ms from a Fortran host (gpurun_out/r05_s05).  The answer only steers speed, so it is remembered per engine for the operand whose
+  // index arrays sit at the same addresses with the same block count (and stamp).
+  struct Memo {
+    void* h;
+    const void *row_p, *blk_p;
+    int64_t nblks;
+    uint64_t stamp;
+    int npass;
+  };
+  static thread_local Memo memo = {nullptr, nullptr, nullptr, -1, 0, 1};
+  if (memo.h == h && memo.row_p == a->row_p && memo.blk_p == a->blk_p && memo.nblks == a->nblks && memo.stamp == (uint64_t)a->index_stamp) return memo.npass;
+  auto remember = [&](int n) {
+    memo = Memo{h, a->row_p, a->blk_p, (int64_t)a->nblks, (uint64_t)a->index_stamp, n};
+    return n;
+  };
   Owned probe;
   if (alloc_row_p(probe, a->nblkrows)) return 1;
   int64_t nb = 0, nz = 0;
   if (dbcsr_amd_bcsr_crop_count(h, dt, a, -1, -1, -1, -1, probe.m.row_p, &nb, &nz, stream)) return 1;
   const double row_bytes = (double)nz * (double)elem_size(dt) / (double)a->nblkrows;
-  if (row_bytes <= 1.0 * 1048576.0) return 1;      // (round 5: 23 x 23 at 20 % fill, rows of 1.2 MB, gains 7 % from two passes)
-  if (nb > 0 && nz > 1024 * nb) return 1;           // blocks above 32 x 32 on average: the workgroup-per-C-block kernel shares its operands in LDS
+  if (row_bytes <= 1.0 * 1048576.0) return remember(1);      // (round 5: 23 x 23 at 20 % fill, rows of 1.2 MB, gains 7 % from two passes)
+  if (nb > 0 && nz > 1024 * nb) return remember(1);           // blocks above 32 x 32 on average: the workgroup-per-C-block kernel shares its operands in LDS
   const int n = (int)std::ceil(row_bytes / 1048576.0);
-  return n > 8 ? 8 : n;
+  return remember(n > 8 ? 8 : n);
 }
 
 int multiply_in_k_passes(void* h, libsmm_acc_data_t dt, double alpha, const dbcsr_amd_bcsr* a, const dbcsr_amd_bcsr* b, double beta,
