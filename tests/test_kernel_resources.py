@@ -70,6 +70,15 @@ def test_no_scratch_and_exact_kernels_keep_their_occupancy(tmp_path):
     too_big = {n: v for n, v in hot64.items() if v > (128 if size_of(n) <= 24 else 184)}
     assert not too_big, too_big
     assert all(v <= 96 for v in hot32.values()), hot32
+    # round 5.  The fp32 direct kernels: five waves per SIMD (<= 96 registers).  The workgroup-per-C-block kernels of the blocks of 33 ... 80:
+    # 16 shapes, the largest (5 x 5 tiles per wave: 50 accumulator registers) within 3 waves per SIMD (<= 168), the smallest within 8.
+    # The fp32 group kernels: R accumulator sets in architectural registers (VGPR-form MFMA), two waves per SIMD at least.
+    direct32 = {pretty[n]: k["vgpr_count"] for n, k in ks.items() if "mm_numeric_f32_direct<" in pretty[n]}
+    assert len(direct32) == 3 and all(v <= 96 for v in direct32.values()), direct32
+    big = {pretty[n]: k["vgpr_count"] for n, k in ks.items() if "mm_numeric_f64_big<" in pretty[n]}
+    assert len(big) == 16 and all(v <= 168 for v in big.values()), big
+    group = {pretty[n]: k["vgpr_count"] for n, k in ks.items() if "mm_numeric_f32_group<" in pretty[n]}
+    assert len(group) == 9 and all(v <= 256 for v in group.values()), group
 
 
 def test_shipping_build_holds_no_experiment(tmp_path):

@@ -21,6 +21,7 @@ for PMC in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_W
            "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_FLAT SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVES"; do
   i=$((i+1))
+  [ -n "${PROFILE_PASSES:-}" ] && [ $i -gt "$PROFILE_PASSES" ] && break   # (a session short of GPU minutes: the first passes only)
   ( cd /tmp && timeout 150 rocprofv3 --pmc $PMC -d "$OUT/pmc$i" -o pmc --output-format csv -- python "$OLDPWD/bench.py" $ARGS ) > "$OUT/pmc$i.log" 2>&1
 done
 python3 - "$OUT" <<'PY'
