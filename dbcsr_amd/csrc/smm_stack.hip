@@ -18,8 +18,12 @@
 #include <mutex>
 
 #include "../../include/dbcsr_acc_libsmm.h"
+#include <algorithm>
+
 #include "common.h"
+#include "mm_types.h"
 #include "smm_core.h"
+#include "mm_numeric_f64_big.h"   // slab geometry of the workgroup-per-C-block kernel (BIG_KSL, BIG_PB, big_*_bytes)
 
 namespace dbcsr_amd {
 
@@ -133,6 +137,146 @@ __global__ void __launch_bounds__(256) smm_stack_f64_lds(const int* __restrict__
       if (c < ncb) *reinterpret_cast<u32x4s*>(lds_b + c * 1024 + voff) = rb[c];
     if (s + 1 < last) issue(s + 1);
     block_product_f64_lds<MA, NC, BT>(acc, reinterpret_cast<const double*>(lds_a), reinterpret_cast<const double*>(lds_b), m, n, k, L);
+  }
+  flush(cur_c);
+}
+
+// Blocks of 33 ... 80 (or an inner dimension above 32) under the acc ABI (round 5): the dataflow of mm_numeric_f64_big.h on a parameter
+// stack.  A WORKGROUP takes `group` consecutive stack entries; its four waves own the C block as 2 x 2 sub-blocks of TM x TN MFMA tiles
+// and keep the sums in registers across runs of equal C offsets (atomic adds at the end of a run, as the other stack kernels and the
+// reference's kernels do, kernels/smm_acc_dnt_largeDB2.h:159-314); a product is consumed in slabs of 16 inner indices copied once into
+// LDS by all 256 threads and read by every wave, double-buffered over slabs AND entries.  B as libsmm_acc_transpose leaves it (n x k, BT):
+// its slab is as contiguous as A's; B as stored (k x n): n runs of 128 bytes with the padded pitch of the engine's kernel.
+// (smm_stack_f64 walks 32 x 32 tiles one after the other with fragments from global memory: 11.6 TFLOP/s at 72^3, acc_bench.)
+template <int TM, int TN, bool BT>
+__global__ void __launch_bounds__(256) smm_stack_f64_big(const int* __restrict__ stack, int nstack, const double* __restrict__ a_data,
+                                                         const double* __restrict__ b_data, double* __restrict__ c_data, int m, int n, int k,
+                                                         int group) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int RA = big_a_rounds(TM), RBC = big_a_rounds(TN), RBS = big_b_rounds(TN), RB = BT ? RBC : RBS;
+  constexpr int ABYTES = big_a_bytes(TM), BUF = ABYTES + (BT ? big_a_bytes(TN) : big_b_bytes(TN));
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int first = blockIdx.x * group;
+  if (first >= nstack) return;
+  const int last = min(first + group, nstack);
+  const LaneMap L(lane);
+  const int mt = (m + 7) >> 3, nt = (n + 7) >> 3;
+  const int ta0 = (wid >> 1) * ((mt + 1) >> 1), tc0 = (wid & 1) * ((nt + 1) >> 1);
+  double acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int c = 0; c < TN; ++c) acc[a][c] = 0.0;
+  int fa[TM], fb[TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+    int row = 8 * (ta0 + a) + L.rowl;
+    row = row < m ? row : m - 1;
+    fa[a] = row + m * L.kq;
+  }
+#pragma unroll
+  for (int c = 0; c < TN; ++c) {
+    int col = 8 * (tc0 + c) + L.coll;
+    col = col < n ? col : n - 1;
+    fb[c] = ABYTES / 8 + (BT ? col + n * L.kq : col * BIG_PB + L.kq);
+  }
+  const int astep = 4 * m, bstep = BT ? 4 * n : 4;
+  const int bk = 2 * (tid & 7), bc = tid >> 3;
+  u32x4 ga[RA], gb[RB];
+  int k0_cur = 0;
+  auto issue = [&](int s, int k0) {
+    const int ao = __builtin_amdgcn_readfirstlane(stack[3 * s]) - 1, bo = __builtin_amdgcn_readfirstlane(stack[3 * s + 1]) - 1;
+    const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)(a_data + ao), 0, m * k * 8, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)(b_data + bo), 0, k * n * 8, 0x00020000);
+    const int abase = tid * 16 + k0 * m * 8;   // (the whole offset in the bounds-checked operand: the k tail must arrive as zeros)
+#pragma unroll
+    for (int r = 0; r < RA; ++r) ga[r] = __builtin_amdgcn_raw_buffer_load_b128(rsa, abase + r * 4096, 0, 0);
+    if constexpr (BT) {
+      const int bbase = tid * 16 + k0 * n * 8;
+#pragma unroll
+      for (int r = 0; r < RB; ++r) gb[r] = __builtin_amdgcn_raw_buffer_load_b128(rsb, bbase + r * 4096, 0, 0);
+    } else {
+#pragma unroll
+      for (int r = 0; r < RB; ++r) {
+        const int col = 32 * r + bc;
+        const int off = col < n ? (col * k + k0 + bk) * 8 : 0x7ffffff0;
+        gb[r] = __builtin_amdgcn_raw_buffer_load_b128(rsb, off, 0, 0);
+      }
+    }
+    k0_cur = k0;
+  };
+  auto stage = [&](char* buf) {
+#pragma unroll
+    for (int r = 0; r < RA; ++r) *reinterpret_cast<u32x4*>(buf + r * 4096 + tid * 16) = ga[r];
+    if constexpr (BT) {
+#pragma unroll
+      for (int r = 0; r < RB; ++r) *reinterpret_cast<u32x4*>(buf + ABYTES + r * 4096 + tid * 16) = gb[r];
+    } else {
+      const bool k0ok = k0_cur + bk < k, k1ok = k0_cur + bk + 1 < k;
+#pragma unroll
+      for (int r = 0; r < RB; ++r) {
+        u32x4 v = gb[r];
+        if (!k0ok) v[0] = 0u, v[1] = 0u;
+        if (!k1ok) v[2] = 0u, v[3] = 0u;
+        *reinterpret_cast<u32x4*>(buf + ABYTES + ((32 * r + bc) * BIG_PB + bk) * 8) = v;
+      }
+    }
+  };
+  auto flush = [&](int co) {
+    double* C = c_data + (co - 1);
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int c = 0; c < TN; ++c) {
+        const int ta = ta0 + a, tc = tc0 + c;
+        const int row = 8 * ta + L.rowd, col = 8 * tc + L.coll;
+        const bool mine = ta < ((wid >> 1) ? mt : ((mt + 1) >> 1)) && tc < ((wid & 1) ? nt : ((nt + 1) >> 1));
+        if (mine && row < m && col < n) unsafeAtomicAdd(C + row + (size_t)m * col, acc[a][c]);
+        acc[a][c] = 0.0;
+      }
+  };
+  int s = first, k0 = 0, it = 0;
+  int cur_c = __builtin_amdgcn_readfirstlane(stack[3 * first + 2]);
+  issue(first, 0);
+  while (s < last) {
+    char* buf = smem + (it & 1) * BUF;
+    if (k0 == 0) {   // a new entry: the end of a run of equal C offsets?
+      const int co = __builtin_amdgcn_readfirstlane(stack[3 * s + 2]);
+      if (co != cur_c) {
+        flush(cur_c);
+        cur_c = co;
+      }
+    }
+    const int rem = (k - k0 + 3) >> 2;
+    const int nst = rem < BIG_KSL / 4 ? rem : BIG_KSL / 4;
+    stage(buf);
+    __syncthreads();
+    int s2 = s, k2 = k0 + BIG_KSL;
+    if (k2 >= k) s2 = s + 1, k2 = 0;
+    if (s2 < last) issue(s2, k2);
+    const double* la = reinterpret_cast<const double*>(buf);
+    double av[2][TM], bv[2][TN];
+    auto fetch = [&](int st_, int set) {
+#pragma unroll
+      for (int a = 0; a < TM; ++a) av[set][a] = la[fa[a] + astep * st_];
+#pragma unroll
+      for (int c = 0; c < TN; ++c) bv[set][c] = la[fb[c] + bstep * st_];
+    };
+    fetch(0, 0);
+#pragma unroll
+    for (int st_ = 0; st_ < BIG_KSL / 4; ++st_) {
+      if (st_ + 1 < nst) fetch(st_ + 1, (st_ + 1) & 1);
+      if (st_ < nst) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int c = 0; c < TN; ++c) acc[a][c] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[st_ & 1][a], bv[st_ & 1][c], acc[a][c], 0, 0, 0);
+      }
+    }
+    s = s2;
+    k0 = k2;
+    ++it;
   }
   flush(cur_c);
 }
@@ -326,10 +470,40 @@ static int launch_f64_nc(int NC, bool bt, dim3 grid, hipStream_t st, const int* 
   }
 }
 
+template <int TM, int TN>
+static int launch_f64_big(bool bt, hipStream_t st, const int* stack, int nstack, const double* a, const double* b, double* c, int m, int n, int k) {
+  const int group = 8;   // stack entries per workgroup (16 k slabs of a 72^3 product are 1600 MFMA cycles per wave: runs rarely span more)
+  const dim3 grid((unsigned)((nstack + group - 1) / group));
+  if (bt)
+    hipLaunchKernelGGL((smm_stack_f64_big<TM, TN, true>), grid, dim3(256), (size_t)2 * (big_a_bytes(TM) + big_a_bytes(TN)), st, stack, nstack, a, b, c, m, n, k, group);
+  else
+    hipLaunchKernelGGL((smm_stack_f64_big<TM, TN, false>), grid, dim3(256), (size_t)2 * (big_a_bytes(TM) + big_b_bytes(TN)), st, stack, nstack, a, b, c, m, n, k, group);
+  return dbcsr_amd::check(hipGetLastError(), "smm_stack_f64_big launch", __FILE__, __LINE__);
+}
+
+static int process_stack_f64_big(const int* dev_stack, int nstack, const double* a, const double* b, double* c, int m, int n, int k, bool bt,
+                                 hipStream_t st) {
+  const int tm = std::max(2, ((m + 7) / 8 + 1) / 2), tn = std::max(2, ((n + 7) / 8 + 1) / 2);
+  switch (tm * 8 + tn) {
+#define DBCSR_BIG_STACK(A_, B_) \
+  case A_ * 8 + B_: return launch_f64_big<A_, B_>(bt, st, dev_stack, nstack, a, b, c, m, n, k);
+    DBCSR_BIG_STACK(2, 2) DBCSR_BIG_STACK(2, 3) DBCSR_BIG_STACK(2, 4) DBCSR_BIG_STACK(2, 5)
+    DBCSR_BIG_STACK(3, 2) DBCSR_BIG_STACK(3, 3) DBCSR_BIG_STACK(3, 4) DBCSR_BIG_STACK(3, 5)
+    DBCSR_BIG_STACK(4, 2) DBCSR_BIG_STACK(4, 3) DBCSR_BIG_STACK(4, 4) DBCSR_BIG_STACK(4, 5)
+    DBCSR_BIG_STACK(5, 2) DBCSR_BIG_STACK(5, 3) DBCSR_BIG_STACK(5, 4) DBCSR_BIG_STACK(5, 5)
+#undef DBCSR_BIG_STACK
+    default: return -1;
+  }
+}
+
 int process_stack_f64(const int* dev_stack, int nstack, const double* a, const double* b, double* c, int m, int n, int k, bool bt,
                       hipStream_t st) {
   if (nstack <= 0) return 0;
   if (m <= 0 || n <= 0 || k <= 0) return 0;
+  // blocks of 33 ... 80 (or an inner dimension above 32): a workgroup per group of entries, operand slabs shared through LDS
+  static const bool big_off = getenv("DBCSR_AMD_SMM_BIG") != nullptr && atoi(getenv("DBCSR_AMD_SMM_BIG")) == 0;
+  if (!big_off && (m > 32 || n > 32 || k > 32) && m <= 80 && n <= 80 && (int64_t)m * k * 8 < (1ll << 30) && (int64_t)n * k * 8 < (1ll << 30))
+    return process_stack_f64_big(dev_stack, nstack, a, b, c, m, n, k, bt, st);
   // C tile per wave: up to 32 x 32; larger blocks are tiled over grid.y/z
   const int MA = m >= 32 ? 4 : (m + 7) / 8, NC = n >= 32 ? 4 : (n + 7) / 8;
   const int tiles_r = (m + 8 * MA - 1) / (8 * MA), tiles_c = (n + 8 * NC - 1) / (8 * NC);

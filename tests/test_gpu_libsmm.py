@@ -14,7 +14,11 @@ pytestmark = pytest.mark.gpu
 
 # tuned flagship triplets of the reference + GPU block mixes of tests/dbcsr_unittest3.F:79-120 + odd shapes
 TRIPLETS = [(23, 23, 23), (13, 13, 13), (32, 32, 32), (4, 4, 4), (5, 7, 9), (1, 3, 4), (13, 23, 32), (32, 13, 23), (23, 16, 23),
-            (16, 23, 16), (14, 29, 32), (4, 13, 25), (9, 8, 5), (24, 24, 24), (45, 67, 78), (78, 45, 67), (1, 1, 1), (7, 1, 33)]
+            (16, 23, 16), (14, 29, 32), (4, 13, 25), (9, 8, 5), (24, 24, 24), (45, 67, 78), (78, 45, 67), (1, 1, 1), (7, 1, 33),
+            # round 5: the workgroup-per-entry-group kernel of the blocks of 33 ... 80 (smm_stack_f64_big): every sub-block shape edge, inner
+            # dimensions with every remainder modulo 4 and 16
+            (72, 72, 72), (80, 80, 80), (64, 64, 64), (40, 40, 40), (33, 33, 33), (55, 55, 55), (23, 23, 78), (80, 16, 37), (13, 72, 33),
+            (48, 56, 17), (48, 56, 18), (48, 56, 19), (41, 49, 35), (80, 80, 1), (33, 80, 64)]
 
 
 @pytest.mark.parametrize("m,n,k", TRIPLETS)
@@ -213,3 +217,30 @@ def test_random_triplets_and_stacks_exact(seed):
     rc, c = run_stack(stack, a, b, np.zeros(nc * m * n), m, n, k, L.dbcsr_type_real_8)
     assert rc >= 0
     assert np.array_equal(c, c_ref), (m, n, k, nstack, order)
+
+
+@pytest.mark.parametrize("m,n,k", [(72, 72, 72), (45, 67, 78), (40, 33, 35), (23, 23, 50)])
+def test_large_block_stack_with_b_as_stored_and_random_order(m, n, k):
+    """smm_stack_f64_big with B NOT transposed (a host whose max_kernel_dim is below the block size skips libsmm_acc_transpose,
+    libsmm_acc.cpp:485) and with C offsets in random order (runs of length one: a flush per entry), random values"""
+    rng = np.random.default_rng(11)
+    na, nb, nc, nstack = 40, 50, 6, 301
+    a, b, c0 = rng.random(na * m * k), rng.random(nb * k * n), rng.random(nc * m * n)
+    stack = np.empty(3 * nstack, np.int32)
+    stack[0::3] = rng.integers(0, na, nstack) * m * k + 1
+    stack[1::3] = rng.integers(0, nb, nstack) * k * n + 1
+    stack[2::3] = rng.integers(0, nc, nstack) * m * n + 1
+    c_ref = c0.copy()
+    O.stack_calc(stack, c_ref, a, b, m, n, k, b_transposed=False)
+    # max_kernel_dim below the block's dimensions: no transposition, libsmm_acc_process is told so through the same argument
+    rc, c = run_stack(stack, a, b, c0.copy(), m, n, k, L.dbcsr_type_real_8, max_kernel_dim=20, transpose_b=True)
+    assert rc >= 0
+    assert rel_err(c, c_ref) <= 1e-10
+    # and transposed, sorted by C as the accelerator driver sorts its stacks
+    order = np.argsort(stack[2::3], kind="stable")
+    st = np.empty_like(stack)
+    for q in range(3):
+        st[q::3] = stack[q::3][order]
+    rc, c = run_stack(st, a, b, c0.copy(), m, n, k, L.dbcsr_type_real_8)
+    assert rc >= 0
+    assert rel_err(c, c_ref) <= 1e-10
