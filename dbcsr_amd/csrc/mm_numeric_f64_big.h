@@ -26,7 +26,9 @@ constexpr int BIG_PB = 20;   // pitch of B's slab in LDS, doubles
 static inline constexpr int big_a_rounds(int TM) { return (16 * TM * BIG_KSL * 8 + 4095) / 4096; }
 static inline constexpr int big_b_rounds(int TN) { return (16 * TN + 31) / 32; }
 static inline constexpr int big_a_bytes(int TM) { return big_a_rounds(TM) * 4096; }
-static inline constexpr int big_b_bytes(int TN) { return big_b_rounds(TN) * 32 * BIG_PB * 8; }
+// (B's part holds exactly the 16 TN columns a workgroup can own: with whole rounds of 32 columns the 5-tile shapes needed 55 KB for
+// their two buffers and only two workgroups fitted a CU's 160 KB; 49 KB lets three in)
+static inline constexpr int big_b_bytes(int TN) { return 16 * TN * BIG_PB * 8; }
 static inline constexpr int big_lds_bytes(int TM, int TN) { return 2 * (big_a_bytes(TM) + big_b_bytes(TN)); }
 
 template <int TM, int TN>
@@ -106,7 +108,7 @@ __global__ void __launch_bounds__(256) mm_numeric_f64_big(const Desc* __restrict
       u32x4 v = gb[r];
       if (!k0ok) v[0] = 0u, v[1] = 0u;
       if (!k1ok) v[2] = 0u, v[3] = 0u;
-      *reinterpret_cast<u32x4*>(buf + ABYTES + ((32 * r + bc) * BIG_PB + bk) * 8) = v;
+      if (32 * r + bc < 16 * TN) *reinterpret_cast<u32x4*>(buf + ABYTES + ((32 * r + bc) * BIG_PB + bk) * 8) = v;
     }
   };
   // the walk over (product, slab): wave-uniform scalars

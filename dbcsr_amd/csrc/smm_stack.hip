@@ -219,7 +219,7 @@ __global__ void __launch_bounds__(256) smm_stack_f64_big(const int* __restrict__
         u32x4 v = gb[r];
         if (!k0ok) v[0] = 0u, v[1] = 0u;
         if (!k1ok) v[2] = 0u, v[3] = 0u;
-        *reinterpret_cast<u32x4*>(buf + ABYTES + ((32 * r + bc) * BIG_PB + bk) * 8) = v;
+        if (32 * r + bc < 16 * TN) *reinterpret_cast<u32x4*>(buf + ABYTES + ((32 * r + bc) * BIG_PB + bk) * 8) = v;
       }
     }
   };
