@@ -70,10 +70,22 @@ def large_blocks():
             chk = r.get("check", {})
             L.append("   m %-3s n %-3s k %-3s " % (r["mix_m"][1], r["mix_n"][1], r["mix_k"][1]) + fmt_block(r) +
                      ("  [check: index %s, diff %.1e]" % ("==" if chk.get("index_identical") else "!=", chk.get("max_abs_diff_over_max_abs", 0.0)) if chk else ""))
-    L += ["", "72^3: 13.4 -> 36.9-37.1 TFLOP/s = 0.47 of the fp64 peak in one pass (the 0.40 asked for; the reference's own tuned kernel: 8.1 TFLOP/s on",
-          "Mi250-class hardware, src/acc/libsmm_acc/parameters/parameters_Mi350.json:433).  64^3 (no padding: 8 tiles = 2 x 4): 0.62-0.64.  The padding of the 2 x 2",
-          "wave arrangement bounds the others: 72 -> 80 (0.81), 55 -> 64 (0.74), 40 -> 48 (0.69), 33 -> 48 (0.47).  k passes are switched off for blocks",
-          "above 32 (three passes cost 72^3 15 %: the slabs are shared through LDS, C re-read per pass is pure cost)."]
+    L.append("-- final (session r05_s08: B slab trimmed to the 16 TN columns a workgroup owns -> three workgroups per CU for the 5-tile shapes)")
+    for r in rows(G + "/r05_s08/large_blocks_final.jsonl"):
+        if "error" not in r:
+            chk = r.get("check", {})
+            L.append("   m %-3s n %-3s k %-3s " % (r["mix_m"][1], r["mix_n"][1], r["mix_k"][1]) + fmt_block(r) +
+                     ("  [check: index %s, diff %.1e]" % ("==" if chk.get("index_identical") else "!=", chk.get("max_abs_diff_over_max_abs", 0.0)) if chk else ""))
+    L += ["", "-- the same dataflow under the acc ABI: tools/acc_bench.py (the reference's acc_bench / kernel timer shape: a 16005-entry stack over 10000 A, 10000 B,",
+          "   1000 C blocks, libsmm_acc_transpose + libsmm_acc_process, every line checked against the CPU oracle)",
+          "   before (session r05_s06: smm_stack_f64, 32 x 32 tiles one after the other, fragments from global memory):"]
+    L += ["      " + ln.strip() for ln in open(G + "/r05_s06/acc_bench_blocks.txt")]
+    L.append("   after (session r05_s08: smm_stack_f64_big, a workgroup per 8 stack entries, sums kept across runs of equal C offsets):")
+    L += ["      " + ln.strip() for ln in open(G + "/r05_s08/acc_bench_blocks.txt")]
+    L += ["", "72^3: engine 13.4 -> 40.6 TFLOP/s = 0.52 of the fp64 peak (the 0.40 asked for), acc ABI 11.6 -> 32.3 = 0.41 (the reference's own tuned kernel: 8.1 TFLOP/s",
+          "on Mi250-class hardware, src/acc/libsmm_acc/parameters/parameters_Mi350.json:433).  80^3 0.61, 64^3 0.64 (no padding).  The padding of the 2 x 2 wave arrangement",
+          "bounds the others: 72 -> 80 (0.81 of the MFMAs useful), 55 -> 64 (0.74), 40 -> 48 (0.69), 33 -> 48 (0.47).  k passes are switched off for blocks above 32",
+          "(three passes cost 72^3 15 %: the slabs are shared through LDS, C re-read per pass is pure cost)."]
     open(P + "/r05_large_blocks.txt", "w").write("\n".join(L) + "\n")
 
 
