@@ -350,7 +350,7 @@ class MultiplyEngine:
             # re-reading and re-writing C per pass costs more than the passes save (72^3 at 30 % fill, 16384^2: 21.5 ms in one pass against
             # 25.5 ms in three, gpurun_out/r05_s02/large_blocks_after.jsonl)
             return 1
-        return int(min(8, math.ceil(row_bytes / 2 ** 20)))
+        return int(min(8, math.ceil(row_bytes / self.KCHUNK_ROW_BYTES)))   # (pieces of at most the threshold: 1 MB)
 
     def _kpass_views(self, A, B, n, counts):
         """[(A's block columns [k0, k1), B's block rows [k0, k1), an engine of its own)] for n ranges of inner blocks of about equal

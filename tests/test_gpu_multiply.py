@@ -399,3 +399,25 @@ def test_filtered_sparse_product_takes_the_product_driven_kernels():
     assert fg == fr and np.array_equal(g.row_p, r.row_p) and np.array_equal(g.col_i, r.col_i)
     assert rel_err(r.data, g.data) <= 1e-12
     assert 0 < r.nblks
+
+
+def test_h2o_like_80_percent_fill_takes_k_passes_by_itself(monkeypatch):
+    """The reference's tests/inputs/test_H2O.perf shape (2208^2, 23 x 23 blocks, sparsity 0.2 = 80 % fill).  What ships for dense fills is
+    not an operand-sharing kernel but passes over k (profiles/r05_fill_sweep.txt: 0.48-0.50 of the peak from 20 % to 80 % fill, the sharing
+    dataflows of the lab build within 1 %); the choice is automatic, by the size of A's block rows.  At this size a block row of A has 325 KB,
+    so the 1 MB rule is scaled down for the test: the shipping build must then split the product by itself, and match the oracle either way."""
+    from dbcsr_amd import multiply as MM
+    for k in ("DBCSR_AMD_MM_KCHUNKS", "DBCSR_AMD_MM_KERNEL", "DBCSR_AMD_MM_HOT"):
+        monkeypatch.delenv(k, raising=False)
+    A, B, Cm = O.perf_case(2208, 2208, 2208, 0.2, 0.2, 0.2, [1, 23], [1, 23], [1, 23])
+    ref, info = O.multiply("N", "N", 1.0, A, B, 1.0, Cm)
+    for row_bytes, passes in ((MM.MultiplyEngine.KCHUNK_ROW_BYTES, 1), (100 * 1024.0, 4)):
+        monkeypatch.setattr(MM.MultiplyEngine, "KCHUNK_ROW_BYTES", row_bytes)
+        E = MultiplyEngine(lab=False)
+        out, counts = E.multiply_local(1.0, to_dev(A), to_dev(B), 1.0, to_dev(Cm))
+        torch.cuda.synchronize()
+        assert E.last_kchunks == passes and E.last_kernel() == "mm_numeric_f64_hot<23,23,23>", (E.last_kchunks, E.last_kernel())
+        got = dev_to_bcsr(out)
+        assert np.array_equal(got.row_p, ref.row_p) and np.array_equal(got.col_i, ref.col_i)
+        assert counts.flop == info["flop"] and counts.nproducts == info["nproducts"]
+        assert np.all(np.abs(got.data - ref.data) <= 1e-10 * np.maximum(np.abs(ref.data), 1.0))
