@@ -1426,7 +1426,8 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
                E->order_len > 0 &&
                launch_big_f64(std::max(2, ((E->max_m + 7) / 8 + 1) / 2), std::max(2, ((E->max_n + 7) / 8 + 1) / 2), (unsigned)(8 * E->order_len), st,
                               E->descs.p, nblk, E->entries.p, static_cast<const double*>(a->data), static_cast<const double*>(b->data),
-                              static_cast<double*>(c_out->data), static_cast<const double*>(c_in->data), alpha, beta, skip_empty, E->order.p)) {
+                              static_cast<double*>(c_out->data), static_cast<const double*>(c_in->data), alpha, beta,
+                              skip_empty | (E->use_big == 2 ? 4 : 0), E->order.p)) {
       // blocks of 33 ... 80 (or an inner dimension above 32): one workgroup per C block, operand slabs shared through LDS (mm_numeric_f64_big.h)
       snprintf(E->last_kernel, sizeof E->last_kernel, "mm_numeric_f64_big<%d,%d>", std::max(2, ((E->max_m + 7) / 8 + 1) / 2),
                std::max(2, ((E->max_n + 7) / 8 + 1) / 2));

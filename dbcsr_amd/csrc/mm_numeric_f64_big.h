@@ -18,6 +18,8 @@
 #ifndef DBCSR_AMD_MM_NUMERIC_F64_BIG_H
 #define DBCSR_AMD_MM_NUMERIC_F64_BIG_H
 
+#include <type_traits>
+
 namespace dbcsr_amd {
 
 constexpr int BIG_KSL = 16;  // inner indices per slab
@@ -32,7 +34,7 @@ static inline constexpr int big_b_bytes(int TN) { return 16 * TN * BIG_PB * 8; }
 static inline constexpr int big_lds_bytes(int TM, int TN) { return 2 * (big_a_bytes(TM) + big_b_bytes(TN)); }
 
 template <int TM, int TN>
-__global__ void __launch_bounds__(256) mm_numeric_f64_big(const Desc* __restrict__ descs, int64_t nblk, const Entry* __restrict__ entries,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) mm_numeric_f64_big(const Desc* __restrict__ descs, int64_t nblk, const Entry* __restrict__ entries,
                                                           const double* __restrict__ a_data, const double* __restrict__ b_data,
                                                           double* __restrict__ c_out, const double* __restrict__ c_in, double alpha,
                                                           double beta, int skip_empty, const int* __restrict__ order) {
@@ -45,7 +47,7 @@ __global__ void __launch_bounds__(256) mm_numeric_f64_big(const Desc* __restrict
   const int64_t cb = order[pos];
   if (cb < 0 || cb >= nblk) return;
   const Desc d = descs[cb];
-  if (skip_empty && d.prod_cnt == 0) return;
+  if ((skip_empty & 1) && d.prod_cnt == 0) return;
   const int m = d.m, n = d.n, cnt = d.prod_cnt;
   const Entry* e = entries + d.prod_start;
   const LaneMap L(lane);
@@ -77,7 +79,7 @@ __global__ void __launch_bounds__(256) mm_numeric_f64_big(const Desc* __restrict
   u32x4 ga[RA], gb[RB];
   int ks_cur = 0;  // k extent of the product whose slab sits in the registers
   int k0_cur = 0;
-  auto issue = [&](uint64_t a_off, uint64_t b_off, int ks, int k0) {
+  auto issue = [&](uint64_t a_off, uint64_t b_off, int ks, int k0) __attribute__((always_inline)) {
     // (explicitly scalar: a descriptor the compiler believes to vary per lane turns every load into a waterfall loop, see cblock_f64_lds)
     const int abytes = __builtin_amdgcn_readfirstlane(m * ks * 8), bbytes = __builtin_amdgcn_readfirstlane(ks * n * 8);
     const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)(a_data + a_off), 0, abytes, 0x00020000);
@@ -97,7 +99,7 @@ __global__ void __launch_bounds__(256) mm_numeric_f64_big(const Desc* __restrict
     ks_cur = ks;
     k0_cur = k0;
   };
-  auto stage = [&](char* buf) {
+  auto stage = [&](char* buf) __attribute__((always_inline)) {
 #pragma unroll
     for (int r = 0; r < RA; ++r) *reinterpret_cast<u32x4*>(buf + r * 4096 + tid * 16) = ga[r];
     // B: the two k of this thread that lie past the product's k extent are the next column's elements (or zeros past the block): they meet
@@ -123,65 +125,85 @@ __global__ void __launch_bounds__(256) mm_numeric_f64_big(const Desc* __restrict
   auto a_of = [](uint32_t lo, uint32_t w) { return (uint64_t)lo | ((uint64_t)((w >> 16) & 0xffu) << 32); };
   auto b_of = [](uint32_t lo, uint32_t w) { return (uint64_t)lo | ((uint64_t)(w >> 24) << 32); };
   if (cnt > 0) issue(a_of(ea, ew), b_of(eb, ew), (int)(ew & 0xffffu), 0);
+  // The sub-blocks of the four waves are not equally large when a dimension has an odd number of tiles (72 = 9 tiles: 5 + 4; 40 = 5 tiles:
+  // 3 + 2): a wave multiplies exactly the TA x TC tiles it owns, so the SIMD's matrix pipe is free for the waves of the CU's other
+  // workgroups meanwhile (72^3: 81 useful tile products per step and workgroup instead of 100 issued).  The variant is chosen ONCE, outside
+  // the product loop -- inside, a wave-uniform switch would put the accumulators through phi copies at every trip.
   int it = 0;
-  while (p < cnt) {
-    char* buf = smem + (it & 1) * BUF;
-    const int ks = ks_cur;
-    const int rem = (ks - k0 + 3) >> 2;
-    const int nst = rem < BIG_KSL / 4 ? rem : BIG_KSL / 4;  // k steps of this slab
-    stage(buf);
-    __syncthreads();
-    // advance, and request the next slab while this one is multiplied
-    int p2 = p, k2 = k0 + BIG_KSL;
-    if (k2 >= ks) {
-      p2 = p + 1;
-      k2 = 0;
-      ea = na, eb = nb, ew = nw;
-      const int i2 = p2 + 1 < cnt ? p2 + 1 : cnt - 1;
-      na = e[i2].a_lo, nb = e[i2].b_lo, nw = e[i2].w;
-    }
-    if (p2 < cnt) issue(a_of(ea, ew), b_of(eb, ew), (int)(ew & 0xffffu), k2);
-    const double* la = reinterpret_cast<const double*>(buf);
-    // the (at most four) k steps of the slab, fragments of step s + 1 requested before the MFMAs of step s
-    double av[2][TM], bv[2][TN];
-    auto fetch = [&](int s, int set) {
-#pragma unroll
-      for (int a = 0; a < TM; ++a) av[set][a] = la[fa[a] + 4 * m * s];
-#pragma unroll
-      for (int c = 0; c < TN; ++c) bv[set][c] = la[fb[c] + 4 * s];
-    };
-    fetch(0, 0);
-#pragma unroll
-    for (int s = 0; s < BIG_KSL / 4; ++s) {
-      if (s + 1 < nst) fetch(s + 1, (s + 1) & 1);
-      if (s < nst) {
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-          for (int c = 0; c < TN; ++c) acc[a][c] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[s & 1][a], bv[s & 1][c], acc[a][c], 0, 0, 0);
+  auto run = [&](auto ta_tag, auto tc_tag) __attribute__((always_inline)) {
+    constexpr int TA = decltype(ta_tag)::value, TC = decltype(tc_tag)::value;
+    while (p < cnt) {
+      char* buf = smem + (it & 1) * BUF;
+      const int ks = ks_cur;
+      const int rem = (ks - k0 + 3) >> 2;
+      const int nst = rem < BIG_KSL / 4 ? rem : BIG_KSL / 4;  // k steps of this slab
+      stage(buf);
+      __syncthreads();
+      // advance, and request the next slab while this one is multiplied
+      int p2 = p, k2 = k0 + BIG_KSL;
+      if (k2 >= ks) {
+        p2 = p + 1;
+        k2 = 0;
+        ea = na, eb = nb, ew = nw;
+        const int i2 = p2 + 1 < cnt ? p2 + 1 : cnt - 1;
+        na = e[i2].a_lo, nb = e[i2].b_lo, nw = e[i2].w;
       }
+      if (p2 < cnt) issue(a_of(ea, ew), b_of(eb, ew), (int)(ew & 0xffffu), k2);
+      const double* la = reinterpret_cast<const double*>(buf);
+      // the (at most four) k steps of the slab, fragments of step s + 1 requested before the MFMAs of step s
+      double av[2][TA], bv[2][TC];
+      auto fetch = [&](int s, int set) {
+#pragma unroll
+        for (int a = 0; a < TA; ++a) av[set][a] = la[fa[a] + 4 * m * s];
+#pragma unroll
+        for (int c = 0; c < TC; ++c) bv[set][c] = la[fb[c] + 4 * s];
+      };
+      fetch(0, 0);
+#pragma unroll
+      for (int s = 0; s < BIG_KSL / 4; ++s) {
+        if (s + 1 < nst) fetch(s + 1, (s + 1) & 1);
+        if (s < nst) {
+#pragma unroll
+          for (int a = 0; a < TA; ++a)
+#pragma unroll
+            for (int c = 0; c < TC; ++c) acc[a][c] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[s & 1][a], bv[s & 1][c], acc[a][c], 0, 0, 0);
+        }
+      }
+      p = p2;
+      k0 = k2;
+      ++it;
     }
-    p = p2;
-    k0 = k2;
-    ++it;
+    // the epilogue inside the variant too: accumulators that met again behind the switch were kept twice (214 registers for 5 x 5 tiles)
+    double* C = c_out + d.c_off;
+    const bool has_in = d.cin_off >= 0;
+    const double* Ci = c_in + (has_in ? d.cin_off : 0);
+#pragma unroll
+    for (int a = 0; a < TA; ++a)
+#pragma unroll
+      for (int c = 0; c < TC; ++c) {
+        const int ta = ta0 + a, tc = tc0 + c;
+        const int row = 8 * ta + L.rowd, col = 8 * tc + L.coll;
+        // a tile belongs to this wave only inside its half of the tile grid (the halves overlap when a dimension has fewer tiles than 2 TM)
+        const bool mine = ta < ((wid >> 1) ? mt : ((mt + 1) >> 1)) && tc < ((wid & 1) ? nt : ((nt + 1) >> 1));
+        if (mine && row < m && col < n) {
+          double v = alpha * acc[a][c];
+          if (has_in) v += beta * Ci[row + (size_t)m * col];
+          C[row + (size_t)m * col] = v;
+        }
+      }
+  };
+  {
+    // tiles this wave owns in each dimension (the second half of an odd count is one tile short; a block smaller than the launch's largest
+    // may own fewer still: the TM - 1 / TN - 1 variant then multiplies a few tiles nobody stores)
+    const int own_r = (wid >> 1) ? mt - ((mt + 1) >> 1) : ((mt + 1) >> 1), own_c = (wid & 1) ? nt - ((nt + 1) >> 1) : ((nt + 1) >> 1);
+    const int sel = (skip_empty & 4) ? 0 : (own_r >= TM ? 0 : 2) + (own_c >= TN ? 0 : 1);   // (wave-uniform; bit 2 of skip_empty: DBCSR_AMD_MM_BIG=2, every wave issues all TM x TN tile products -- measurements)
+    switch (sel) {
+      case 0: run(std::integral_constant<int, TM>{}, std::integral_constant<int, TN>{}); break;
+      case 1: run(std::integral_constant<int, TM>{}, std::integral_constant<int, TN - 1>{}); break;
+      case 2: run(std::integral_constant<int, TM - 1>{}, std::integral_constant<int, TN>{}); break;
+      default: run(std::integral_constant<int, TM - 1>{}, std::integral_constant<int, TN - 1>{}); break;
+    }
   }
-  double* C = c_out + d.c_off;
-  const bool has_in = d.cin_off >= 0;
-  const double* Ci = c_in + (has_in ? d.cin_off : 0);
-#pragma unroll
-  for (int a = 0; a < TM; ++a)
-#pragma unroll
-    for (int c = 0; c < TN; ++c) {
-      const int ta = ta0 + a, tc = tc0 + c;
-      const int row = 8 * ta + L.rowd, col = 8 * tc + L.coll;
-      // a tile belongs to this wave only inside its half of the tile grid (the halves overlap when a dimension has fewer tiles than 2 TM)
-      const bool mine = ta < ((wid >> 1) ? mt : ((mt + 1) >> 1)) && tc < ((wid & 1) ? nt : ((nt + 1) >> 1));
-      if (mine && row < m && col < n) {
-        double v = alpha * acc[a][c];
-        if (has_in) v += beta * Ci[row + (size_t)m * col];
-        C[row + (size_t)m * col] = v;
-      }
-    }
 }
 
 }  // namespace dbcsr_amd

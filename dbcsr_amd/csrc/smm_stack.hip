@@ -151,8 +151,10 @@ __global__ void __launch_bounds__(256) smm_stack_f64_lds(const int* __restrict__
 template <int TM, int TN, bool BT>
 __global__ void __launch_bounds__(256) smm_stack_f64_big(const int* __restrict__ stack, int nstack, const double* __restrict__ a_data,
                                                          const double* __restrict__ b_data, double* __restrict__ c_data, int m, int n, int k,
-                                                         int group) {
+                                                         int group_arg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int group = group_arg & 0xffff;
+  const bool full_tiles = (group_arg >> 16) & 1;   // DBCSR_AMD_SMM_BIG_EXACT=0 (measurements): every wave issues all TM x TN tile products
   constexpr int RA = big_a_rounds(TM), RBC = big_a_rounds(TN), RBS = big_b_rounds(TN), RB = BT ? RBC : RBS;
   constexpr int ABYTES = big_a_bytes(TM), BUF = ABYTES + (BT ? big_a_bytes(TN) : big_b_bytes(TN));
   const int tid = threadIdx.x, lane = tid & 63;
@@ -185,7 +187,7 @@ __global__ void __launch_bounds__(256) smm_stack_f64_big(const int* __restrict__
   const int bk = 2 * (tid & 7), bc = tid >> 3;
   u32x4 ga[RA], gb[RB];
   int k0_cur = 0;
-  auto issue = [&](int s, int k0) {
+  auto issue = [&](int s, int k0) __attribute__((always_inline)) {
     const int ao = __builtin_amdgcn_readfirstlane(stack[3 * s]) - 1, bo = __builtin_amdgcn_readfirstlane(stack[3 * s + 1]) - 1;
     const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)(a_data + ao), 0, m * k * 8, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)(b_data + bo), 0, k * n * 8, 0x00020000);
@@ -206,7 +208,7 @@ __global__ void __launch_bounds__(256) smm_stack_f64_big(const int* __restrict__
     }
     k0_cur = k0;
   };
-  auto stage = [&](char* buf) {
+  auto stage = [&](char* buf) __attribute__((always_inline)) {
 #pragma unroll
     for (int r = 0; r < RA; ++r) *reinterpret_cast<u32x4*>(buf + r * 4096 + tid * 16) = ga[r];
     if constexpr (BT) {
@@ -223,7 +225,7 @@ __global__ void __launch_bounds__(256) smm_stack_f64_big(const int* __restrict__
       }
     }
   };
-  auto flush = [&](int co) {
+  auto flush = [&](int co) __attribute__((always_inline)) {
     double* C = c_data + (co - 1);
 #pragma unroll
     for (int a = 0; a < TM; ++a)
@@ -239,46 +241,59 @@ __global__ void __launch_bounds__(256) smm_stack_f64_big(const int* __restrict__
   int s = first, k0 = 0, it = 0;
   int cur_c = __builtin_amdgcn_readfirstlane(stack[3 * first + 2]);
   issue(first, 0);
-  while (s < last) {
-    char* buf = smem + (it & 1) * BUF;
-    if (k0 == 0) {   // a new entry: the end of a run of equal C offsets?
-      const int co = __builtin_amdgcn_readfirstlane(stack[3 * s + 2]);
-      if (co != cur_c) {
-        flush(cur_c);
-        cur_c = co;
+  // every wave multiplies exactly the TA x TC tiles it owns (see mm_numeric_f64_big.h: the variant is chosen once, outside the loop)
+  auto run = [&](auto ta_tag, auto tc_tag) __attribute__((always_inline)) {
+    constexpr int TA = decltype(ta_tag)::value, TC = decltype(tc_tag)::value;
+    while (s < last) {
+      char* buf = smem + (it & 1) * BUF;
+      if (k0 == 0) {   // a new entry: the end of a run of equal C offsets?
+        const int co = __builtin_amdgcn_readfirstlane(stack[3 * s + 2]);
+        if (co != cur_c) {
+          flush(cur_c);
+          cur_c = co;
+        }
       }
-    }
-    const int rem = (k - k0 + 3) >> 2;
-    const int nst = rem < BIG_KSL / 4 ? rem : BIG_KSL / 4;
-    stage(buf);
-    __syncthreads();
-    int s2 = s, k2 = k0 + BIG_KSL;
-    if (k2 >= k) s2 = s + 1, k2 = 0;
-    if (s2 < last) issue(s2, k2);
-    const double* la = reinterpret_cast<const double*>(buf);
-    double av[2][TM], bv[2][TN];
-    auto fetch = [&](int st_, int set) {
+      const int rem = (k - k0 + 3) >> 2;
+      const int nst = rem < BIG_KSL / 4 ? rem : BIG_KSL / 4;
+      stage(buf);
+      __syncthreads();
+      int s2 = s, k2 = k0 + BIG_KSL;
+      if (k2 >= k) s2 = s + 1, k2 = 0;
+      if (s2 < last) issue(s2, k2);
+      const double* la = reinterpret_cast<const double*>(buf);
+      double av[2][TA], bv[2][TC];
+      auto fetch = [&](int st_, int set) {
 #pragma unroll
-      for (int a = 0; a < TM; ++a) av[set][a] = la[fa[a] + astep * st_];
+        for (int a = 0; a < TA; ++a) av[set][a] = la[fa[a] + astep * st_];
 #pragma unroll
-      for (int c = 0; c < TN; ++c) bv[set][c] = la[fb[c] + bstep * st_];
-    };
-    fetch(0, 0);
+        for (int c = 0; c < TC; ++c) bv[set][c] = la[fb[c] + bstep * st_];
+      };
+      fetch(0, 0);
 #pragma unroll
-    for (int st_ = 0; st_ < BIG_KSL / 4; ++st_) {
-      if (st_ + 1 < nst) fetch(st_ + 1, (st_ + 1) & 1);
-      if (st_ < nst) {
+      for (int st_ = 0; st_ < BIG_KSL / 4; ++st_) {
+        if (st_ + 1 < nst) fetch(st_ + 1, (st_ + 1) & 1);
+        if (st_ < nst) {
 #pragma unroll
-        for (int a = 0; a < TM; ++a)
+          for (int a = 0; a < TA; ++a)
 #pragma unroll
-          for (int c = 0; c < TN; ++c) acc[a][c] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[st_ & 1][a], bv[st_ & 1][c], acc[a][c], 0, 0, 0);
+            for (int c = 0; c < TC; ++c) acc[a][c] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[st_ & 1][a], bv[st_ & 1][c], acc[a][c], 0, 0, 0);
+        }
       }
+      s = s2;
+      k0 = k2;
+      ++it;
     }
-    s = s2;
-    k0 = k2;
-    ++it;
+    flush(cur_c);   // (inside the variant: accumulators that met again behind the switch were kept twice)
+  };
+  {
+    const int own_r = (wid >> 1) ? mt - ((mt + 1) >> 1) : ((mt + 1) >> 1), own_c = (wid & 1) ? nt - ((nt + 1) >> 1) : ((nt + 1) >> 1);
+    switch (full_tiles ? 0 : (own_r >= TM ? 0 : 2) + (own_c >= TN ? 0 : 1)) {   // (wave-uniform)
+      case 0: run(std::integral_constant<int, TM>{}, std::integral_constant<int, TN>{}); break;
+      case 1: run(std::integral_constant<int, TM>{}, std::integral_constant<int, TN - 1>{}); break;
+      case 2: run(std::integral_constant<int, TM - 1>{}, std::integral_constant<int, TN>{}); break;
+      default: run(std::integral_constant<int, TM - 1>{}, std::integral_constant<int, TN - 1>{}); break;
+    }
   }
-  flush(cur_c);
 }
 
 template <bool BT>
@@ -472,8 +487,10 @@ static int launch_f64_nc(int NC, bool bt, dim3 grid, hipStream_t st, const int* 
 
 template <int TM, int TN>
 static int launch_f64_big(bool bt, hipStream_t st, const int* stack, int nstack, const double* a, const double* b, double* c, int m, int n, int k) {
-  const int group = 8;   // stack entries per workgroup (16 k slabs of a 72^3 product are 1600 MFMA cycles per wave: runs rarely span more)
-  const dim3 grid((unsigned)((nstack + group - 1) / group));
+  const int group8 = 8;   // stack entries per workgroup (16 k slabs of a 72^3 product are 1600 MFMA cycles per wave: runs rarely span more)
+  static const int full = (getenv("DBCSR_AMD_SMM_BIG_EXACT") != nullptr && atoi(getenv("DBCSR_AMD_SMM_BIG_EXACT")) == 0) ? 1 : 0;
+  const int group = group8 | (full << 16);
+  const dim3 grid((unsigned)((nstack + group8 - 1) / group8));
   if (bt)
     hipLaunchKernelGGL((smm_stack_f64_big<TM, TN, true>), grid, dim3(256), (size_t)2 * (big_a_bytes(TM) + big_a_bytes(TN)), st, stack, nstack, a, b, c, m, n, k, group);
   else
