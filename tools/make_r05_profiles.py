@@ -76,16 +76,26 @@ def large_blocks():
             chk = r.get("check", {})
             L.append("   m %-3s n %-3s k %-3s " % (r["mix_m"][1], r["mix_n"][1], r["mix_k"][1]) + fmt_block(r) +
                      ("  [check: index %s, diff %.1e]" % ("==" if chk.get("index_identical") else "!=", chk.get("max_abs_diff_over_max_abs", 0.0)) if chk else ""))
+    L.append("-- final (session r05_s11): every wave multiplies exactly the tiles it owns (the halves of an odd tile count are one tile apart: 72 = 5 + 4, 40 = 3 + 2),")
+    L.append("   the variant chosen once outside the product loop; 'all_tiles' = the same build with every wave issuing all TM x TN tile products (DBCSR_AMD_MM_BIG=2)")
+    for r in rows(G + "/r05_s11/large_blocks_exact.jsonl"):
+        if "error" not in r:
+            chk = r.get("check", {})
+            L.append("   m %-3s n %-3s k %-3s " % (r["mix_m"][1], r["mix_n"][1], r["mix_k"][1]) + fmt_block(r) +
+                     ("  [check: index %s, diff %.1e]" % ("==" if chk.get("index_identical") else "!=", chk.get("max_abs_diff_over_max_abs", 0.0)) if chk else ""))
     L += ["", "-- the same dataflow under the acc ABI: tools/acc_bench.py (the reference's acc_bench / kernel timer shape: a 16005-entry stack over 10000 A, 10000 B,",
           "   1000 C blocks, libsmm_acc_transpose + libsmm_acc_process, every line checked against the CPU oracle)",
           "   before (session r05_s06: smm_stack_f64, 32 x 32 tiles one after the other, fragments from global memory):"]
     L += ["      " + ln.strip() for ln in open(G + "/r05_s06/acc_bench_blocks.txt")]
     L.append("   after (session r05_s08: smm_stack_f64_big, a workgroup per 8 stack entries, sums kept across runs of equal C offsets):")
     L += ["      " + ln.strip() for ln in open(G + "/r05_s08/acc_bench_blocks.txt")]
-    L += ["", "72^3: engine 13.4 -> 40.6 TFLOP/s = 0.52 of the fp64 peak (the 0.40 asked for), acc ABI 11.6 -> 32.3 = 0.41 (the reference's own tuned kernel: 8.1 TFLOP/s",
-          "on Mi250-class hardware, src/acc/libsmm_acc/parameters/parameters_Mi350.json:433).  80^3 0.61, 64^3 0.64 (no padding).  The padding of the 2 x 2 wave arrangement",
-          "bounds the others: 72 -> 80 (0.81 of the MFMAs useful), 55 -> 64 (0.74), 40 -> 48 (0.69), 33 -> 48 (0.47).  k passes are switched off for blocks above 32",
-          "(three passes cost 72^3 15 %: the slabs are shared through LDS, C re-read per pass is pure cost)."]
+    L.append("   final (session r05_s11: exact tile counts per wave; [all tiles] = DBCSR_AMD_SMM_BIG_EXACT=0 on the same build):")
+    L += ["      " + ln.strip() for ln in open(G + "/r05_s11/acc_bench_exact.txt")]
+    L += ["", "72^3: engine 13.4 -> 46.3 TFLOP/s = 0.59 of the fp64 peak (the 0.40 asked for), acc ABI 11.6 -> 33.0 = 0.42 (the reference's own tuned kernel: 8.1 TFLOP/s",
+          "on Mi250-class hardware, src/acc/libsmm_acc/parameters/parameters_Mi350.json:433).  80^3 0.63, 64^3 0.65 (no padding), 55^3 0.54, 40^3 0.47, 45x67x78 0.48, 33^3 0.29.",
+          "What is left of the 2 x 2 wave arrangement's imbalance: the workgroup waits for its largest sub-block (72: 25 of 20.25 tiles on average); the matrix pipe of a",
+          "SIMD is shared with the waves of two other workgroups, which is where the exact tile counts gain (72^3 +14 %, 40^3 +17 %, 55^3 +14 %).  k passes are switched off",
+          "for blocks above 32 (three passes cost 72^3 15 %: the slabs are shared through LDS, C re-read per pass is pure cost)."]
     open(P + "/r05_large_blocks.txt", "w").write("\n".join(L) + "\n")
 
 
