@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(256) smm_stack_f64_lds(const int* __restrict__
 // LDS by all 256 threads and read by every wave, double-buffered over slabs AND entries.  B as libsmm_acc_transpose leaves it (n x k, BT):
 // its slab is as contiguous as A's; B as stored (k x n): n runs of 128 bytes with the padded pitch of the engine's kernel.
 // (smm_stack_f64 walks 32 x 32 tiles one after the other with fragments from global memory: 11.6 TFLOP/s at 72^3, acc_bench.)
-template <int TM, int TN, bool BT>
+template <int TM, int TN, bool BT, bool EXACT>
 __global__ void __launch_bounds__(256) smm_stack_f64_big(const int* __restrict__ stack, int nstack, const double* __restrict__ a_data,
                                                          const double* __restrict__ b_data, double* __restrict__ c_data, int m, int n, int k,
                                                          int group_arg) {
@@ -287,11 +287,17 @@ __global__ void __launch_bounds__(256) smm_stack_f64_big(const int* __restrict__
   };
   {
     const int own_r = (wid >> 1) ? mt - ((mt + 1) >> 1) : ((mt + 1) >> 1), own_c = (wid & 1) ? nt - ((nt + 1) >> 1) : ((nt + 1) >> 1);
-    switch (full_tiles ? 0 : (own_r >= TM ? 0 : 2) + (own_c >= TN ? 0 : 1)) {   // (wave-uniform)
-      case 0: run(std::integral_constant<int, TM>{}, std::integral_constant<int, TN>{}); break;
-      case 1: run(std::integral_constant<int, TM>{}, std::integral_constant<int, TN - 1>{}); break;
-      case 2: run(std::integral_constant<int, TM - 1>{}, std::integral_constant<int, TN>{}); break;
-      default: run(std::integral_constant<int, TM - 1>{}, std::integral_constant<int, TN - 1>{}); break;
+    if constexpr (EXACT) {
+      switch (full_tiles ? 0 : (own_r >= TM ? 0 : 2) + (own_c >= TN ? 0 : 1)) {   // (wave-uniform)
+        case 0: run(std::integral_constant<int, TM>{}, std::integral_constant<int, TN>{}); break;
+        case 1: run(std::integral_constant<int, TM>{}, std::integral_constant<int, TN - 1>{}); break;
+        case 2: run(std::integral_constant<int, TM - 1>{}, std::integral_constant<int, TN>{}); break;
+        default: run(std::integral_constant<int, TM - 1>{}, std::integral_constant<int, TN - 1>{}); break;
+      }
+    } else {   // even tile counts in both dimensions: the four sub-blocks are equally large, one variant (and fewer registers: three waves per SIMD for 5 x 5)
+      (void)own_r;
+      (void)own_c;
+      run(std::integral_constant<int, TM>{}, std::integral_constant<int, TN>{});
     }
   }
 }
@@ -491,10 +497,18 @@ static int launch_f64_big(bool bt, hipStream_t st, const int* stack, int nstack,
   static const int full = (getenv("DBCSR_AMD_SMM_BIG_EXACT") != nullptr && atoi(getenv("DBCSR_AMD_SMM_BIG_EXACT")) == 0) ? 1 : 0;
   const int group = group8 | (full << 16);
   const dim3 grid((unsigned)((nstack + group8 - 1) / group8));
-  if (bt)
-    hipLaunchKernelGGL((smm_stack_f64_big<TM, TN, true>), grid, dim3(256), (size_t)2 * (big_a_bytes(TM) + big_a_bytes(TN)), st, stack, nstack, a, b, c, m, n, k, group);
+  // a stack is homogeneous: whether the 2 x 2 sub-blocks are equally large is known here
+  const int mt = (m + 7) / 8, nt = (n + 7) / 8;
+  const bool even = mt == 2 * TM && nt == 2 * TN;   // every wave owns exactly TM x TN tiles
+  const size_t lds_t = (size_t)2 * (big_a_bytes(TM) + big_a_bytes(TN)), lds_s = (size_t)2 * (big_a_bytes(TM) + big_b_bytes(TN));
+  if (bt && even)
+    hipLaunchKernelGGL((smm_stack_f64_big<TM, TN, true, false>), grid, dim3(256), lds_t, st, stack, nstack, a, b, c, m, n, k, group);
+  else if (bt)
+    hipLaunchKernelGGL((smm_stack_f64_big<TM, TN, true, true>), grid, dim3(256), lds_t, st, stack, nstack, a, b, c, m, n, k, group);
+  else if (even)
+    hipLaunchKernelGGL((smm_stack_f64_big<TM, TN, false, false>), grid, dim3(256), lds_s, st, stack, nstack, a, b, c, m, n, k, group);
   else
-    hipLaunchKernelGGL((smm_stack_f64_big<TM, TN, false>), grid, dim3(256), (size_t)2 * (big_a_bytes(TM) + big_b_bytes(TN)), st, stack, nstack, a, b, c, m, n, k, group);
+    hipLaunchKernelGGL((smm_stack_f64_big<TM, TN, false, true>), grid, dim3(256), lds_s, st, stack, nstack, a, b, c, m, n, k, group);
   return dbcsr_amd::check(hipGetLastError(), "smm_stack_f64_big launch", __FILE__, __LINE__);
 }
 
