@@ -493,7 +493,10 @@ static int launch_f64_nc(int NC, bool bt, dim3 grid, hipStream_t st, const int* 
 
 template <int TM, int TN>
 static int launch_f64_big(bool bt, hipStream_t st, const int* stack, int nstack, const double* a, const double* b, double* c, int m, int n, int k) {
-  const int group8 = 8;   // stack entries per workgroup (16 k slabs of a 72^3 product are 1600 MFMA cycles per wave: runs rarely span more)
+  // stack entries per workgroup: sums are kept in registers across the entries of a run of equal C offsets and flushed with atomic adds at its
+  // end (and at the workgroup's last entry), so longer groups flush less often but leave fewer workgroups to balance (DBCSR_AMD_SMM_BIG_GROUP)
+  static const int group_env = getenv("DBCSR_AMD_SMM_BIG_GROUP") ? atoi(getenv("DBCSR_AMD_SMM_BIG_GROUP")) : 0;
+  const int group8 = group_env > 0 && group_env < 65536 ? group_env : 8;
   static const int full = (getenv("DBCSR_AMD_SMM_BIG_EXACT") != nullptr && atoi(getenv("DBCSR_AMD_SMM_BIG_EXACT")) == 0) ? 1 : 0;
   const int group = group8 | (full << 16);
   const dim3 grid((unsigned)((nstack + group8 - 1) / group8));
