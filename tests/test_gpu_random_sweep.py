@@ -58,6 +58,35 @@ def test_random_multiply_matches_oracle(seed):
     run_case(make_case(1000 + seed))
 
 
+# round 5: the same walk over matrices with blocks of 33 ... 80 (the workgroup-per-C-block kernel mm_numeric_f64_big, mixed with small blocks,
+# tails, empty rows), a seed range of its own so that the cases of the walks above stay what they were
+BIG_MIXES = [[1, 45], [1, 72], [1, 67, 1, 5], [1, 40, 1, 23], [1, 80], [2, 33, 1, 13], [1, 64], [1, 55, 1, 3], [1, 78, 1, 32], [1, 23]]
+
+
+def make_big_case(seed):
+    rng = np.random.default_rng(seed)
+    mix_m, mix_n, mix_k = (BIG_MIXES[int(rng.integers(len(BIG_MIXES)))] for _ in range(3))
+    symm_c = "N" if rng.random() < 0.85 else ("S" if rng.random() < 0.7 else "A")
+    if symm_c != "N":
+        mix_n = mix_m
+    M = int(rng.integers(1, 600))
+    N = M if symm_c != "N" else int(rng.integers(1, 600))
+    K = int(rng.integers(1, 600))
+    sp = tuple(float(x) for x in rng.choice([0.0, 0.3, 0.6, 0.8, 0.95], size=3))
+    ta, tb = (str(x) for x in rng.choice(["N", "T"], size=2))
+    alpha = float(rng.choice([1.0, -0.5, 0.0, 2.25]))
+    beta = float(rng.choice([1.0, 0.0, -1.5, 0.5]))
+    retain = bool(rng.random() < 0.2)
+    eps = float(rng.choice([0.0, 0.0, 0.0, 30.0, 200.0]))
+    return dict(M=M, N=N, K=K, sp=sp, mix_m=mix_m, mix_n=mix_n, mix_k=mix_k, ta=ta, tb=tb, alpha=alpha, beta=beta, retain=retain, eps=eps,
+                symm_c=symm_c, dtype=np.float64)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("DBCSR_AMD_SWEEP_BIG", "60"))))
+def test_random_multiply_large_blocks(seed):
+    run_case(make_big_case(9000 + seed))
+
+
 def build_case(c):
     """(A, B, C_in, reference result, reference info) of a case on the host -- everything the oracle contributes"""
     sm, sn, sk = O.make_block_sizes(c["M"], c["mix_m"]), O.make_block_sizes(c["N"], c["mix_n"]), O.make_block_sizes(c["K"], c["mix_k"])
