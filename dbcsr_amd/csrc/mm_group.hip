@@ -71,14 +71,16 @@ __global__ void __launch_bounds__(256) mm_numeric_f32_group(const Desc* __restri
   auto sgpr = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
   int cbr[R], cnt[R], idx[R];
   const Entry* e[R];
-  uint32_t h_a[R], h_b[R], h_w[R], n_a[R], n_b[R], n_w[R];  // head entry of every list and the one after it
+  // head entry of every list, the one after it, and the one after that: the entry a peek looks at was requested a whole step earlier (with
+  // one entry of look-ahead the scalar load sat between the commit of a step and the peek of the next: a trip to L2 per step and wave)
+  uint32_t h_a[R], h_b[R], h_w[R], n_a[R], n_b[R], n_w[R], f_a[R], f_b[R], f_w[R];
   bool any = false;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     cbr[r] = __builtin_amdgcn_readfirstlane(gr[r]);
     cnt[r] = 0, idx[r] = 0;
     e[r] = entries;
-    h_a[r] = h_b[r] = h_w[r] = n_a[r] = n_b[r] = n_w[r] = 0;
+    h_a[r] = h_b[r] = h_w[r] = n_a[r] = n_b[r] = n_w[r] = f_a[r] = f_b[r] = f_w[r] = 0;
     if (cbr[r] >= 0) {
       any = true;
       cnt[r] = __builtin_amdgcn_readfirstlane(descs[cbr[r]].prod_cnt);
@@ -86,8 +88,9 @@ __global__ void __launch_bounds__(256) mm_numeric_f32_group(const Desc* __restri
       e[r] = entries + (((int64_t)__builtin_amdgcn_readfirstlane((int)(ps >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)ps));
       if (cnt[r] > 0) {
         h_a[r] = sgpr(e[r][0].a_lo), h_b[r] = sgpr(e[r][0].b_lo), h_w[r] = sgpr(e[r][0].w);
-        const int i1 = cnt[r] > 1 ? 1 : 0;
+        const int i1 = cnt[r] > 1 ? 1 : 0, i2 = cnt[r] > 2 ? 2 : cnt[r] - 1;
         n_a[r] = sgpr(e[r][i1].a_lo), n_b[r] = sgpr(e[r][i1].b_lo), n_w[r] = sgpr(e[r][i1].w);
+        f_a[r] = sgpr(e[r][i2].a_lo), f_b[r] = sgpr(e[r][i2].b_lo), f_w[r] = sgpr(e[r][i2].w);
       }
     }
   }
@@ -211,8 +214,9 @@ __global__ void __launch_bounds__(256) mm_numeric_f32_group(const Desc* __restri
           if ((mcur >> q) & 1u) {
             ++idx[q];
             h_a[q] = n_a[q], h_b[q] = n_b[q], h_w[q] = n_w[q];
-            const int i2 = idx[q] + 1 < cnt[q] ? idx[q] + 1 : cnt[q] - 1;
-            n_a[q] = sgpr(e[q][i2].a_lo), n_b[q] = sgpr(e[q][i2].b_lo), n_w[q] = sgpr(e[q][i2].w);
+            n_a[q] = f_a[q], n_b[q] = f_b[q], n_w[q] = f_w[q];
+            const int i3 = idx[q] + 2 < cnt[q] ? idx[q] + 2 : cnt[q] - 1;
+            f_a[q] = sgpr(e[q][i3].a_lo), f_b[q] = sgpr(e[q][i3].b_lo), f_w[q] = sgpr(e[q][i3].w);
           }
         bhi = nhi, blo = nlo, mcur = mnext;
         todo = mcur;
