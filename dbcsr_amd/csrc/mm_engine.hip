@@ -212,8 +212,20 @@ static bool launch_hot_f32(int m, int n, int k, dim3 grid, int wg_waves, hipStre
 // the direct form of the fp32 exact-size kernel (mm_numeric_f32.h, round 5): cubes whose k is a multiple of 8
 static bool launch_hot_f32_direct(int m, int n, int k, dim3 grid, int wg_waves, hipStream_t st, const Desc* descs, int64_t nblk, const Entry* entries,
                                   const float* a_data, const float* b_data, float* c_out, const float* c_in, float alpha, float beta,
-                                  int skip_empty, const int* order) {
+                                  int skip_empty, const int* order, bool slim = false) {
   if (m != n || m != k) return false;
+  if (slim) {   // every C block has the dominant size: LDS for the B images only
+    switch (m) {
+#define DBCSR_SLIM_CASE(S_)                                                                                                    \
+  case S_:                                                                                                                     \
+    hipLaunchKernelGGL((mm_numeric_f32_direct_slim<S_, S_, S_>), grid, dim3(64 * wg_waves), (size_t)wg_waves * f32d_wave_floats(S_) * sizeof(float), st, \
+                       descs, nblk, entries, a_data, b_data, c_out, c_in, alpha, beta, skip_empty, order);                     \
+    return true;
+      DBCSR_SLIM_CASE(16) DBCSR_SLIM_CASE(24) DBCSR_SLIM_CASE(32)
+#undef DBCSR_SLIM_CASE
+      default: return false;
+    }
+  }
   switch (m) {
 #define DBCSR_DIRECT_CASE(S_)                                                                                                  \
   case S_:                                                                                                                     \
@@ -268,7 +280,7 @@ struct Engine {
   bool group_built = false, b_monotone = false;
   DevBuf<int> groups, group_flag;
   int use_big = 1;     // DBCSR_AMD_MM_BIG=0: blocks above 32 through the one-wave-per-block kernel of rounds 1-4 (mm_numeric_f64) instead of mm_numeric_f64_big
-  int f32_direct = 1;  // DBCSR_AMD_MM_F32_DIRECT=0: the fp32 exact-size kernel that stages both operands in LDS (rounds 1-4) instead of the direct form
+  int f32_direct = 2;  // (2: + the slim-LDS launch when every C block has the dominant size, 1: never slim) DBCSR_AMD_MM_F32_DIRECT=0: the fp32 exact-size kernel that stages both operands in LDS (rounds 1-4) instead of the direct form
   int wg_waves = 0;   // DBCSR_AMD_MM_WG_WAVES = 1 | 2 | 4: waves per workgroup of the one-wave-per-C-block kernels (0: by list length).  A workgroup's LDS is
                       // released when its LAST wave ends, so with product lists of uneven length fewer waves per workgroup keep
                       // more of the CU's wave slots busy (config 3: kernel 8.93 / 8.09 / 7.51 ms for 4 / 2 / 1, config 2: 23.6 / 22.7 /
@@ -1465,7 +1477,8 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
       } else if (E->use_hot && E->hot_m > 0 && E->f32_direct &&
           launch_hot_f32_direct(E->hot_m, E->hot_n, E->hot_k, dim3(nwg_o), ww, st, E->descs.p, nblk, E->entries.p, static_cast<const float*>(a->data),
                                 static_cast<const float*>(b->data), static_cast<float*>(c_out->data), static_cast<const float*>(c_in->data),
-                                (float)alpha, (float)beta, skip_empty, E->order.p)) {
+                                (float)alpha, (float)beta, skip_empty, E->order.p,
+                                E->f32_direct >= 2 && E->hot_cnt_m == nbr && E->hot_cnt_n == b->nblkcols)) {
         snprintf(E->last_kernel, sizeof E->last_kernel, "mm_numeric_f32_direct<%d,%d,%d>", E->hot_m, E->hot_n, E->hot_k);
       } else if (E->use_hot && E->hot_m > 0 &&
           launch_hot_f32(E->hot_m, E->hot_n, E->hot_k, dim3(nwg_o), ww, st, E->descs.p, nblk, E->entries.p, static_cast<const float*>(a->data),

@@ -224,6 +224,8 @@ __device__ __forceinline__ void cblock_f32_direct(const Desc& d, const Entry* __
   const int a_voff = ((i < M ? i : M - 1) + KH * h * M) * 4;           // this lane's row of A, its half of k
   u32x4 sb[CB];     // B block of the NEXT product on its way to LDS
   float an[KH];     // A operand of the NEXT product
+  // (two register sets that change roles from product to product -- no copy -- were tried in round 5: the twice-unrolled loop needed 116
+  //  registers instead of 84)
   auto issue = [&](uint64_t a_off, uint64_t b_off) {
     const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)(b_data + b_off), 0, K * N * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)(a_data + a_off), 0, M * K * 4, 0x00020000);
@@ -330,6 +332,26 @@ __global__ void __launch_bounds__(256) mm_numeric_f32_direct(const Desc* __restr
     cblock_f32_direct<M, N, K>(d, entries, a_data, b_data, c_out, c_in, alpha, beta, lane, lds_a);
   else
     cblock_f32_lds(d, entries, a_data, b_data, c_out, c_in, alpha, beta, lane, lds_a, lds_bt);
+}
+
+// the same when EVERY C block of the launch is M x N (no tail block row / column: config 5): the workgroup's LDS is the B images of its waves and
+// nothing else -- 4.5 KB per wave instead of the 8.7 KB the staged fall-back of the kernel above needs, which held the CU at 16 waves
+template <int M, int N, int K>
+__global__ void __launch_bounds__(256) mm_numeric_f32_direct_slim(const Desc* __restrict__ descs, int64_t nblk, const Entry* __restrict__ entries,
+                                                                  const float* __restrict__ a_data, const float* __restrict__ b_data,
+                                                                  float* __restrict__ c_out, const float* __restrict__ c_in, float alpha,
+                                                                  float beta, int skip_empty, const int* __restrict__ order) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw_[];   // blockDim / 64 * f32d_wave_floats(K) floats
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int64_t pos = (int64_t)wg * (int)(blockDim.x >> 6) + wid;
+  const int64_t cb = order[pos];
+  if (cb < 0 || cb >= nblk) return;
+  const Desc d = descs[cb];
+  if ((skip_empty & 1) && d.prod_cnt == 0) return;
+  if (d.m != M || d.n != N) return;   // (never: the host launches this form only when all C blocks have the dominant size)
+  cblock_f32_direct<M, N, K>(d, entries, a_data, b_data, c_out, c_in, alpha, beta, lane, reinterpret_cast<float*>(smem_raw_) + (size_t)wid * f32d_wave_floats(K));
 }
 
 __global__ void __launch_bounds__(256) mm_numeric_f32(const Desc* __restrict__ descs, int64_t nblk, const Entry* __restrict__ entries,
