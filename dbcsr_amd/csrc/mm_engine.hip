@@ -280,7 +280,8 @@ struct Engine {
   bool group_built = false, b_monotone = false;
   DevBuf<int> groups, group_flag;
   int use_big = 1;     // DBCSR_AMD_MM_BIG=0: blocks above 32 through the one-wave-per-block kernel of rounds 1-4 (mm_numeric_f64) instead of mm_numeric_f64_big
-  int f32_direct = 2;  // (2: + the slim-LDS launch when every C block has the dominant size, 1: never slim) DBCSR_AMD_MM_F32_DIRECT=0: the fp32 exact-size kernel that stages both operands in LDS (rounds 1-4) instead of the direct form
+  int f32_direct = 1;  // (2: + the slim-LDS launch when every C block has the dominant size -- more waves per CU, measured 0-4 % slower: the
+                       // kernel is fabric-bound, gpurun_out/r05_s17 --, 1: never slim) DBCSR_AMD_MM_F32_DIRECT=0: the fp32 exact-size kernel that stages both operands in LDS (rounds 1-4) instead of the direct form
   int wg_waves = 0;   // DBCSR_AMD_MM_WG_WAVES = 1 | 2 | 4: waves per workgroup of the one-wave-per-C-block kernels (0: by list length).  A workgroup's LDS is
                       // released when its LAST wave ends, so with product lists of uneven length fewer waves per workgroup keep
                       // more of the CU's wave slots busy (config 3: kernel 8.93 / 8.09 / 7.51 ms for 4 / 2 / 1, config 2: 23.6 / 22.7 /
