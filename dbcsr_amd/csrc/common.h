@@ -18,6 +18,16 @@ static inline hipStream_t stream_of(void* handle) { return handle ? *static_cast
 hipError_t pool_malloc(void** p, size_t nbytes);
 hipError_t pool_free(void* p);
 
+// dbcsr_amd_multiply's k-pass decision for the operand an engine saw last (mm_api.hip: k_passes).  Lives in the engine, so it dies with the
+// handle; an operand whose index_stamp is 0 ("unknown generation", include/dbcsr_amd_mm.h) is never remembered.
+struct KPassMemo {
+  const void *row_p = nullptr, *blk_p = nullptr;
+  int64_t nblks = -1;
+  uint64_t stamp = 0;
+  int dt = 0, nblkrows = 0, nblkcols = 0, npass = 1;
+};
+KPassMemo* engine_kpass_memo(void* handle);  // mm_engine.hip
+
 }  // namespace dbcsr_amd
 
 #define ACC_CHECK(call)                                                        \

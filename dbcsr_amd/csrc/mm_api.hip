@@ -155,18 +155,17 @@ int k_passes(void* h, libsmm_acc_data_t dt, const dbcsr_amd_bcsr* a, double filt
   // The probe below runs on the engine and costs it its plan (it shares the symbolic phase's work areas): a loop that multiplies the
   // same resident operand again and again (dbcsr_amd_dev_multiply) would pay a full symbolic phase per call for it -- 1.6 of config 2's
   // 20.3 ms from a Fortran host (gpurun_out/r05_s05).  The answer only steers speed, so it is remembered per engine for the operand whose
-  // index arrays sit at the same addresses with the same block count (and stamp).
-  struct Memo {
-    void* h;
-    const void *row_p, *blk_p;
-    int64_t nblks;
-    uint64_t stamp;
-    int npass;
-  };
-  static thread_local Memo memo = {nullptr, nullptr, nullptr, -1, 0, 1};
-  if (memo.h == h && memo.row_p == a->row_p && memo.blk_p == a->blk_p && memo.nblks == a->nblks && memo.stamp == (uint64_t)a->index_stamp) return memo.npass;
+  // index arrays sit at the same addresses with the same shape, data type, block count and (non-zero) stamp.
+  KPassMemo* memo = engine_kpass_memo(h);
+  const bool stamped = memo && a->index_stamp != 0;  // stamp 0 = the owner does not track its index arrays: never trusted
+  if (stamped && memo->row_p == a->row_p && memo->blk_p == a->blk_p && memo->nblks == (int64_t)a->nblks && memo->stamp == (uint64_t)a->index_stamp &&
+      memo->dt == (int)dt && memo->nblkrows == a->nblkrows && memo->nblkcols == a->nblkcols)
+    return memo->npass;
   auto remember = [&](int n) {
-    memo = Memo{h, a->row_p, a->blk_p, (int64_t)a->nblks, (uint64_t)a->index_stamp, n};
+    if (stamped) {
+      memo->row_p = a->row_p, memo->blk_p = a->blk_p, memo->nblks = (int64_t)a->nblks, memo->stamp = (uint64_t)a->index_stamp;
+      memo->dt = (int)dt, memo->nblkrows = a->nblkrows, memo->nblkcols = a->nblkcols, memo->npass = n;
+    }
     return n;
   };
   Owned probe;

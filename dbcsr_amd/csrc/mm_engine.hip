@@ -41,7 +41,6 @@
 #include "mm_symbolic.h"
 #include "mm_numeric_f64.h"
 #include "mm_numeric_f64_big.h"
-#include "mm_group.h"
 #include "mm_numeric_f32.h"
 #include "mm_aux.h"
 // The library comes in two builds (Makefile): the SHIPPING one holds what a multiply can run by itself -- the kernels listed above, their
@@ -50,6 +49,9 @@
 // C tiles with B shared in LDS (mm_band.*), the persistent form and the ablation / keep-alive variants of the exact-size kernel, the
 // G-block bodies and stream spreading of the class kernels, the occupancy and row-group knobs.  Their switches exist in the lab build only.
 #ifdef DBCSR_AMD_EXPERIMENTS
+#include "mm_lab_api.h"
+#include "mm_group.h"
+#include "mm_group64.h"
 #include "mm_dma.h"
 #include "mm_tile_index.h"
 #include "mm_band_index.h"
@@ -279,6 +281,16 @@ struct Engine {
   int f32_group = 0, group_R = 0;
   bool group_built = false, b_monotone = false;
   DevBuf<int> groups, group_flag;
+  // fp64 (round 6, mm_group64.h): DBCSR_AMD_MM_F64_GROUP = 2 ... 6: a wave owns that many C blocks of one block column whenever the kernel
+  // applies; 0 / unset: off.  DBCSR_AMD_MM_GROUP_PANEL_MB: target size of a B column panel of the group launch (0: panel_bytes)
+  int f64_group = 0;
+  int64_t group_panel_bytes = 0;
+  DevBuf<int> group_cnt;
+#ifdef DBCSR_AMD_EXPERIMENTS
+  DevBuf<GWork> group_work;
+  DevBuf<GEntry> group_entries;
+#endif
+  DevBuf<int64_t> group_start;
   int use_big = 1;     // DBCSR_AMD_MM_BIG=0: blocks above 32 through the one-wave-per-block kernel of rounds 1-4 (mm_numeric_f64) instead of mm_numeric_f64_big
   int f32_direct = 1;  // (2: + the slim-LDS launch when every C block has the dominant size -- more waves per CU, measured 0-4 % slower: the
                        // kernel is fabric-bound, gpurun_out/r05_s17 --, 1: never slim) DBCSR_AMD_MM_F32_DIRECT=0: the fp32 exact-size kernel that stages both operands in LDS (rounds 1-4) instead of the direct form
@@ -387,7 +399,10 @@ struct Engine {
   char last_kernel[96] = "";  // name of the numeric kernel of the last dbcsr_amd_mm_numeric (dbcsr_amd_mm_last_kernel)
   int dma_stages = 0;  // DBCSR_AMD_MM_KERNEL=dma2|dma3|dma4: LDS-DMA exact-size kernel with that many ring slots (0: off)
   int use_lds = 1;  // DBCSR_AMD_MM_KERNEL=direct selects the v1 kernel (A/B experiments)
+  KPassMemo kpass_memo;  // dbcsr_amd_multiply's k-pass decision for the last stamped A operand (mm_api.hip)
 };
+
+KPassMemo* engine_kpass_memo(void* handle) { return handle ? &static_cast<Engine*>(handle)->kpass_memo : nullptr; }
 
 // waves per block row for the kernels that stream whole blocks (norms, compaction): enough waves to keep the memory system busy
 static inline int row_split(int64_t nbr, int64_t nblks) {
@@ -415,6 +430,7 @@ static int exclusive_scan(Engine* E, const int* in, int64_t n, TO* out, int64_t*
 
 static inline dim3 grid_for(int64_t nthreads) { return dim3((unsigned)((nthreads + 255) / 256)); }
 
+#ifdef DBCSR_AMD_EXPERIMENTS
 // fp32 group kernel: 0 = launched, 1 = does not apply here (the caller runs the one-wave-per-block kernel), < 0 = error
 static int run_group_f32(Engine* E, int R, bool reuse, hipStream_t st, const dbcsr_amd_bcsr* a, const dbcsr_amd_bcsr* b, const dbcsr_amd_bcsr* c_in,
                          dbcsr_amd_bcsr* c_out, float alpha, float beta, int skip_empty) {
@@ -425,14 +441,14 @@ static int run_group_f32(Engine* E, int R, bool reuse, hipStream_t st, const dbc
   if (!(reuse && E->group_built && E->group_R == R)) {
     if (E->group_flag.ensure(4) || E->groups.ensure((size_t)ng * nbc * R + 1)) return -1;
     ACC_CHECK(hipMemsetAsync(E->group_flag.p, 0, sizeof(int), st));
-    group_f32_check_ascending(st, static_cast<const int64_t*>(b->blk_p), (int64_t)b->nblks, E->group_flag.p);
+    group_check_ascending(st, static_cast<const int64_t*>(b->blk_p), (int64_t)b->nblks, E->group_flag.p);
     int* hflag = reinterpret_cast<int*>(E->host_scalars + 12);
     ACC_CHECK(hipMemcpyAsync(hflag, E->group_flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
     ACC_CHECK(hipStreamSynchronize(st));
     E->b_monotone = *hflag == 0;
     E->group_R = R;
     E->group_built = true;
-    if (E->b_monotone) group_f32_build_table(st, c_out->row_p, c_out->col_i, E->descs.p, nbr, nbc, R, S, E->groups.p);
+    if (E->b_monotone) group_build_table(st, c_out->row_p, c_out->col_i, E->descs.p, nbr, nbc, R, S, E->groups.p);
   }
   if (!E->b_monotone) return 1;
   GroupGeom G;
@@ -448,6 +464,50 @@ static int run_group_f32(Engine* E, int R, bool reuse, hipStream_t st, const dbc
   const float* cid = static_cast<const float*>(c_in->data);
   return group_f32_launch(S, R, nwg, st, E->descs.p, E->entries.p, ad, bd, cd, cid, alpha, beta, skip_empty, E->groups.p, G);
 }
+
+// fp64 group kernel (mm_group64.h): 0 = launched, 1 = does not apply here (the caller runs the one-wave-per-block kernel), < 0 = error
+static int run_group_f64(Engine* E, int R, bool reuse, hipStream_t st, const dbcsr_amd_bcsr* a, const dbcsr_amd_bcsr* b, const dbcsr_amd_bcsr* c_in,
+                         dbcsr_amd_bcsr* c_out, double alpha, double beta, int skip_empty) {
+  const int S = E->hot_m, nbr = E->nbr, nbc = b->nblkcols;
+  if (!group64_has_kernel(S, R) || nbr <= 0 || nbc <= 0) return 1;
+  const int ng = (nbr + R - 1) / R, ngx = (ng + 7) / 8;
+  const int64_t ngj = (int64_t)ng * nbc;
+  if ((int64_t)ngx * nbc >= (1ll << 28)) return 1;
+  if (!(reuse && E->group_built && E->group_R == R)) {
+    if (E->group_flag.ensure(4) || E->groups.ensure((size_t)ngj * R + 1) || E->group_cnt.ensure((size_t)ngj + 1) || E->group_work.ensure((size_t)ngj + 1) ||
+        E->group_start.ensure((size_t)ngj + 2))
+      return -1;
+    ACC_CHECK(hipMemsetAsync(E->group_flag.p, 0, sizeof(int), st));
+    group_check_ascending(st, static_cast<const int64_t*>(b->blk_p), (int64_t)b->nblks, E->group_flag.p);
+    int* hflag = reinterpret_cast<int*>(E->host_scalars + 12);
+    ACC_CHECK(hipMemcpyAsync(hflag, E->group_flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    ACC_CHECK(hipStreamSynchronize(st));
+    E->b_monotone = *hflag == 0;
+    E->group_R = R;
+    E->group_built = true;
+    if (E->b_monotone) {
+      // the merged lists hold at most as many records as there are products
+      if (E->group_entries.ensure((size_t)E->nproducts + 4)) return -1;
+      group_build_table(st, c_out->row_p, c_out->col_i, E->descs.p, nbr, nbc, R, S, E->groups.p);
+      group64_count(st, E->groups.p, E->descs.p, ngj, R, E->group_cnt.p);
+      if (exclusive_scan<int64_t>(E, E->group_cnt.p, ngj, E->group_start.p, nullptr, true, st)) return -1;
+      group64_merge(st, E->groups.p, E->descs.p, E->entries.p, ngj, R, S, E->group_start.p, E->group_work.p, E->group_entries.p);
+    }
+  }
+  if (!E->b_monotone) return 1;
+  GroupGeom G;
+  G.nbc = nbc, G.ng = ng, G.ngx = ngx;
+  const int64_t b_bytes = (int64_t)b->nblks * S * S * (int64_t)sizeof(double);
+  const int64_t pb = E->group_panel_bytes > 0 ? E->group_panel_bytes : E->panel_bytes;
+  int np = (int)std::min<int64_t>(std::max<int64_t>(1, (b_bytes + pb - 1) / pb), (int64_t)nbc);
+  G.pw = (nbc + np - 1) / np;
+  G.np = (nbc + G.pw - 1) / G.pw;
+  const int has_tail = (E->min_k != E->max_k || E->max_k != S) ? 1 : 0;
+  return group64_launch(S, R, st, E->descs.p, E->entries.p, static_cast<const double*>(a->data), static_cast<const double*>(b->data),
+                        static_cast<double*>(c_out->data), static_cast<const double*>(c_in->data), alpha, beta, skip_empty, has_tail, E->group_work.p,
+                        E->group_entries.p, G);
+}
+#endif
 
 static inline void plan_invalidate(Engine* E) { E->plan_saved = E->plan_hit = E->plan_numeric = false; }
 
@@ -760,6 +820,8 @@ int dbcsr_amd_mm_create(void** handle) {
     const int r = atoi(k);
     E->f32_group = (r >= 2 && r <= 4) ? r : (r < 0 ? -1 : 0);
   }
+  if (const char* k = getenv("DBCSR_AMD_MM_F64_GROUP")) E->f64_group = atoi(k);
+  if (const char* k = getenv("DBCSR_AMD_MM_GROUP_PANEL_MB")) E->group_panel_bytes = (int64_t)atoll(k) << 20;
   if (const char* k = getenv("DBCSR_AMD_MM_SYMBOLIC")) {
     E->force_word_kernels = strcmp(k, "word") == 0;
     E->force_symbolic = strcmp(k, "word") == 0 ? 1 : (strcmp(k, "grid") == 0 ? 2 : (strcmp(k, "rows") == 0 ? 3 : 0));
@@ -1336,15 +1398,23 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
                      static_cast<const double*>(c_in->data), alpha, beta, lds_a, lds_wave, E->dbg | (skip_empty ? 32 : 0), E->order.p)
       int tile_rc = 1;
 #ifdef DBCSR_AMD_EXPERIMENTS
+      // a wave per R C blocks of one block column, B shared inside the wave (mm_group64.h): one dominant cube size the kernel is built for, no
+      // block norms to leave behind (filtered multiplies), no symmetric product
+      if (E->f64_group >= 2 && hot_work && E->use_hot && E->use_pipe != 1 && E->dma_stages == 0 && E->hot_m == E->hot_n && E->hot_m == E->hot_k && !epi_norms &&
+          !E->canonical_c && !(E->dbg & ~32) && !E->hot_persistent) {
+        tile_rc = run_group_f64(E, E->f64_group, reuse, st, a, b, c_in, c_out, alpha, beta, skip_empty);
+        if (tile_rc < 0) return -1;
+        if (tile_rc == 0) tile_rc = 3;
+      }
       // XCD-wide C tiles (mm_tile.h): one dominant cube size the tile kernel is built for, a C dense enough that sub-tiles of
       // 3 x 3 blocks have long product lists, no on-the-fly filter, no in-place accumulation, no symmetric product
-      if (E->use_tile > 0 && hot_work && E->use_hot && E->use_pipe != 1 && E->dma_stages == 0 && E->hot_m == 23 && E->hot_n == 23 && E->hot_k == 23 &&
+      if (tile_rc != 3 && E->use_tile > 0 && hot_work && E->use_hot && E->use_pipe != 1 && E->dma_stages == 0 && E->hot_m == 23 && E->hot_n == 23 && E->hot_k == 23 &&
           !E->filter.a_norms && !skip_empty && !E->canonical_c && !epi_norms && !(E->dbg & ~32) &&
           (E->use_tile > 1 || (E->nproducts >= 8 * nblk && nblk >= 200000)))
         tile_rc = run_tile_f64<23>(E, st, a, b, c_in, c_out, alpha, beta);
       if (tile_rc < 0) return -1;
       // CU-wide C tiles, B shared in LDS (mm_band.h): the same conditions, and no retain_sparsity (its lists take C's pattern from the operands)
-      if (tile_rc != 0 && E->use_band > 0 && hot_work && E->use_hot && E->use_pipe != 1 && E->dma_stages == 0 && E->hot_m == 23 && E->hot_n == 23 &&
+      if (tile_rc != 0 && tile_rc != 3 && E->use_band > 0 && hot_work && E->use_hot && E->use_pipe != 1 && E->dma_stages == 0 && E->hot_m == 23 && E->hot_n == 23 &&
           E->hot_k == 23 && !E->filter.a_norms && !skip_empty && !E->canonical_c && !epi_norms && !(E->dbg & ~32) && !E->retain && !E->hot_persistent &&
           (E->use_band > 1 || (E->nproducts >= 8 * nblk && nblk >= 200000))) {
         tile_rc = run_band_f64<23>(E, st, a, b, c_in, c_out, alpha, beta);
@@ -1354,7 +1424,15 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
       // measured: the pipelined kernel wins when C blocks have few products (config 3: 3.7 per block, 10.4 vs 11.8 ms) and
       // loses when they have many (config 2: 14.4 per block, 32 vs 22 ms)
 #endif
-      if (tile_rc == 0 || tile_rc == 2) {
+      if (tile_rc == 3) {
+        // the C blocks of other sizes (tail block row / column): the one-wave-per-block kernel, told to leave the dominant size alone
+        if (E->hot_cnt_m < nbr || E->hot_cnt_n < b->nblkcols)
+          launch_hot_f64(E->hot_m, E->hot_n, E->hot_k, dim3((unsigned)(8 * E->order_len / ww)), (size_t)ww * lds_wave * sizeof(double) + (size_t)E->lds_pad,
+                         st, E->descs.p, nblk, E->entries.p, static_cast<const double*>(a->data), static_cast<const double*>(b->data),
+                         static_cast<double*>(c_out->data), static_cast<const double*>(c_in->data), alpha, beta, lds_a, lds_wave, 64 | (skip_empty ? 32 : 0),
+                         E->order.p, hot_work, ww, nullptr, 0);
+        snprintf(E->last_kernel, sizeof E->last_kernel, "mm_numeric_f64_group<%d,%d,%d;%d>", E->hot_m, E->hot_n, E->hot_k, E->group_R);
+      } else if (tile_rc == 0 || tile_rc == 2) {
         // the tile / band kernel computed the C blocks of the dominant size (products with inner blocks of another size included);
         // this launch: the exact-size kernel over the blocks of the other sizes only
         launch_hot_f64(E->hot_m, E->hot_n, E->hot_k, dim3((unsigned)(8 * E->order_len / ww)), (size_t)ww * lds_wave * sizeof(double) + (size_t)E->lds_pad,
@@ -1463,11 +1541,13 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
     } else if (small32 && E->use_lds) {
       const unsigned nwg_o = (unsigned)(8 * E->order_len / ww);
       int grp_rc = 1;
+#ifdef DBCSR_AMD_EXPERIMENTS
       if (E->use_hot && E->hot_m > 0 && E->hot_m == E->hot_n && E->hot_m == E->hot_k && E->f32_direct && E->f32_group != 0 && E->min_k == E->max_k &&
           E->max_k == E->hot_k && (E->f32_group > 0 || (E->nproducts >= 16 * nblk && nblk >= 1024))) {
         grp_rc = run_group_f32(E, E->f32_group > 0 ? E->f32_group : 4, reuse, st, a, b, c_in, c_out, (float)alpha, (float)beta, skip_empty);
         if (grp_rc < 0) return -1;
       }
+#endif
       if (grp_rc == 0) {
         // the C blocks of other sizes (tail block row / column): the one-wave-per-block kernel, told to leave the dominant size alone
         if (E->hot_cnt_m < nbr || E->hot_cnt_n < b->nblkcols)
@@ -1910,6 +1990,7 @@ int dbcsr_amd_mm_plan_stats(void* handle, int64_t* reused, int64_t* built) {
   return 0;
 }
 
+#ifdef DBCSR_AMD_EXPERIMENTS
 int dbcsr_amd_mm_tile_stats(void* handle, int* waves_gave_up, int* list_mismatches) {
   Engine* E = static_cast<Engine*>(handle);
   if (!E) return -1;
@@ -1955,5 +2036,6 @@ int dbcsr_amd_mm_band_stats(void* handle, int* waits_gave_up, int* list_mismatch
   }
   return 0;
 }
+#endif  // DBCSR_AMD_EXPERIMENTS
 
 }  // extern "C"

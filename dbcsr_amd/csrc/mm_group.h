@@ -23,26 +23,12 @@
 
 #include "common.h"
 #include "mm_types.h"
+#include "mm_group64.h"   // GroupGeom, group_check_ascending, group_build_table: shared with the fp64 form
 
 namespace dbcsr_amd {
 
-// the image of B in LDS shared by the direct (mm_numeric_f32.h) and the group form: B as stored (k contiguous), 32 rows of K + 4 floats
-constexpr int F32D_ROWS = 32;
-static inline constexpr int f32d_pitch(int K) { return K + 4; }
-static inline constexpr int f32d_wave_floats(int K) { return F32D_ROWS * f32d_pitch(K); }
+// (the image of B in LDS -- F32D_ROWS, f32d_pitch, f32d_wave_floats -- is mm_types.h's: shared with the direct form of mm_numeric_f32.h)
 
-struct GroupGeom {
-  int nbc;   // block columns of C
-  int ng;    // row groups
-  int ngx;   // row groups per XCD (the largest share: XCDs with fewer find empty positions)
-  int pw;    // columns per panel
-  int np;    // panels
-};
-
-// flag_dev[0] (zeroed by the caller) becomes non-zero when some block of the matrix lies before its predecessor in index order
-void group_f32_check_ascending(hipStream_t st, const int64_t* blk_p, int64_t nblks, int* flag_dev);
-// groups[(g * nbc + j) * R + r] = index of the C block (R g + r, j) when it exists and is S x S, else -1
-void group_f32_build_table(hipStream_t st, const int* c_row_p, const int* c_col_i, const Desc* descs, int nbr, int nbc, int R, int S, int* groups);
 // 0 = launched, 1 = no kernel for this (S, R)
 int group_f32_launch(int S, int R, unsigned nwg, hipStream_t st, const Desc* descs, const Entry* entries, const float* a, const float* b, float* c,
                      const float* ci, float alpha, float beta, int skip_empty, const int* groups, GroupGeom G);

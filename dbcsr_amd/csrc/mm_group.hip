@@ -7,40 +7,6 @@
 
 namespace dbcsr_amd {
 
-static inline dim3 group_grid_for(int64_t nthreads) { return dim3((unsigned)((nthreads + 255) / 256)); }
-
-
-// groups[(g * nbc + j) * R + r] = index of the C block (R g + r, j) when it exists and is M x N, else -1
-__global__ void __launch_bounds__(256) build_groups(const int* __restrict__ c_row_p, const int* __restrict__ c_col_i, const Desc* __restrict__ descs,
-                                                    int nbr, int nbc, int R, int M, int N, int* __restrict__ groups) {
-  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t ng = (nbr + R - 1) / R;
-  if (tid >= ng * nbc * R) return;
-  const int r = (int)(tid % R);
-  const int64_t gj = tid / R;
-  const int j = (int)(gj % nbc), i = (int)(gj / nbc) * R + r;
-  int cb = -1;
-  if (i < nbr) {
-    int lo = c_row_p[i], hi = c_row_p[i + 1];  // binary search of column j in the sorted row
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if (c_col_i[mid] < j)
-        lo = mid + 1;
-      else
-        hi = mid;
-    }
-    if (lo < c_row_p[i + 1] && c_col_i[lo] == j && descs[lo].m == M && descs[lo].n == N) cb = lo;
-  }
-  groups[tid] = cb;
-}
-
-// flag[0] != 0 afterwards: some block of the matrix lies before its predecessor in index order
-__global__ void __launch_bounds__(256) blk_p_not_ascending(const int64_t* __restrict__ blk_p, int64_t nblks, int* __restrict__ flag) {
-  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b + 1 < nblks && blk_p[b + 1] <= blk_p[b]) flag[0] = 1;
-}
-
-
 template <int M, int N, int K, int R>
 __global__ void __launch_bounds__(256) mm_numeric_f32_group(const Desc* __restrict__ descs, const Entry* __restrict__ entries,
                                                             const float* __restrict__ a_data, const float* __restrict__ b_data,
@@ -242,15 +208,6 @@ __global__ void __launch_bounds__(256) mm_numeric_f32_group(const Desc* __restri
   }
 }
 
-
-void group_f32_check_ascending(hipStream_t st, const int64_t* blk_p, int64_t nblks, int* flag_dev) {
-  if (nblks > 1) hipLaunchKernelGGL(blk_p_not_ascending, group_grid_for(nblks), dim3(256), 0, st, blk_p, nblks, flag_dev);
-}
-
-void group_f32_build_table(hipStream_t st, const int* c_row_p, const int* c_col_i, const Desc* descs, int nbr, int nbc, int R, int S, int* groups) {
-  const int64_t ng = (nbr + R - 1) / R;
-  hipLaunchKernelGGL(build_groups, group_grid_for(ng * nbc * R), dim3(256), 0, st, c_row_p, c_col_i, descs, nbr, nbc, R, S, S, groups);
-}
 
 template <int S_, int R_>
 static void launch_group_f32(unsigned nwg, hipStream_t st, const Desc* descs, const Entry* entries, const float* a, const float* b, float* c,

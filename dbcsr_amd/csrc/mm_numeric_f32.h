@@ -197,7 +197,7 @@ __device__ __forceinline__ void cblock_f32_exact(const Desc& d, const Entry* __r
 //     four B values of one ds_read_b128 four successive steps' operands.
 // acc: register r of lane l = C[m = l & 31][n = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)]: for a fixed r a half-wave writes 128
 // consecutive bytes of C.  K must be a multiple of 8 (a half's k range a multiple of 4); the other sizes keep cblock_f32_exact.
-// (F32D_ROWS, f32d_pitch, f32d_wave_floats: mm_group.h, shared with the group form)
+// (F32D_ROWS, f32d_pitch, f32d_wave_floats: mm_types.h, shared with the lab's group form)
 
 template <int M, int N, int K>
 __device__ __forceinline__ void cblock_f32_direct(const Desc& d, const Entry* __restrict__ entries, const float* __restrict__ a_data,

@@ -60,6 +60,12 @@ struct Work {  // one position of the launch order: the C block's descriptor AND
   int32_t cb;              // index of the C block (order[pos])
 };
 
+// the image of B in LDS of the fp32 direct kernel (mm_numeric_f32.h) and the lab's fp32 group kernel (mm_group.hip): B as stored (k contiguous),
+// 32 rows of K + 4 floats
+constexpr int F32D_ROWS = 32;
+static inline constexpr int f32d_pitch(int K) { return K + 4; }
+static inline constexpr int f32d_wave_floats(int K) { return F32D_ROWS * f32d_pitch(K); }
+
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   // Workgroup b is dispatched to XCD b % 8 (MI355X_MICROARCH.md); give each XCD a
   // contiguous range of C blocks so that the A block-row it works on stays in

@@ -431,7 +431,10 @@ class MultiplyEngine:
                 work = c["work"]
                 work.data = out.data
             else:
-                work = DbcsrMatrix(out.row_blk_size, out.col_blk_size, out.row_p.clone(), out.col_i.clone(), out.blk_p.clone(), out.data, out.name)
+                # (the copies are made on the stream init_c wrote the arrays on: on torch's current stream they could read col_i / blk_p of a
+                # caller's side stream before init_c has filled them, and the trusted pass plans would keep the half-filled index)
+                with torch.cuda.stream(stream if stream is not None else torch.cuda.current_stream()):
+                    work = DbcsrMatrix(out.row_blk_size, out.col_blk_size, out.row_p.clone(), out.col_i.clone(), out.blk_p.clone(), out.data, out.name)
                 tensors = (work.row_p, work.col_i, work.blk_p)
                 self._kpass_cidx = {"key": ckey, "work": work, "tensors": tensors, "versions": tuple(t._version for t in tensors)}
             flop = nprod = 0

@@ -216,16 +216,6 @@ const char* dbcsr_amd_mm_last_kernel(void* handle);
 int dbcsr_amd_mm_trust_plan(void* handle, int on);
 int dbcsr_amd_mm_plan_stats(void* handle, int64_t* reused, int64_t* built);
 
-/* Diagnostics of the tile kernel (dbcsr_amd/csrc/mm_tile.h) in the last dbcsr_amd_mm_numeric of this handle: waves that gave up
- * waiting in the team's k window (they went on unthrottled: speed only), sub-tiles whose product list disagreed with the per-block
- * product counts (must be 0).  Returns 1 when that call did not run the tile kernel.  Synchronises the device. */
-int dbcsr_amd_mm_tile_stats(void* handle, int* waves_gave_up, int* list_mismatches);
-
-/* The same for the band kernel (dbcsr_amd/csrc/mm_band.h: CU-wide C tiles, B shared in an LDS ring): waits of the ring protocol that
- * gave up (must be 0: a block was used before it had landed), (tile, wave) lists that disagreed with the per-block product counts
- * (must be 0).  Returns 1 when the last dbcsr_amd_mm_numeric of this handle did not run the band kernel.  Synchronises the device. */
-int dbcsr_amd_mm_band_stats(void* handle, int* waits_gave_up, int* list_mismatches);
-
 /* Measurement helper (bench.py, roofline.fabric): what the L2 <-> Infinity-Cache fabric of the current device delivers, in TB/s -- a
  * plain streaming read of a 160 MB window by all CUs, and the block gather of the block-product dataflow (4232-byte blocks from
  * pseudo-random places of the window into LDS, whole 128-byte lines counted).  Takes well under a second; synchronises the device. */

@@ -4,6 +4,7 @@ and 32, dense and sparse C (groups with empty slots, lists of very different len
 of another size at the edges (their C blocks go through the second launch), row counts that are no multiple of R or of 8 R (XCDs with
 fewer groups), several column panels, retain_sparsity with in-place accumulation, k passes (each pass a launch of the group kernel with
 its own table), and the cases where the kernel must stand back: an inner tail block, a B whose blocks do not lie in index order.
+Round 6: the kernel lives in the LAB build (it does not win; dbcsr_amd/csrc/Makefile), every engine here loads it.
 Values 2e-5 of the largest element (fp32 sums in another order than the oracle's), index bit-exact."""
 import numpy as np
 import pytest
@@ -60,7 +61,7 @@ def test_group_kernel_matches_oracle(monkeypatch, name, R):
     A, B, Cm = build(CASES[name])
     bs = CASES[name][6]
     ref, info = O.multiply("N", "N", 0.75, wide(A), wide(B), 1.25, wide(Cm))
-    eng = MultiplyEngine()
+    eng = MultiplyEngine(lab=True)
     dA, dB, dC = to_dev(A), to_dev(B), to_dev(Cm)
     flop = [0]
     dbcsr_multiply("N", "N", 0.75, dA, dB, 1.25, dC, flop=flop, engine=eng)
@@ -79,7 +80,7 @@ def test_group_kernel_panels_retain_and_in_place(monkeypatch, R):
     monkeypatch.setenv("DBCSR_AMD_MM_PANEL_MB", "1")
     A, B, Cm = build(CASES["fill20_32"])
     ref, _ = O.multiply("N", "N", 1.0, wide(A), wide(B), 1.0, wide(Cm), retain_sparsity=True)
-    eng = MultiplyEngine()
+    eng = MultiplyEngine(lab=True)
     dA, dB, dC = to_dev(A), to_dev(B), to_dev(Cm)
     dbcsr_multiply("N", "N", 1.0, dA, dB, 1.0, dC, retain_sparsity=True, engine=eng)
     torch.cuda.synchronize()
@@ -101,7 +102,7 @@ def test_group_kernel_in_k_passes(monkeypatch, npass):
     monkeypatch.setenv("DBCSR_AMD_MM_KCHUNKS", str(npass))
     A, B, Cm = build((32 * 21, 32 * 15, 32 * 96, 0.8, 0.8, 0.7, 32))
     ref, info = O.multiply("N", "N", 1.0, wide(A), wide(B), 1.0, wide(Cm))
-    eng = MultiplyEngine()
+    eng = MultiplyEngine(lab=True)
     dA, dB = to_dev(A), to_dev(B)
     for _ in range(3):
         dC = to_dev(Cm)
@@ -120,7 +121,7 @@ def test_group_kernel_stands_back(monkeypatch):
     # (a) an inner tail block: products of another k extent would sit in the lists
     A, B, Cm = build((32 * 12, 32 * 11, 32 * 13 + 12, 0.5, 0.5, 0.5, 32))
     ref, _ = O.multiply("N", "N", 1.0, wide(A), wide(B), 1.0, wide(Cm))
-    eng = MultiplyEngine()
+    eng = MultiplyEngine(lab=True)
     dA, dB, dC = to_dev(A), to_dev(B), to_dev(Cm)
     dbcsr_multiply("N", "N", 1.0, dA, dB, 1.0, dC, engine=eng)
     torch.cuda.synchronize()
@@ -137,7 +138,7 @@ def test_group_kernel_stands_back(monkeypatch):
     for b in range(nb):
         data[new_p[b]:new_p[b] + sizes[b]] = B.data[B.blk_p[b]:B.blk_p[b] + sizes[b]]
     Brev = O.Bcsr(B.row_sizes, B.col_sizes, B.row_p, B.col_i, new_p, data)
-    eng = MultiplyEngine()
+    eng = MultiplyEngine(lab=True)
     dA, dB, dC = to_dev(A), to_dev(Brev), to_dev(Cm)
     dbcsr_multiply("N", "N", 1.0, dA, dB, 1.0, dC, engine=eng)
     torch.cuda.synchronize()
@@ -145,7 +146,7 @@ def test_group_kernel_stands_back(monkeypatch):
     check(dev_to_bcsr(dC), ref)
     # (c) switched off
     monkeypatch.setenv("DBCSR_AMD_MM_F32_GROUP", "0")
-    eng = MultiplyEngine()
+    eng = MultiplyEngine(lab=True)
     dA, dB, dC = to_dev(A), to_dev(B), to_dev(Cm)
     dbcsr_multiply("N", "N", 1.0, dA, dB, 1.0, dC, engine=eng)
     torch.cuda.synchronize()
@@ -159,21 +160,21 @@ def test_group_kernel_automatic_choice(monkeypatch):
     for k in ENV:
         monkeypatch.delenv(k, raising=False)
     A, B, Cm = build((32 * 36, 32 * 34, 32 * 120, 0.6, 0.6, 0.5, 32))   # 120 * 0.16 = 19 products per block
-    eng = MultiplyEngine()
+    eng = MultiplyEngine(lab=True)
     dA, dB, dC = to_dev(A), to_dev(B), to_dev(Cm)
     dbcsr_multiply("N", "N", 1.0, dA, dB, 1.0, dC, engine=eng)
     torch.cuda.synchronize()
     assert eng.last_kernel() == "mm_numeric_f32_direct<32,32,32>", eng.last_kernel()
     monkeypatch.setenv("DBCSR_AMD_MM_F32_GROUP", "-1")
     ref, _ = O.multiply("N", "N", 1.0, wide(A), wide(B), 1.0, wide(Cm))
-    eng = MultiplyEngine()
+    eng = MultiplyEngine(lab=True)
     dA, dB, dC = to_dev(A), to_dev(B), to_dev(Cm)
     dbcsr_multiply("N", "N", 1.0, dA, dB, 1.0, dC, engine=eng)
     torch.cuda.synchronize()
     assert eng.last_kernel() == "mm_numeric_f32_group<32,32,32;4>", eng.last_kernel()
     check(dev_to_bcsr(dC), ref)
     A, B, Cm = build(CASES["sparse32"])
-    eng = MultiplyEngine()
+    eng = MultiplyEngine(lab=True)
     dA, dB, dC = to_dev(A), to_dev(B), to_dev(Cm)
     dbcsr_multiply("N", "N", 1.0, dA, dB, 1.0, dC, engine=eng)
     torch.cuda.synchronize()

@@ -72,13 +72,10 @@ def test_no_scratch_and_exact_kernels_keep_their_occupancy(tmp_path):
     assert all(v <= 96 for v in hot32.values()), hot32
     # round 5.  The fp32 direct kernels: five waves per SIMD (<= 96 registers).  The workgroup-per-C-block kernels of the blocks of 33 ... 80:
     # 16 shapes, the largest (5 x 5 tiles per wave: 50 accumulator registers) within 3 waves per SIMD (<= 168), the smallest within 8.
-    # The fp32 group kernels: R accumulator sets in architectural registers (VGPR-form MFMA), two waves per SIMD at least.
     direct32 = {pretty[n]: k["vgpr_count"] for n, k in ks.items() if "mm_numeric_f32_direct<" in pretty[n]}
     assert len(direct32) == 3 and all(v <= 96 for v in direct32.values()), direct32
     big = {pretty[n]: k["vgpr_count"] for n, k in ks.items() if "mm_numeric_f64_big<" in pretty[n]}
     assert len(big) == 16 and all(v <= 168 for v in big.values()), big
-    group = {pretty[n]: k["vgpr_count"] for n, k in ks.items() if "mm_numeric_f32_group<" in pretty[n]}
-    assert len(group) == 9 and all(v <= 256 for v in group.values()), group
 
 
 def test_shipping_build_holds_no_experiment(tmp_path):
@@ -86,10 +83,16 @@ def test_shipping_build_holds_no_experiment(tmp_path):
     ablation or keep-alive variant of the exact-size kernel (what ships must be auditable)"""
     ks = kernels_of_library(tmp_path)
     pretty = demangle(sorted(ks))
-    lab_only = [v for v in pretty.values() if re.search(r"mm_numeric_f64_(tile|band|dma|hot_persistent)<", v) or
+    lab_only = [v for v in pretty.values() if re.search(r"mm_numeric_f64_(tile|band|dma|hot_persistent|group)<", v) or "mm_numeric_f32_group<" in v or
                 re.search(r"mm_numeric_f64_hot<\d+, \d+, \d+, [1-9]>", v) or re.search(r"\b(tile|band)_(lists|descs|remainder|select)", v)]
     assert not lab_only, lab_only
     assert sum("mm_numeric_f64_hot<" in v for v in pretty.values()) == 24
+    # round 6 (VERDICT r05 weak 9): the EXPORT list too -- no diagnostics or launchers of the experimental dataflows
+    nm = shutil.which("nm") or os.path.join(LLVM, "llvm-nm")
+    exported = [l.split()[-1] for l in subprocess.run([nm, "-D", "--defined-only", LIB], capture_output=True, text=True).stdout.splitlines() if l.strip()]
+    assert len(exported) > 60
+    leftovers = [s for s in exported if re.search(r"tile|band|group|persistent|dma_", s, re.I)]
+    assert not leftovers, leftovers
 
 
 def test_lab_build_kernels_fit_their_occupancy(tmp_path):
@@ -107,3 +110,9 @@ def test_lab_build_kernels_fit_their_occupancy(tmp_path):
     band = {pretty[n]: k["vgpr_count"] for n, k in ks.items() if "mm_numeric_f64_band<" in pretty[n]}
     band_waves = lambda n: int(re.search(r"band<\d+, \d+, \d+, \d+, \d+, (\d+),", n).group(1))
     assert band and all(v <= (256 if band_waves(n) == 8 else 128) for n, v in band.items()), band
+    # the group kernels (mm_group.hip fp32, round 5; mm_group64.hip fp64, round 6): R accumulator sets in architectural registers, two waves per
+    # SIMD (<= 256 registers) for every R
+    group = {pretty[n]: k["vgpr_count"] for n, k in ks.items() if "mm_numeric_f32_group<" in pretty[n]}
+    assert len(group) == 9 and all(v <= 256 for v in group.values()), group
+    group64 = {pretty[n]: k["vgpr_count"] for n, k in ks.items() if "mm_numeric_f64_group<" in pretty[n]}
+    assert len(group64) == 16 and all(v <= 256 for v in group64.values()), group64
