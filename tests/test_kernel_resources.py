@@ -116,3 +116,4 @@ def test_lab_build_kernels_fit_their_occupancy(tmp_path):
     assert len(group) == 9 and all(v <= 256 for v in group.values()), group
     group64 = {pretty[n]: k["vgpr_count"] for n, k in ks.items() if "mm_numeric_f64_group<" in pretty[n]}
     assert len(group64) == 16 and all(v <= 256 for v in group64.values()), group64
+
