@@ -790,6 +790,34 @@ class CannonMultiply:
         works = dist.batch_isend_irecv(ops) if ops else []
         return works, staged
 
+    def comm_probe(self, reps=2):
+        """The step's panel exchange ALONE (no multiply beside it): every image this rank misses travels as in one step of the gather
+        schedule, timed on the host between two device synchronisations (the caller reduces over the ranks).  Returns the bytes this
+        rank received, the largest share that came from ONE peer -- over ONE xGMI link -- and the best time: what bench.py's
+        `comm` object (GB/s per link, overlap fraction) is made of."""
+        import time
+        g, r, c = self.grid, self.grid.myprow, self.grid.mypcol
+        esz = torch.empty(0, dtype=self.dtype).element_size()
+        per_peer = {}
+        for v in range(g.nvirt):
+            for n, own in ((self.A_img[v].data_numel, g.a_owner(r, v)), (self.B_img[v].data_numel, g.b_owner(v, c))):
+                if n and own != g.rank:
+                    per_peer[own] = per_peer.get(own, 0) + n * esz
+        best = float("inf")
+        sync = torch.cuda.synchronize if self.device.type == "cuda" else (lambda: None)
+        for _ in range(max(1, reps)):
+            sync()
+            if dist.is_initialized() and g.world > 1:
+                dist.barrier()
+            sync()
+            t0 = time.perf_counter()
+            works, staged = self._post_all()
+            self._arrived(works, staged)
+            sync()
+            best = min(best, time.perf_counter() - t0)
+        return {"bytes_in": int(sum(per_peer.values())), "peers_in": len(per_peer), "max_bytes_from_one_peer": int(max(per_peer.values()) if per_peer else 0),
+                "ms": best * 1e3}
+
     def _multiply_gather(self, alpha, beta):
         eng = self.last_engine = self.eng
         works, staged = self._post_all()                       # panels travel over all links ...

@@ -1514,7 +1514,7 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
       }
 #undef DBCSR_LAUNCH
     } else if (E->use_big && E->use_lds && E->max_m <= 80 && E->max_n <= 80 && E->min_m >= 1 && E->min_n >= 1 && E->min_k >= 1 && !E->cls_mode &&
-               E->order_len > 0 &&
+               E->order_len > 0 && (E->max_m > 32 || E->max_n > 32 || ((E->max_m + 7) / 8) * ((E->max_n + 7) / 8) >= 4) &&
                launch_big_f64(std::max(2, ((E->max_m + 7) / 8 + 1) / 2), std::max(2, ((E->max_n + 7) / 8 + 1) / 2), (unsigned)(8 * E->order_len), st,
                               E->descs.p, nblk, E->entries.p, static_cast<const double*>(a->data), static_cast<const double*>(b->data),
                               static_cast<double*>(c_out->data), static_cast<const double*>(c_in->data), alpha, beta,

@@ -536,7 +536,10 @@ int process_stack_f64(const int* dev_stack, int nstack, const double* a, const d
   if (m <= 0 || n <= 0 || k <= 0) return 0;
   // blocks of 33 ... 80 (or an inner dimension above 32): a workgroup per group of entries, operand slabs shared through LDS
   static const bool big_off = getenv("DBCSR_AMD_SMM_BIG") != nullptr && atoi(getenv("DBCSR_AMD_SMM_BIG")) == 0;
-  if (!big_off && (m > 32 || n > 32 || k > 32) && m <= 80 && n <= 80 && (int64_t)m * k * 8 < (1ll << 30) && (int64_t)n * k * 8 < (1ll << 30))
+  // (a long inner dimension alone takes this path only when the C block has work for the four waves of a workgroup -- at least 2 x 2 tiles of
+  // 8 x 8: for 5 x 5 x 64 three of them would stage slabs and wait at barriers for nothing; those stay with the wave-per-entry kernels below)
+  const bool wide = m > 32 || n > 32 || (k > 32 && ((m + 7) / 8) * ((n + 7) / 8) >= 4);
+  if (!big_off && wide && m <= 80 && n <= 80 && (int64_t)m * k * 8 < (1ll << 30) && (int64_t)n * k * 8 < (1ll << 30))
     return process_stack_f64_big(dev_stack, nstack, a, b, c, m, n, k, bt, st);
   // C tile per wave: up to 32 x 32; larger blocks are tiled over grid.y/z
   const int MA = m >= 32 ? 4 : (m + 7) / 8, NC = n >= 32 ? 4 : (n + 7) / 8;
