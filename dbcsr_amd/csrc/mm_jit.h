@@ -1,4 +1,4 @@
-// mm_jit.h -- run-time compilation (hiprtc) of the exact-size class kernels of mm_exact.h, cached per process.
+// mm_jit.h -- run-time compilation (hiprtc) of the exact-size class kernels of mm_exact.h and the stack kernels of smm_exact.h, cached per process.
 // The reference does the same per (m, n, k) triple (src/acc/libsmm_acc/libsmm_acc.cpp:90-195, ~0.5 s per kernel there).
 #ifndef DBCSR_AMD_MM_JIT_H
 #define DBCSR_AMD_MM_JIT_H
@@ -16,6 +16,16 @@ struct ClassKernel {
 // (the caller then runs the generic kernel on that class).
 // g > 1: the variant in which a wave walks g consecutive C blocks of the class (mm_class_stream_body)
 int jit_class_kernel(int m, int n, int k0, int k1, int k2, int g, ClassKernel* out);
+
+
+// The exact-size kernel of smm_exact.h for homogeneous parameter stacks of (m, n, k), all <= 32; bt: B as libsmm_acc_transpose leaves it
+// (n x k).  Same contract as above: thread-safe, compiled on the first stack of a triplet, non-zero when hiprtc is unavailable or fails
+// (the caller then runs smm_stack_f64_lds).
+struct StackKernel {
+  hipFunction_t fn = nullptr;
+  int wave_lds = 0;
+};
+int jit_stack_kernel(int m, int n, int k, bool bt, StackKernel* out);
 
 }  // namespace dbcsr_amd
 #endif

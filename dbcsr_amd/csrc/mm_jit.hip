@@ -1,5 +1,5 @@
-// mm_jit.hip -- hiprtc front end for mm_exact.h (see mm_jit.h).  libhiprtc is opened lazily: a process that never meets a
-// mixed-size multiply does not load it.
+// mm_jit.hip -- hiprtc front end for mm_exact.h and smm_exact.h (see mm_jit.h).  libhiprtc is opened lazily: a process that never meets a
+// mixed-size multiply or a homogeneous parameter stack does not load it.
 #include "mm_jit.h"
 
 #include <dlfcn.h>
@@ -13,12 +13,13 @@
 #include <tuple>
 #include <vector>
 
-#include "mm_exact.h"  // class_wave_lds(): the same constexpr function the kernel sizes its LDS slice with
+#include "mm_exact.h"   // class_wave_lds(): the same constexpr function the kernel sizes its LDS slice with
+#include "smm_exact.h"  // stack_wave_lds()
 
 namespace dbcsr_amd {
 namespace {
 
-#include "jit_sources.inc"  // kJitSrc_mm_types, kJitSrc_smm_core, kJitSrc_mm_exact: the texts of the three headers
+#include "jit_sources.inc"  // kJitSrc_mm_types, kJitSrc_smm_core, kJitSrc_mm_exact, kJitSrc_smm_exact: the texts of the four headers
 
 typedef struct _hiprtcProgram* rtc_program;
 struct Rtc {
@@ -69,6 +70,59 @@ struct Cached {
 std::mutex g_mu;
 std::map<std::tuple<int, int, int, int, int, int, int>, Cached> g_cache;  // (device, m, n, k0, k1, k2, g)
 
+// text `defs` (macros + one #include) -> code object -> module; the function `entry` of it.  Caller holds g_mu.
+int compile_and_load(const char* defs, const char* tu_name, const char* what, const char* entry, const hipDeviceProp_t& prop, hipModule_t* mod,
+                     hipFunction_t* fn, size_t* code_size) {
+  Rtc& r = rtc();
+  if (!r.ok) return -1;
+  const char* hsrc[] = {kJitSrc_mm_types, kJitSrc_smm_core, kJitSrc_mm_exact, kJitSrc_smm_exact};
+  const char* hname[] = {"mm_types.h", "smm_core.h", "mm_exact.h", "smm_exact.h"};
+  rtc_program prog = nullptr;
+  if (r.CreateProgram(&prog, defs, tu_name, 4, hsrc, hname) != 0) return -1;
+  std::string arch = std::string("--offload-arch=") + prop.gcnArchName;
+  // DBCSR_AMD_JIT_DEFS: extra -D switches for the kernel text (tuning experiments, see mm_exact.h), space separated
+  std::vector<std::string> extra;
+  if (const char* d = getenv("DBCSR_AMD_JIT_DEFS")) {
+    std::string all(d);
+    size_t pos = 0;
+    while (pos < all.size()) {
+      const size_t e = all.find(' ', pos);
+      const std::string tok = all.substr(pos, e == std::string::npos ? std::string::npos : e - pos);
+      if (!tok.empty()) extra.push_back(tok);
+      if (e == std::string::npos) break;
+      pos = e + 1;
+    }
+  }
+  std::vector<const char*> opts = {arch.c_str(), "-O3", "-std=c++17", "-munsafe-fp-atomics"};
+  for (const std::string& t : extra) opts.push_back(t.c_str());
+  const int rc = r.CompileProgram(prog, (int)opts.size(), opts.data());
+  if (rc != 0) {
+    size_t ls = 0;
+    r.GetProgramLogSize(prog, &ls);
+    std::string log(ls + 1, 0);
+    if (ls) r.GetProgramLog(prog, &log[0]);
+    fprintf(stderr, "dbcsr_amd: hiprtc failed for %s:\n%s\n", what, log.c_str());
+    r.DestroyProgram(&prog);
+    return -1;
+  }
+  size_t cs = 0;
+  r.GetCodeSize(prog, &cs);
+  std::vector<char> code(cs);
+  r.GetCode(prog, code.data());
+  r.DestroyProgram(&prog);
+  if (hipModuleLoadData(mod, code.data()) != hipSuccess) return -1;
+  if (hipModuleGetFunction(fn, *mod, entry) != hipSuccess) return -1;
+  if (code_size) *code_size = cs;
+  return 0;
+}
+
+struct CachedStack {
+  hipModule_t mod = nullptr;
+  StackKernel k;
+  bool failed = false;
+};
+std::map<std::tuple<int, int, int, int, int>, CachedStack> g_stack_cache;  // (device, m, n, k, bt)
+
 }  // namespace
 
 int jit_class_kernel(int m, int n, int k0, int k1, int k2, int g, ClassKernel* out) {
@@ -86,8 +140,6 @@ int jit_class_kernel(int m, int n, int k0, int k1, int k2, int g, ClassKernel* o
   }
   Cached& c = g_cache[key];
   c.failed = true;
-  Rtc& r = rtc();
-  if (!r.ok) return -1;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
   const int wave_lds = class_wave_lds(m, n, k0, k1, k2);
@@ -100,46 +152,49 @@ int jit_class_kernel(int m, int n, int k0, int k1, int k2, int g, ClassKernel* o
            "#define DBCSR_AMD_JIT_M %d\n#define DBCSR_AMD_JIT_N %d\n#define DBCSR_AMD_JIT_K0 %d\n#define DBCSR_AMD_JIT_K1 %d\n"
            "#define DBCSR_AMD_JIT_K2 %d\n#define DBCSR_AMD_JIT_MINW %d\n#define DBCSR_AMD_JIT_G %d\n#include \"mm_exact.h\"\n",
            m, n, k0, k1, k2, minw, g);
-  const char* hsrc[] = {kJitSrc_mm_types, kJitSrc_smm_core, kJitSrc_mm_exact};
-  const char* hname[] = {"mm_types.h", "smm_core.h", "mm_exact.h"};
-  rtc_program prog = nullptr;
-  if (r.CreateProgram(&prog, defs, "mm_class.hip", 3, hsrc, hname) != 0) return -1;
-  std::string arch = std::string("--offload-arch=") + prop.gcnArchName;
-  // DBCSR_AMD_JIT_DEFS: extra -D switches for the kernel text (tuning experiments, see mm_exact.h), space separated
-  std::vector<std::string> extra;
-  if (const char* d = getenv("DBCSR_AMD_JIT_DEFS")) {
-    std::string all(d);
-    size_t pos = 0;
-    while (pos < all.size()) {
-      const size_t e = all.find(' ', pos);
-      const std::string tok = all.substr(pos, e == std::string::npos ? std::string::npos : e - pos);
-      if (!tok.empty()) extra.push_back(tok);
-      if (e == std::string::npos) break;
-      pos = e + 1;
-    }
-  }
-  std::vector<const char*> opts = {arch.c_str(), "-O3", "-std=c++17"};
-  for (const std::string& t : extra) opts.push_back(t.c_str());
-  const int rc = r.CompileProgram(prog, (int)opts.size(), opts.data());
-  if (rc != 0) {
-    size_t ls = 0;
-    r.GetProgramLogSize(prog, &ls);
-    std::string log(ls + 1, 0);
-    if (ls) r.GetProgramLog(prog, &log[0]);
-    fprintf(stderr, "dbcsr_amd: hiprtc failed for class (%d, %d; %d, %d, %d):\n%s\n", m, n, k0, k1, k2, log.c_str());
-    r.DestroyProgram(&prog);
-    return -1;
-  }
+  char what[96];
+  snprintf(what, sizeof what, "class (%d, %d; %d, %d, %d)", m, n, k0, k1, k2);
   size_t cs = 0;
-  r.GetCodeSize(prog, &cs);
-  std::vector<char> code(cs);
-  r.GetCode(prog, code.data());
-  r.DestroyProgram(&prog);
-  if (hipModuleLoadData(&c.mod, code.data()) != hipSuccess) return -1;
-  if (hipModuleGetFunction(&c.k.fn, c.mod, "mm_numeric_f64_class") != hipSuccess) return -1;
+  if (compile_and_load(defs, "mm_class.hip", what, "mm_numeric_f64_class", prop, &c.mod, &c.k.fn, &cs) != 0) return -1;
   c.k.wave_lds = wave_lds;
   c.failed = false;
   if (getenv("DBCSR_AMD_MM_VERBOSE")) fprintf(stderr, "dbcsr_amd: compiled class kernel (%d, %d; %d, %d, %d), %zu bytes, %d B LDS per wave\n", m, n, k0, k1, k2, cs, wave_lds);
+  *out = c.k;
+  return 0;
+}
+
+
+int jit_stack_kernel(int m, int n, int k, bool bt, StackKernel* out) {
+  if (!out || m < 1 || n < 1 || k < 1 || m > 32 || n > 32 || k > 32) return -1;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return -1;
+  std::lock_guard<std::mutex> lock(g_mu);
+  auto key = std::make_tuple(dev, m, n, k, (int)bt);
+  auto it = g_stack_cache.find(key);
+  if (it != g_stack_cache.end()) {
+    if (it->second.failed) return -1;
+    *out = it->second.k;
+    return 0;
+  }
+  CachedStack& c = g_stack_cache[key];
+  c.failed = true;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+  const int wave_lds = stack_wave_lds(m, n, k, bt);
+  int wgs = (160 * 1024) / (4 * wave_lds);
+  const int minw = wgs > 4 ? 4 : (wgs < 1 ? 1 : wgs);
+  char defs[512];
+  snprintf(defs, sizeof defs,
+           "#define DBCSR_AMD_JIT_SM %d\n#define DBCSR_AMD_JIT_SN %d\n#define DBCSR_AMD_JIT_SK %d\n#define DBCSR_AMD_JIT_SBT %d\n"
+           "#define DBCSR_AMD_JIT_MINW %d\n#include \"smm_exact.h\"\n",
+           m, n, k, bt ? 1 : 0, minw);
+  char what[96];
+  snprintf(what, sizeof what, "stack kernel (%d, %d, %d%s)", m, n, k, bt ? "; B transposed" : "");
+  size_t cs = 0;
+  if (compile_and_load(defs, "smm_stack_exact.hip", what, "smm_stack_f64_exact", prop, &c.mod, &c.k.fn, &cs) != 0) return -1;
+  c.k.wave_lds = wave_lds;
+  c.failed = false;
+  if (getenv("DBCSR_AMD_MM_VERBOSE")) fprintf(stderr, "dbcsr_amd: compiled %s, %zu bytes, %d B LDS per wave\n", what, cs, wave_lds);
   *out = c.k;
   return 0;
 }

@@ -24,10 +24,16 @@
 #include "mm_types.h"
 #include "smm_core.h"
 #include "mm_numeric_f64_big.h"   // slab geometry of the workgroup-per-C-block kernel (BIG_KSL, BIG_PB, big_*_bytes)
+#include "mm_jit.h"               // jit_stack_kernel: the exact-size kernel of smm_exact.h, compiled per (m, n, k) at run time
 
 namespace dbcsr_amd {
 
 constexpr int kStackGroup = 16;  // default number of stack entries per wavefront (see stack_group())
+
+// name of the kernel the calling host thread's last libsmm_acc_process launched (dbcsr_amd_smm_last_kernel: tests and acc_bench say
+// which dataflow they measured)
+thread_local char g_last_smm_kernel[64] = "";
+static void note_kernel(const char* fmt, int m, int n, int k, bool bt) { snprintf(g_last_smm_kernel, sizeof g_last_smm_kernel, fmt, m, n, k, bt ? "; B transposed" : ""); }
 
 template <int MA, int NC, bool BT>
 __global__ void __launch_bounds__(256) smm_stack_f64(const int* __restrict__ stack, int nstack, const double* __restrict__ a_data,
@@ -530,17 +536,67 @@ static int process_stack_f64_big(const int* dev_stack, int nstack, const double*
   }
 }
 
+// Homogeneous stacks of blocks up to 32 x 32 x 32 (round 6): the exact-size kernel of smm_exact.h, compiled the first time a stack of the
+// triplet arrives -- as the reference does (libsmm_acc.cpp:90-195, 281-321).  Short stacks of a triplet not compiled yet do not pay for a
+// compilation (~0.5 s); they -- and every stack when hiprtc is missing or DBCSR_AMD_SMM_EXACT=0 -- run the run-time-size kernels below.
+// DBCSR_AMD_SMM_EXACT=1: every stack (tests).  Returns 1 when the stack was not taken.
+static int process_stack_f64_exact(const int* dev_stack, int nstack, const double* a, const double* b, double* c, int m, int n, int k, bool bt,
+                                   hipStream_t st) {
+  static const int mode = getenv("DBCSR_AMD_SMM_EXACT") ? atoi(getenv("DBCSR_AMD_SMM_EXACT")) : -1;   // -1: automatic
+  if (mode == 0) return 1;
+  // blocks below 8^3: a stack is one launch of ~13 us whatever the kernel, and sixteen host threads launching through hipModuleLaunchKernel were
+  // measured slower than through the ahead-of-time kernels (4^3: 0.17 against 0.13 ms per stack and thread, profiles/r06_acc_abi_threads.txt)
+  if (mode < 0 && (int64_t)m * n * k < 512) return 1;
+  struct Hit {
+    int m = 0, n = 0, k = 0, bt = 0, dev = -1;
+    StackKernel sk;
+  };
+  thread_local Hit last[4];   // the triplets this host thread met last (a host thread works through stacks of a few triplets in turn)
+  thread_local int next = 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 1;
+  const StackKernel* sk = nullptr;
+  for (const Hit& h : last)
+    if (h.dev == dev && h.m == m && h.n == n && h.k == k && h.bt == (int)bt) sk = &h.sk;
+  if (!sk) {
+    if (mode < 0 && nstack < 256) return 1;
+    Hit& h = last[next];
+    if (jit_stack_kernel(m, n, k, bt, &h.sk) != 0) {
+      h.dev = -1;
+      return 1;
+    }
+    h.m = m, h.n = n, h.k = k, h.bt = (int)bt, h.dev = dev;
+    next = (next + 1) & 3;
+    sk = &h.sk;
+  }
+  const int group = stack_group(m, n, k);
+  const int nwaves = (nstack + group - 1) / group;
+  int group_arg = group;
+  const int* stack_arg = dev_stack;
+  void* args[] = {&stack_arg, &nstack, &a, &b, &c, &group_arg};
+  note_kernel("smm_stack_f64_exact<%d,%d,%d%s>", m, n, k, bt);
+  const hipError_t e = hipModuleLaunchKernel(sk->fn, (unsigned)((nwaves + 3) / 4), 1, 1, 256, 1, 1, (unsigned)(4 * sk->wave_lds), st, args, nullptr);
+  return dbcsr_amd::check(e, "smm_stack_f64_exact launch", __FILE__, __LINE__);
+}
+
 int process_stack_f64(const int* dev_stack, int nstack, const double* a, const double* b, double* c, int m, int n, int k, bool bt,
                       hipStream_t st) {
   if (nstack <= 0) return 0;
   if (m <= 0 || n <= 0 || k <= 0) return 0;
+  if (m <= 32 && n <= 32 && k <= 32) {
+    const int rc = process_stack_f64_exact(dev_stack, nstack, a, b, c, m, n, k, bt, st);
+    if (rc <= 0) return rc;
+  }
   // blocks of 33 ... 80 (or an inner dimension above 32): a workgroup per group of entries, operand slabs shared through LDS
   static const bool big_off = getenv("DBCSR_AMD_SMM_BIG") != nullptr && atoi(getenv("DBCSR_AMD_SMM_BIG")) == 0;
   // (a long inner dimension alone takes this path only when the C block has work for the four waves of a workgroup -- at least 2 x 2 tiles of
   // 8 x 8: for 5 x 5 x 64 three of them would stage slabs and wait at barriers for nothing; those stay with the wave-per-entry kernels below)
   const bool wide = m > 32 || n > 32 || (k > 32 && ((m + 7) / 8) * ((n + 7) / 8) >= 4);
-  if (!big_off && wide && m <= 80 && n <= 80 && (int64_t)m * k * 8 < (1ll << 30) && (int64_t)n * k * 8 < (1ll << 30))
+  if (!big_off && wide && m <= 80 && n <= 80 && (int64_t)m * k * 8 < (1ll << 30) && (int64_t)n * k * 8 < (1ll << 30)) {
+    note_kernel("smm_stack_f64_big(%d,%d,%d%s)", m, n, k, bt);
     return process_stack_f64_big(dev_stack, nstack, a, b, c, m, n, k, bt, st);
+  }
+  note_kernel(m <= 32 && n <= 32 && k <= 32 ? "smm_stack_f64_lds(%d,%d,%d%s)" : "smm_stack_f64(%d,%d,%d%s)", m, n, k, bt);
   // C tile per wave: up to 32 x 32; larger blocks are tiled over grid.y/z
   const int MA = m >= 32 ? 4 : (m + 7) / 8, NC = n >= 32 ? 4 : (n + 7) / 8;
   const int tiles_r = (m + 8 * MA - 1) / (8 * MA), tiles_c = (n + 8 * NC - 1) / (8 * NC);
@@ -694,6 +750,8 @@ int libsmm_acc_finalize(void) { return 0; }
 c_dbcsr_acc_bool_t libsmm_acc_is_thread_safe(void) { return 1; }
 
 int libsmm_acc_gpu_warp_size(void) { return 64; }
+
+const char* dbcsr_amd_smm_last_kernel(void) { return g_last_smm_kernel; }
 
 int libsmm_acc_transpose(const int* dev_trs_stack, int offset, int stack_size, void* dev_data, libsmm_acc_data_t datatype, int m,
                          int n, int max_kernel_dim, void* stream) {

@@ -34,7 +34,7 @@ MM_SYMBOLS = [
     "dbcsr_amd_bcsr_crop_count", "dbcsr_amd_bcsr_crop_apply", "dbcsr_amd_bcsr_scale_window",
     "dbcsr_amd_multiply", "dbcsr_amd_bcsr_release", "dbcsr_amd_bcsr_desymmetrize_count", "dbcsr_amd_bcsr_desymmetrize_apply",
     "dbcsr_amd_bcsr_twin_count", "dbcsr_amd_bcsr_twin_apply", "dbcsr_amd_mm_set_canonical_product", "dbcsr_amd_multiply_symmetric_c",
-    "dbcsr_amd_bcsr_desymmetrized",
+    "dbcsr_amd_bcsr_desymmetrized", "dbcsr_amd_smm_last_kernel",
 ]
 
 
@@ -161,6 +161,8 @@ def load_library(lab=False):
     L.dbcsr_amd_comm_allgather.argtypes = [vp, vp, vp, i64, vp]
     L.dbcsr_amd_mm_last_kernel.argtypes = [vp]
     L.dbcsr_amd_mm_last_kernel.restype = C.c_char_p
+    L.dbcsr_amd_smm_last_kernel.argtypes = []
+    L.dbcsr_amd_smm_last_kernel.restype = C.c_char_p
     L.dbcsr_amd_fabric_probe.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.dbcsr_amd_mm_plan_stats.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
     L.dbcsr_amd_mm_trust_plan.argtypes = [vp, C.c_int]

@@ -202,6 +202,9 @@ int dbcsr_amd_mm_stats(void* handle, dbcsr_amd_mnk_stat* out, int max_entries, i
 const char* dbcsr_amd_mm_kernel_name(libsmm_acc_data_t datatype);
 /* name (with its template arguments) of the block-product kernel the last dbcsr_amd_mm_numeric of this handle launched */
 const char* dbcsr_amd_mm_last_kernel(void* handle);
+/* name of the stack kernel the calling thread's last libsmm_acc_process (fp64, homogeneous stack) launched: "smm_stack_f64_exact<m,n,k>" (compiled
+   for the triplet at run time, as libsmm_acc.cpp:90-195 does), "smm_stack_f64_lds(...)" (run-time sizes), "smm_stack_f64_big(...)" (blocks of 33 ... 80) */
+const char* dbcsr_amd_smm_last_kernel(void);
 
 /* Plan reuse: a multiply whose A, B and C_in have exactly the index arrays (row_p, col_i, blk_p, block sizes) of the previous
  * multiply of this handle -- every SCF step of a CP2K run -- skips its symbolic phase: the engine keeps device copies of the last
