@@ -41,6 +41,7 @@
 #include "mm_symbolic.h"
 #include "mm_numeric_f64.h"
 #include "mm_numeric_f64_big.h"
+#include "mm_numeric_f64_mid.h"
 #include "mm_numeric_f32.h"
 #include "mm_aux.h"
 // The library comes in two builds (Makefile): the SHIPPING one holds what a multiply can run by itself -- the kernels listed above, their
@@ -259,6 +260,29 @@ static bool launch_big_f64(int tm, int tn, unsigned npos, hipStream_t st, const 
   }
 }
 
+// blocks of 33 ... 40 in both dimensions: one wave per C block (mm_numeric_f64_mid.h).  rb x cb: the dominant block in units of 4 x 4 (9 or 10 each); when
+// that is not 10 x 10 a second launch of the <10, 10> kernel takes every other block of the multiply (other_sizes: there are such blocks)
+static bool launch_mid_f64(int rb, int cb, bool other_sizes, unsigned npos, hipStream_t st, const Desc* descs, int64_t nblk, const Entry* entries,
+                           const double* a_data, const double* b_data, double* c_out, const double* c_in, double alpha, double beta, int skip_empty,
+                           const int* order) {
+  if (npos == 0) return false;
+  const size_t lds = (size_t)mid_lds_bytes(5, 5, 8);
+  const int flags = skip_empty & 1;
+  switch (rb * 16 + cb) {
+#define DBCSR_MID_CASE(A_, B_)                                                                                                                          \
+  case A_ * 16 + B_:                                                                                                                                    \
+    hipLaunchKernelGGL((mm_numeric_f64_mid<A_, B_, 8>), dim3(npos), dim3(64), lds, st, descs, nblk, entries, a_data, b_data, c_out, c_in, alpha, beta, flags, order); \
+    break;
+    DBCSR_MID_CASE(9, 9) DBCSR_MID_CASE(9, 10) DBCSR_MID_CASE(10, 9) DBCSR_MID_CASE(10, 10)
+#undef DBCSR_MID_CASE
+    default: return false;
+  }
+  if ((rb != 10 || cb != 10) && other_sizes)
+    hipLaunchKernelGGL((mm_numeric_f64_mid<10, 10, 8>), dim3(npos), dim3(64), lds, st, descs, nblk, entries, a_data, b_data, c_out, c_in, alpha, beta,
+                       flags | 16 | (rb << 8) | (cb << 12), order);
+  return true;
+}
+
 struct Engine {
   DevBuf<uint32_t> b_bm, c_bm, cin_bm;
   DevBuf<int> b_pre, c_pre, cin_pre, row_nnz, prod_cnt, blk_nze, tmp_i32;
@@ -291,6 +315,7 @@ struct Engine {
   DevBuf<GEntry> group_entries;
 #endif
   DevBuf<int64_t> group_start;
+  int use_mid = 1;     // DBCSR_AMD_MM_MID=0: blocks of 33 ... 40 through the workgroup kernel mm_numeric_f64_big instead of the one-wave kernel mm_numeric_f64_mid
   int use_big = 1;     // DBCSR_AMD_MM_BIG=0: blocks above 32 through the one-wave-per-block kernel of rounds 1-4 (mm_numeric_f64) instead of mm_numeric_f64_big
   int f32_direct = 1;  // (2: + the slim-LDS launch when every C block has the dominant size -- more waves per CU, measured 0-4 % slower: the
                        // kernel is fabric-bound, gpurun_out/r05_s17 --, 1: never slim) DBCSR_AMD_MM_F32_DIRECT=0: the fp32 exact-size kernel that stages both operands in LDS (rounds 1-4) instead of the direct form
@@ -816,6 +841,7 @@ int dbcsr_amd_mm_create(void** handle) {
   if (const char* k = getenv("DBCSR_AMD_MM_TINY")) E->use_tiny = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_F32_DIRECT")) E->f32_direct = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_BIG")) E->use_big = atoi(k);
+  if (const char* k = getenv("DBCSR_AMD_MM_MID")) E->use_mid = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_F32_GROUP")) {
     const int r = atoi(k);
     E->f32_group = (r >= 2 && r <= 4) ? r : (r < 0 ? -1 : 0);
@@ -1513,6 +1539,15 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
       }
       }
 #undef DBCSR_LAUNCH
+    } else if (E->use_big && E->use_mid && E->use_lds && E->max_m <= 40 && E->max_n <= 40 && E->max_m > 32 && E->max_n > 32 && E->min_m >= 1 && E->min_n >= 1 &&
+               E->min_k >= 1 && !E->cls_mode && E->order_len > 0 &&
+               launch_mid_f64(((E->hot_m > 32 ? E->hot_m : E->max_m) + 3) / 4, ((E->hot_n > 32 ? E->hot_n : E->max_n) + 3) / 4,
+                              E->min_m != E->max_m || E->min_n != E->max_n, (unsigned)(8 * E->order_len), st, E->descs.p, nblk, E->entries.p,
+                              static_cast<const double*>(a->data), static_cast<const double*>(b->data), static_cast<double*>(c_out->data),
+                              static_cast<const double*>(c_in->data), alpha, beta, skip_empty, E->order.p)) {
+      // blocks of 33 ... 40 in both dimensions: one wave per C block (mm_numeric_f64_mid.h), the dominant size (else the largest) multiplied exactly
+      snprintf(E->last_kernel, sizeof E->last_kernel, "mm_numeric_f64_mid<%d,%d>", ((E->hot_m > 32 ? E->hot_m : E->max_m) + 3) / 4,
+               ((E->hot_n > 32 ? E->hot_n : E->max_n) + 3) / 4);
     } else if (E->use_big && E->use_lds && E->max_m <= 80 && E->max_n <= 80 && E->min_m >= 1 && E->min_n >= 1 && E->min_k >= 1 && !E->cls_mode &&
                E->order_len > 0 && (E->max_m > 32 || E->max_n > 32 || ((E->max_m + 7) / 8) * ((E->max_n + 7) / 8) >= 4) &&
                launch_big_f64(std::max(2, ((E->max_m + 7) / 8 + 1) / 2), std::max(2, ((E->max_n + 7) / 8 + 1) / 2), (unsigned)(8 * E->order_len), st,

@@ -1,4 +1,5 @@
-"""Blocks of 33 ... 80 (libsmm_acc's range: max_kernel_dim = 80, src/core/dbcsr_config.F:185; libsmm_acc.cpp:324-339) through the
+"""Blocks of 33 ... 80 (libsmm_acc's range: max_kernel_dim = 80, src/core/dbcsr_config.F:185; libsmm_acc.cpp:324-339) -- round 6: 33 ... 40 in
+both dimensions through the one-wave kernel mm_numeric_f64_mid (see CASES), the rest through the
 workgroup-per-C-block kernel mm_numeric_f64_big (one 2 x 2 arrangement of waves per block, operand slabs of 16 inner indices shared
 through LDS) against the CPU oracle: every sub-block shape TM x TN in {2 .. 5}^2 that the host can choose, inner dimensions with every
 remainder modulo 4 and 16 (slab and k-step tails), blocks smaller than the launch's largest in the same launch, C blocks without
@@ -19,8 +20,8 @@ CASES = {
     "72cube": ((72 * 5, 72 * 4, 72 * 6, 0.4, 0.4, 0.5, [1, 72], [1, 72], [1, 72]), "mm_numeric_f64_big<5,5>"),
     "80cube_tails": ((80 * 3 + 33, 80 * 3 + 7, 80 * 4 + 50, 0.3, 0.3, 0.5, [1, 80], [1, 80], [1, 80]), "mm_numeric_f64_big<5,5>"),
     "64cube": ((64 * 5, 64 * 5, 64 * 5, 0.4, 0.4, 0.5, [1, 64], [1, 64], [1, 64]), "mm_numeric_f64_big<4,4>"),
-    "40cube": ((40 * 8, 40 * 7, 40 * 9, 0.5, 0.5, 0.5, [1, 40], [1, 40], [1, 40]), "mm_numeric_f64_big<3,3>"),
-    "33cube": ((33 * 8, 33 * 9, 33 * 7, 0.5, 0.5, 0.5, [1, 33], [1, 33], [1, 33]), "mm_numeric_f64_big<3,3>"),
+    "40cube": ((40 * 8, 40 * 7, 40 * 9, 0.5, 0.5, 0.5, [1, 40], [1, 40], [1, 40]), "mm_numeric_f64_mid<10,10>"),
+    "33cube": ((33 * 8, 33 * 9, 33 * 7, 0.5, 0.5, 0.5, [1, 33], [1, 33], [1, 33]), "mm_numeric_f64_mid<9,9>"),
     "55cube": ((55 * 6, 55 * 5, 55 * 7, 0.5, 0.5, 0.5, [1, 55], [1, 55], [1, 55]), "mm_numeric_f64_big<4,4>"),
     "45x67x78": ((45 * 7, 67 * 5, 78 * 5, 0.4, 0.4, 0.5, [1, 45], [1, 67], [1, 78]), "mm_numeric_f64_big<3,5>"),
     "78x45x67": ((78 * 4, 45 * 7, 67 * 5, 0.4, 0.4, 0.5, [1, 78], [1, 45], [1, 67]), "mm_numeric_f64_big<5,3>"),
@@ -31,9 +32,26 @@ CASES = {
     "k_remainders": ((48 * 5, 56 * 5, 420, 0.4, 0.4, 0.5, [1, 48], [1, 56], [1, 17, 1, 18, 1, 19, 1, 33, 1, 34, 1, 35, 1, 49, 1, 1, 1, 64]), "mm_numeric_f64_big<3,4>"),
     "sparse_lists": ((72 * 9, 72 * 9, 72 * 9, 0.85, 0.85, 0.7, [1, 72], [1, 72], [1, 72]), "mm_numeric_f64_big<5,5>"),   # C blocks with 0 .. 2 products
     "one_block": ((72, 80, 33, 0.0, 0.0, 0.0, [1, 72], [1, 80], [1, 33]), "mm_numeric_f64_big<5,5>"),
+    # round 6: blocks of 33 ... 40 in both dimensions -- one wave per C block in units of 4 x 4 (mm_numeric_f64_mid<rows / 4, columns / 4>): 9 x 9 with
+    # both edges, 9 x 10 / 10 x 9 with one, 10 x 10 with none; the blocks of another size (tail row / column, mixes) through the second launch
+    "34cube": ((34 * 8, 34 * 9, 34 * 7, 0.5, 0.5, 0.5, [1, 34], [1, 34], [1, 34]), "mm_numeric_f64_mid<9,9>"),
+    "35x36x37": ((35 * 8, 36 * 8, 37 * 7, 0.5, 0.5, 0.5, [1, 35], [1, 36], [1, 37]), "mm_numeric_f64_mid<9,9>"),
+    "37x33x36": ((37 * 8, 33 * 9, 36 * 7, 0.5, 0.5, 0.5, [1, 37], [1, 33], [1, 36]), "mm_numeric_f64_mid<10,9>"),
+    "36x39_k80": ((36 * 8, 39 * 8, 80 * 4, 0.5, 0.5, 0.5, [1, 36], [1, 39], [1, 80]), "mm_numeric_f64_mid<9,10>"),
+    "36cube_tails": ((36 * 6 + 20, 36 * 6 + 7, 36 * 6 + 30, 0.4, 0.4, 0.5, [1, 36], [1, 36], [1, 36]), "mm_numeric_f64_mid<9,9>"),
+    "mix_33_to_40": ((36 * 8, 36 * 8, 300, 0.5, 0.5, 0.5, [1, 33, 1, 40, 1, 37, 1, 36], [1, 40, 1, 34, 1, 38], [1, 40, 1, 5, 1, 33, 1, 17]), "mm_numeric_f64_mid<10,10>"),
+    "mostly_34_some_small": ((34 * 12 + 13, 34 * 12 + 40, 34 * 8, 0.5, 0.5, 0.5, [12, 34, 1, 13], [12, 34, 1, 40], [1, 34]), "mm_numeric_f64_mid<"),
+    # the workgroup kernel beside it: every parity of ceil(m / 8) tiles split between the two wave rows / columns
+    "41x49x20": ((41 * 7, 49 * 6, 20 * 12, 0.5, 0.5, 0.5, [1, 41], [1, 49], [1, 20]), "mm_numeric_f64_big<3,4>"),
+    "53x64x41": ((53 * 6, 64 * 5, 41 * 7, 0.5, 0.5, 0.5, [1, 53], [1, 64], [1, 41]), "mm_numeric_f64_big<4,4>"),
+    "65x73x16": ((65 * 5, 73 * 4, 16 * 15, 0.4, 0.4, 0.5, [1, 65], [1, 73], [1, 16]), "mm_numeric_f64_big<5,5>"),
+    "69x77x31": ((69 * 4, 77 * 4, 31 * 9, 0.4, 0.4, 0.5, [1, 69], [1, 77], [1, 31]), "mm_numeric_f64_big<5,5>"),
+    "33x80x5": ((33 * 9, 80 * 4, 5 * 40, 0.4, 0.4, 0.5, [1, 33], [1, 80], [1, 5]), "mm_numeric_f64_big<3,5>"),
+    "mixed_odd_sizes": ((420, 410, 400, 0.5, 0.5, 0.6, [1, 33, 1, 37, 1, 41, 1, 9, 1, 72, 1, 69], [1, 35, 1, 65, 1, 4, 1, 53, 1, 80], [1, 40, 1, 23, 1, 3, 1, 61]),
+                        "mm_numeric_f64_big<5,5>"),
 }
 ENV = ("DBCSR_AMD_MM_KERNEL", "DBCSR_AMD_MM_HOT", "DBCSR_AMD_MM_TINY", "DBCSR_AMD_MM_SYMBOLIC", "DBCSR_AMD_MM_CLASSES", "DBCSR_AMD_MM_WG_WAVES",
-       "DBCSR_AMD_MM_BIG", "DBCSR_AMD_MM_KCHUNKS")
+       "DBCSR_AMD_MM_BIG", "DBCSR_AMD_MM_MID", "DBCSR_AMD_MM_KCHUNKS")
 
 
 def check(out, ref, tol=1e-10):
@@ -54,12 +72,12 @@ def test_big_block_kernel_matches_oracle(monkeypatch, name, alpha, beta):
     flop = [0]
     dbcsr_multiply("N", "N", alpha, dA, dB, beta, dC, flop=flop, engine=eng)
     torch.cuda.synchronize()
-    assert eng.last_kernel() == expect, (eng.last_kernel(), expect)
+    assert eng.last_kernel() == expect or (expect.endswith("<") and eng.last_kernel().startswith(expect)), (eng.last_kernel(), expect)
     assert flop[0] == info["flop"]
     check(dev_to_bcsr(dC), ref)
 
 
-@pytest.mark.parametrize("name", ["72cube", "45x67x78", "mixed_sizes", "sparse_lists"])
+@pytest.mark.parametrize("name", ["72cube", "45x67x78", "mixed_sizes", "sparse_lists", "36cube_tails", "mix_33_to_40"])
 def test_big_block_kernel_retain_and_in_place(monkeypatch, name):
     """retain_sparsity, then a second product accumulated in place (C blocks without products in the call stay untouched: skip_empty)"""
     for k in ENV:

@@ -18,7 +18,9 @@ TRIPLETS = [(23, 23, 23), (13, 13, 13), (32, 32, 32), (4, 4, 4), (5, 7, 9), (1, 
             # round 5: the workgroup-per-entry-group kernel of the blocks of 33 ... 80 (smm_stack_f64_big): every sub-block shape edge, inner
             # dimensions with every remainder modulo 4 and 16
             (72, 72, 72), (80, 80, 80), (64, 64, 64), (40, 40, 40), (33, 33, 33), (55, 55, 55), (23, 23, 78), (80, 16, 37), (13, 72, 33),
-            (48, 56, 17), (48, 56, 18), (48, 56, 19), (41, 49, 35), (80, 80, 1), (33, 80, 64)]
+            (48, 56, 17), (48, 56, 18), (48, 56, 19), (41, 49, 35), (80, 80, 1), (33, 80, 64),
+            # round 6: sub-blocks in units of 4 x 4 (BigSub): odd / even halves in either dimension
+            (34, 34, 34), (35, 36, 37), (37, 33, 36), (53, 64, 41), (65, 73, 16), (69, 77, 31), (36, 36, 36), (44, 52, 20), (57, 61, 9)]
 
 
 @pytest.mark.parametrize("m,n,k", TRIPLETS)

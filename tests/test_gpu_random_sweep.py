@@ -63,9 +63,14 @@ def test_random_multiply_matches_oracle(seed):
 BIG_MIXES = [[1, 45], [1, 72], [1, 67, 1, 5], [1, 40, 1, 23], [1, 80], [2, 33, 1, 13], [1, 64], [1, 55, 1, 3], [1, 78, 1, 32], [1, 23]]
 
 
-def make_big_case(seed):
+# round 6: C blocks of 33 ... 40 in both dimensions (the one-wave kernel mm_numeric_f64_mid and its second launch for the blocks of another size)
+MID_MIXES = [[1, 33], [1, 36], [1, 40], [1, 37, 1, 34], [3, 35, 1, 8], [1, 39, 1, 40], [1, 38]]
+
+
+def make_big_case(seed, mixes=BIG_MIXES, k_mixes=BIG_MIXES):
     rng = np.random.default_rng(seed)
-    mix_m, mix_n, mix_k = (BIG_MIXES[int(rng.integers(len(BIG_MIXES)))] for _ in range(3))
+    mix_m, mix_n = (mixes[int(rng.integers(len(mixes)))] for _ in range(2))
+    mix_k = k_mixes[int(rng.integers(len(k_mixes)))]
     symm_c = "N" if rng.random() < 0.85 else ("S" if rng.random() < 0.7 else "A")
     if symm_c != "N":
         mix_n = mix_m
@@ -85,6 +90,11 @@ def make_big_case(seed):
 @pytest.mark.parametrize("seed", range(int(os.environ.get("DBCSR_AMD_SWEEP_BIG", "60"))))
 def test_random_multiply_large_blocks(seed):
     run_case(make_big_case(9000 + seed))
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("DBCSR_AMD_SWEEP_MID", "40"))))
+def test_random_multiply_blocks_of_33_to_40(seed):
+    run_case(make_big_case(12000 + seed, MID_MIXES, BIG_MIXES + MID_MIXES))
 
 
 def build_case(c):
