@@ -379,7 +379,20 @@ int dbcsr_amd_bcsr_desymmetrized(void* handle, libsmm_acc_data_t datatype, const
 int dbcsr_amd_multiply_symmetric_c(void* handle, char transa, char transb, libsmm_acc_data_t datatype, double alpha,
                                    const dbcsr_amd_bcsr* matrix_a, const dbcsr_amd_bcsr* matrix_b, double beta, const dbcsr_amd_bcsr* matrix_c,
                                    int antisymmetric, int retain_sparsity, double filter_eps, dbcsr_amd_bcsr* c_out, int64_t* flop, void* stream) {
+  return dbcsr_amd_multiply_symmetric_c_klimits(handle, transa, transb, datatype, alpha, matrix_a, matrix_b, beta, matrix_c, antisymmetric, 0, 0,
+                                                retain_sparsity, filter_eps, c_out, flop, stream);
+}
+
+// ... with limits on the INNER dimension (first_k / last_k of dbcsr_multiply: 1-based inclusive element indices, 0 = not given).  They crop op(A)'s
+// columns and op(B)'s rows and have nothing to do with C's symmetry; the reference's own tests multiply into symmetric products with exactly these
+// (tests/dbcsr_test_multiply.F:196-200: full row / column limits, any k limits).  Row / column limits together with a product with symmetry are not
+// offered (the caller leaves such a multiply to the reference path).
+int dbcsr_amd_multiply_symmetric_c_klimits(void* handle, char transa, char transb, libsmm_acc_data_t datatype, double alpha,
+                                           const dbcsr_amd_bcsr* matrix_a, const dbcsr_amd_bcsr* matrix_b, double beta, const dbcsr_amd_bcsr* matrix_c,
+                                           int antisymmetric, int64_t first_k, int64_t last_k, int retain_sparsity, double filter_eps,
+                                           dbcsr_amd_bcsr* c_out, int64_t* flop, void* stream) {
   if (!handle || !matrix_c || !c_out || matrix_c->nblkrows != matrix_c->nblkcols) return -1;
+  const int64_t limits[6] = {0, 0, 0, 0, first_k, last_k};
   if (datatype != dbcsr_type_real_8 && datatype != dbcsr_type_real_4) return -10;
   // dbcsr_mm.F:711-719: the index of a product matrix with symmetry is put into canonical form before the multiplication ...
   Owned canon;
@@ -388,8 +401,8 @@ int dbcsr_amd_multiply_symmetric_c(void* handle, char transa, char transb, libsm
   // ... the local multiply computes only the blocks stored in that form (dbcsr_mm_csr.F:280-292) ...
   dbcsr_amd_bcsr prod;
   if ((rc = dbcsr_amd_mm_set_canonical_product(handle, 1))) return rc;
-  rc = dbcsr_amd_multiply(handle, transa, transb, datatype, alpha, matrix_a, matrix_b, beta, &canon.m, nullptr, retain_sparsity, filter_eps, &prod,
-                          flop, stream);
+  rc = dbcsr_amd_multiply(handle, transa, transb, datatype, alpha, matrix_a, matrix_b, beta, &canon.m, (first_k || last_k) ? limits : nullptr,
+                          retain_sparsity, filter_eps, &prod, flop, stream);
   (void)dbcsr_amd_mm_set_canonical_product(handle, 0);
   if (rc) return rc;
   // ... and the result goes back to the stored triangle (row <= column)

@@ -34,7 +34,7 @@ MM_SYMBOLS = [
     "dbcsr_amd_bcsr_crop_count", "dbcsr_amd_bcsr_crop_apply", "dbcsr_amd_bcsr_scale_window",
     "dbcsr_amd_multiply", "dbcsr_amd_bcsr_release", "dbcsr_amd_bcsr_desymmetrize_count", "dbcsr_amd_bcsr_desymmetrize_apply",
     "dbcsr_amd_bcsr_twin_count", "dbcsr_amd_bcsr_twin_apply", "dbcsr_amd_mm_set_canonical_product", "dbcsr_amd_multiply_symmetric_c",
-    "dbcsr_amd_bcsr_desymmetrized", "dbcsr_amd_smm_last_kernel",
+    "dbcsr_amd_bcsr_desymmetrized", "dbcsr_amd_smm_last_kernel", "dbcsr_amd_multiply_symmetric_c_klimits",
 ]
 
 

@@ -193,6 +193,11 @@ int dbcsr_amd_mm_set_canonical_product(void* handle, int on);
 int dbcsr_amd_multiply_symmetric_c(void* handle, char transa, char transb, libsmm_acc_data_t datatype, double alpha,
   const dbcsr_amd_bcsr* matrix_a, const dbcsr_amd_bcsr* matrix_b, double beta, const dbcsr_amd_bcsr* matrix_c, int antisymmetric,
   int retain_sparsity, double filter_eps, dbcsr_amd_bcsr* c_out, int64_t* flop, void* stream);
+/* the same with limits on the inner dimension (dbcsr_multiply's first_k / last_k: 1-based inclusive element indices, 0 = not given) -- what the
+   reference's own tests of products with symmetry use (tests/dbcsr_test_multiply.F:196-200: full row / column limits, any k limits) */
+int dbcsr_amd_multiply_symmetric_c_klimits(void* handle, char transa, char transb, libsmm_acc_data_t datatype, double alpha,
+  const dbcsr_amd_bcsr* matrix_a, const dbcsr_amd_bcsr* matrix_b, double beta, const dbcsr_amd_bcsr* matrix_c, int antisymmetric,
+  int64_t first_k, int64_t last_k, int retain_sparsity, double filter_eps, dbcsr_amd_bcsr* c_out, int64_t* flop, void* stream);
 
 /* Statistics of the last dbcsr_amd_mm_numeric of this handle, by (m, n, k): at most max_entries records are written to
  * `out` (host memory), *n_entries receives the number of distinct triples (larger than max_entries = truncated).
