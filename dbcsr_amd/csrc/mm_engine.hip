@@ -41,7 +41,7 @@
 #include "mm_symbolic.h"
 #include "mm_numeric_f64.h"
 #include "mm_numeric_f64_big.h"
-#include "mm_numeric_f64_mid.h"
+#include "mm_mid.h"   // the one-wave slab kernels of the blocks of 25 ... 40 (mm_numeric_f64_mid.h, mm_mid.hip)
 #include "mm_numeric_f32.h"
 #include "mm_aux.h"
 // The library comes in two builds (Makefile): the SHIPPING one holds what a multiply can run by itself -- the kernels listed above, their
@@ -258,29 +258,6 @@ static bool launch_big_f64(int tm, int tn, unsigned npos, hipStream_t st, const 
 #undef DBCSR_BIG_CASE
     default: return false;
   }
-}
-
-// blocks of 33 ... 40 in both dimensions: one wave per C block (mm_numeric_f64_mid.h).  rb x cb: the dominant block in units of 4 x 4 (9 or 10 each); when
-// that is not 10 x 10 a second launch of the <10, 10> kernel takes every other block of the multiply (other_sizes: there are such blocks)
-static bool launch_mid_f64(int rb, int cb, bool other_sizes, unsigned npos, hipStream_t st, const Desc* descs, int64_t nblk, const Entry* entries,
-                           const double* a_data, const double* b_data, double* c_out, const double* c_in, double alpha, double beta, int skip_empty,
-                           const int* order) {
-  if (npos == 0) return false;
-  const size_t lds = (size_t)mid_lds_bytes(5, 5, 8);
-  const int flags = skip_empty & 1;
-  switch (rb * 16 + cb) {
-#define DBCSR_MID_CASE(A_, B_)                                                                                                                          \
-  case A_ * 16 + B_:                                                                                                                                    \
-    hipLaunchKernelGGL((mm_numeric_f64_mid<A_, B_, 8>), dim3(npos), dim3(64), lds, st, descs, nblk, entries, a_data, b_data, c_out, c_in, alpha, beta, flags, order); \
-    break;
-    DBCSR_MID_CASE(9, 9) DBCSR_MID_CASE(9, 10) DBCSR_MID_CASE(10, 9) DBCSR_MID_CASE(10, 10)
-#undef DBCSR_MID_CASE
-    default: return false;
-  }
-  if ((rb != 10 || cb != 10) && other_sizes)
-    hipLaunchKernelGGL((mm_numeric_f64_mid<10, 10, 8>), dim3(npos), dim3(64), lds, st, descs, nblk, entries, a_data, b_data, c_out, c_in, alpha, beta,
-                       flags | 16 | (rb << 8) | (cb << 12), order);
-  return true;
 }
 
 struct Engine {
@@ -1282,6 +1259,18 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
   // in-place accumulation (Cannon ticks after the first): C blocks without products in this call are left untouched
   const int skip_empty = (c_out->data == c_in->data && E->retain && beta == 1.0) ? 1 : 0;
   // launch-order work records for the exact-size fp64 kernels (one wave per C block): descriptor + first product in one read
+  // the one-wave slab kernel (mm_numeric_f64_mid.h): fp64 C blocks whose dominant (else largest) size has a dimension of 33 ... 40 and the other of
+  // 21 ... 40 (mid_f64_serves), any inner dimension; its second launch takes the blocks of another size.  Mixed-size multiplies (cls_mode) ask per class below.
+  int mid_rb = 0, mid_cb = 0;
+  if (datatype == dbcsr_type_real_8 && E->use_big && E->use_mid && E->use_lds && !E->cls_mode && E->max_m <= 40 && E->max_n <= 40 && E->min_m >= 1 &&
+      E->min_n >= 1 && E->min_k >= 1 && E->order_len > 0 && !(E->dbg & ~32) && !E->dma_stages && !E->hot_persistent && E->hot_variant == 0 && E->use_hot &&
+      E->use_pipe != 1) {
+    // (without a dominant size -- the size statistics stop at 32 -- the largest size is multiplied exactly when the blocks go beyond 32, where the
+    // alternative is the workgroup kernel, or when every block is in the range: the second launch pads the others to 40 x 40)
+    const bool dom = E->hot_m > 0 && E->hot_n > 0, all_in = (E->min_m > 24 && E->min_n > 24) || E->max_m > 32 || E->max_n > 32;
+    const int ur = dom ? (E->hot_m + 3) / 4 : (all_in ? (E->max_m + 3) / 4 : 0), uc = dom ? (E->hot_n + 3) / 4 : (all_in ? (E->max_n + 3) / 4 : 0);
+    if (mid_f64_serves(ur, uc, 0)) mid_rb = ur, mid_cb = uc;
+  }
   const Work* hot_work = nullptr;
   {
     const bool small64 = datatype == dbcsr_type_real_8 && E->use_lds && E->max_m <= 32 && E->max_k <= 32 && E->max_n <= 32 && E->min_m >= 1 &&
@@ -1290,7 +1279,7 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
     const bool exact = E->cls_mode ? (E->class_g == 1 && E->use_work)
                                    : (E->use_hot && E->use_pipe != 1 && E->hot_m > 0 && E->dma_stages == 0 && E->hot_m == E->hot_n && E->hot_m == E->hot_k);
     const int64_t npos = 8 * E->order_len;
-    if (small64 && exact && npos > 0) {
+    if (((small64 && exact) || mid_rb) && npos > 0) {
       if (!(reuse && E->work_built)) {
         if (E->work.ensure((size_t)npos + 1)) return -1;
         hipLaunchKernelGGL(build_work, grid_for(npos), dim3(256), 0, st, E->order.p, npos, E->descs.p, nblk, E->entries.p, E->work.p);
@@ -1325,6 +1314,13 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
         auto tiny = E->max_k > 4 ? mm_numeric_f64_tiny<false> : mm_numeric_f64_tiny<true>;
         hipLaunchKernelGGL(tiny, dim3(nwg_t), dim3(256), 0, st, E->descs.p, nblk, E->entries.p, ad, bd, cd, cid, alpha, beta, skip_empty, E->order.p);
       }
+    } else if (mid_rb && launch_mid_f64(mid_rb, mid_cb, E->min_m != E->max_m || E->min_n != E->max_n, (unsigned)(8 * E->order_len), st, E->descs.p, nblk,
+                                         E->entries.p, static_cast<const double*>(a->data), static_cast<const double*>(b->data),
+                                         static_cast<double*>(c_out->data), static_cast<const double*>(c_in->data), alpha, beta, skip_empty, E->order.p,
+                                         hot_work)) {
+      // blocks of 25 ... 40 in both dimensions: one wave per C block, operands in slabs (mm_numeric_f64_mid.h); the dominant size (else the largest)
+      // multiplied exactly, the blocks of another size by the second launch.  (It leaves no block norms: a filtered multiply computes them.)
+      snprintf(E->last_kernel, sizeof E->last_kernel, "mm_numeric_f64_mid<%d,%d>", mid_rb, mid_cb);
     } else if (small && E->use_lds && E->cls_mode) {
       // one launch per (m, n) class on its segment of order[]: the run-time compiled exact-size kernel of the class
       // (mm_exact.h, mm_jit.hip), the generic LDS kernel for class 9 (other sizes) and for classes hiprtc could not serve
@@ -1332,7 +1328,7 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
       const int g_lds_wave = g_lds_a + g_lds_b;
       const int g_maxt = (std::max(E->max_m, E->max_n) + 7) / 8;
       const int dbgv = E->dbg | (skip_empty ? 32 : 0);
-      int njit = 0, ngen = 0, jit_mask = 0;
+      int njit = 0, ngen = 0, nmid = 0, jit_mask = 0;
       const hipStream_t st_main = st;
       int nside = 0, nlaunch = 0;
       if (E->class_streams > 1) {
@@ -1357,7 +1353,14 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
         const unsigned nwg_c = (unsigned)(8 * E->cls_len[c] / 4);
         ClassKernel ck;
         const int cm = c < 9 ? E->cls_m[c / 3] : 0, cn = c < 9 ? E->cls_n[c % 3] : 0;
-        if (c < 9 && cm > 0 && cn > 0 && jit_class_kernel(cm, cn, E->cls_k[0], E->cls_k[1], E->cls_k[2], E->class_g, &ck) == 0) {
+        // classes of 29 ... 32 rows and columns, or 21 ... 24 in one of them (DBCSR_AMD_MM_MID=3: not those): the one-wave slab kernel -- half the LDS of
+        // the class kernel, which stages whole blocks (17.9 KB per wave for (32, 32), 15 KB for (32, 23): two waves per SIMD)
+        if (c < 9 && E->use_mid && E->use_big && E->class_g == 1 && mid_f64_serves((cm + 3) / 4, (cn + 3) / 4, E->use_mid == 3 ? 3 : 1) &&
+            launch_mid_f64((cm + 3) / 4, (cn + 3) / 4, false, (unsigned)(8 * E->cls_len[c]), st, E->descs.p, nblk, E->entries.p,
+                           static_cast<const double*>(a->data), static_cast<const double*>(b->data), static_cast<double*>(c_out->data),
+                           static_cast<const double*>(c_in->data), alpha, beta, skip_empty, ord, hot_work ? hot_work + E->cls_off[c] : nullptr)) {
+          ++nmid;
+        } else if (c < 9 && cm > 0 && cn > 0 && jit_class_kernel(cm, cn, E->cls_k[0], E->cls_k[1], E->cls_k[2], E->class_g, &ck) == 0) {
           const Desc* p_descs = E->descs.p;
           long p_nblk = (long)nblk;
           const Entry* p_entries = E->entries.p;
@@ -1405,6 +1408,10 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
         E->norms_data = c_out->data;
         E->norms_nblks = nblk;
       }
+      if (nmid > 0)
+        snprintf(E->last_kernel, sizeof E->last_kernel, "mm_numeric_f64_class[%d jit + %d slab + %d generic launches; m {%d,%d,%d} n {%d,%d,%d} k {%d,%d,%d}]",
+                 njit, nmid, ngen, E->cls_m[0], E->cls_m[1], E->cls_m[2], E->cls_n[0], E->cls_n[1], E->cls_n[2], E->cls_k[0], E->cls_k[1], E->cls_k[2]);
+      else
       snprintf(E->last_kernel, sizeof E->last_kernel, "mm_numeric_f64_class[%d jit + %d generic launches; m {%d,%d,%d} n {%d,%d,%d} k {%d,%d,%d}]", njit,
                ngen, E->cls_m[0], E->cls_m[1], E->cls_m[2], E->cls_n[0], E->cls_n[1], E->cls_n[2], E->cls_k[0], E->cls_k[1], E->cls_k[2]);
     } else if (small && E->use_lds) {
@@ -1412,7 +1419,14 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
       // start right after A's (zero-padded) block -- the tail of A's last chunk is simply overwritten by B's first chunk
       // (one wave, in-order LDS queue) -- and only B's part is rounded up to whole chunks.  For 23x23 blocks this is
       // 9.5 KB per wave instead of 10 KB, which is what lets a 4th workgroup (16 waves) fit the CU's 160 KB.
-      const int lds_a = (E->max_m * ((E->max_k + 3) & ~3) + 1) & ~1, lds_b = ((E->max_k * E->max_n + 127) / 128) * 128;
+      int lds_a = (E->max_m * ((E->max_k + 3) & ~3) + 1) & ~1, lds_b = ((E->max_k * E->max_n + 127) / 128) * 128;
+      if (E->hot_m > 0 && E->hot_m == E->hot_n && E->hot_m == E->hot_k && E->hot_m % 16 == 0) {
+        // the exact-size kernel stages columns of 16 / 32 doubles with a pitch of + 2 (mm_numeric_f64.h: cblock_f64_exact): its A image has hot_m + 2
+        // rows per column, its B image 16 more bytes per column (128 per KiB piece at most)
+        const int S = E->hot_m, cb = (S * S * 8 + 1023) / 1024;
+        lds_a = std::max(lds_a, (S + 2) * S);
+        lds_b = std::max(lds_b, cb * (1024 + 128) / 8 + 2);
+      }
       const int lds_wave = lds_a + lds_b;
       const int maxt = (std::max(E->max_m, E->max_n) + 7) / 8;
       const size_t lds_bytes = (size_t)4 * lds_wave * sizeof(double) + (size_t)E->lds_pad;
@@ -1539,15 +1553,6 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
       }
       }
 #undef DBCSR_LAUNCH
-    } else if (E->use_big && E->use_mid && E->use_lds && E->max_m <= 40 && E->max_n <= 40 && E->max_m > 32 && E->max_n > 32 && E->min_m >= 1 && E->min_n >= 1 &&
-               E->min_k >= 1 && !E->cls_mode && E->order_len > 0 &&
-               launch_mid_f64(((E->hot_m > 32 ? E->hot_m : E->max_m) + 3) / 4, ((E->hot_n > 32 ? E->hot_n : E->max_n) + 3) / 4,
-                              E->min_m != E->max_m || E->min_n != E->max_n, (unsigned)(8 * E->order_len), st, E->descs.p, nblk, E->entries.p,
-                              static_cast<const double*>(a->data), static_cast<const double*>(b->data), static_cast<double*>(c_out->data),
-                              static_cast<const double*>(c_in->data), alpha, beta, skip_empty, E->order.p)) {
-      // blocks of 33 ... 40 in both dimensions: one wave per C block (mm_numeric_f64_mid.h), the dominant size (else the largest) multiplied exactly
-      snprintf(E->last_kernel, sizeof E->last_kernel, "mm_numeric_f64_mid<%d,%d>", ((E->hot_m > 32 ? E->hot_m : E->max_m) + 3) / 4,
-               ((E->hot_n > 32 ? E->hot_n : E->max_n) + 3) / 4);
     } else if (E->use_big && E->use_lds && E->max_m <= 80 && E->max_n <= 80 && E->min_m >= 1 && E->min_n >= 1 && E->min_k >= 1 && !E->cls_mode &&
                E->order_len > 0 && (E->max_m > 32 || E->max_n > 32 || ((E->max_m + 7) / 8) * ((E->max_n + 7) / 8) >= 4) &&
                launch_big_f64(std::max(2, ((E->max_m + 7) / 8 + 1) / 2), std::max(2, ((E->max_n + 7) / 8 + 1) / 2), (unsigned)(8 * E->order_len), st,

@@ -190,6 +190,12 @@ __device__ __forceinline__ void cblock_f64_exact(const Desc& d, const Entry firs
   const int dbg = VAR == 1 ? dbg_rt : 0;
   constexpr int MA = (M + 7) / 8, NC = (N + 7) / 8, KS = (K + 3) / 4, K4 = 4 * KS;
   constexpr int CA = (M * K4 * 8 + 1023) / 1024, CB = (K * N * 8 + 1023) / 1024;
+  // Columns of 16 or 32 doubles are staged with a pitch of + 2 doubles (round 6; the run-time compiled class kernels have had it since round 2,
+  // mm_exact.h: Pitch): with a column stride of 128 or 256 bytes the 8 columns of a B fragment read -- and the k index of an A fragment read -- all
+  // fall into the same LDS banks.  Measured on 32^3 blocks (profiles/r06_slab_kernel.txt): hot<32,32,32> 25.0 ms where hot<30,30,30> scales to 15.1.
+  constexpr int APAD = (M % 16 == 0) ? 2 : 0, BPAD = (K % 16 == 0) ? 2 : 0, AP = M + APAD, BP = K + BPAD;
+  static_assert(APAD == 0 || 128 % M == 0, "a padded column must not straddle two lanes' 16-byte granules");
+  static_assert(BPAD == 0 || 128 % K == 0, "a padded column must not straddle two lanes' 16-byte granules");
   double acc[MA][NC];
 #pragma unroll
   for (int a = 0; a < MA; ++a)
@@ -199,6 +205,9 @@ __device__ __forceinline__ void cblock_f64_exact(const Desc& d, const Entry firs
   const int cnt = d.prod_cnt;
   u32x4 ra[CA], rb[CB];
   const int voff = lane * 16;
+  // byte offset in the staged image of the 16-byte granule this lane carries of piece c: (with padding) 16 bytes more per column before it
+  auto soff_a = [&](int c) { return c * 1024 + voff + (APAD ? 8 * APAD * ((c * 128 + lane * 2) / M) : 0); };
+  auto soff_b = [&](int c) { return c * 1024 + voff + (BPAD ? 8 * BPAD * ((c * 128 + lane * 2) / K) : 0); };
   unsigned touch = 0;  // VAR 3 / 4: the dwords of the keep-alive loads, folded so that each is waited for one product later
   // fragment addresses: constant for the whole life of the wave
   const double* pa[MA];
@@ -208,15 +217,15 @@ __device__ __forceinline__ void cblock_f64_exact(const Desc& d, const Entry firs
   for (int a = 0; a < MA; ++a) {
     int row = 8 * a + L.rowl;
     row = row < M ? row : M - 1;
-    pa[a] = reinterpret_cast<const double*>(lds_a) + row + M * L.kq;
+    pa[a] = reinterpret_cast<const double*>(lds_a) + row + AP * L.kq;
   }
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     int col = 8 * c + L.coll;
     col = col < N ? col : N - 1;
-    pb[c] = reinterpret_cast<const double*>(lds_b) + L.kq + K * col;
+    pb[c] = reinterpret_cast<const double*>(lds_b) + L.kq + BP * col;
     const int kt = 4 * (KS - 1) + L.kq;
-    pbt[c] = reinterpret_cast<const double*>(lds_b) + (kt < K ? kt : 0) + K * col;
+    pbt[c] = reinterpret_cast<const double*>(lds_b) + (kt < K ? kt : 0) + BP * col;
   }
   auto issue = [&](uint64_t a_off, uint64_t b_off_in) {
     if (dbg & 1) return;
@@ -258,10 +267,10 @@ __device__ __forceinline__ void cblock_f64_exact(const Desc& d, const Entry firs
   while (i0 < cnt) {
     if (!(dbg & 4)) {
 #pragma unroll
-      for (int c = 0; c < CA; ++c) *reinterpret_cast<u32x4*>(lds_a + c * 1024 + voff) = ra[c];
+      for (int c = 0; c < CA; ++c) *reinterpret_cast<u32x4*>(lds_a + soff_a(c)) = ra[c];
       DBCSR_AMD_LDS_ORDER();
 #pragma unroll
-      for (int c = 0; c < CB; ++c) *reinterpret_cast<u32x4*>(lds_b + c * 1024 + voff) = rb[c];
+      for (int c = 0; c < CB; ++c) *reinterpret_cast<u32x4*>(lds_b + soff_b(c)) = rb[c];
     }
     while (i1 < cnt && e1.ks() != K) {
       ++i1;
@@ -279,9 +288,9 @@ __device__ __forceinline__ void cblock_f64_exact(const Desc& d, const Entry firs
 #pragma unroll
       for (int a = 0; a < MA; ++a) {
         if constexpr (VAR == 2 || VAR == 6)
-          av[a] = *(lds_vd*)(pa[a] + s * 4 * M);
+          av[a] = *(lds_vd*)(pa[a] + s * 4 * AP);
         else
-          av[a] = pa[a][s * 4 * M];
+          av[a] = pa[a][s * 4 * AP];
       }
 #pragma unroll
       for (int c = 0; c < NC; ++c) {

@@ -138,18 +138,29 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) mm
                                                           const Entry* __restrict__ entries, const double* __restrict__ a_data,
                                                           const double* __restrict__ b_data, double* __restrict__ c_out,
                                                           const double* __restrict__ c_in, double alpha, double beta, int flags,
-                                                          const int* __restrict__ order) {
+                                                          const int* __restrict__ order, const Work* __restrict__ work) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // rounds of the slab copies: A -- the wave moves 1 KiB per round; B -- a lane moves two k of a column: 128 / KSL columns per round
-  constexpr int TM = 5, TN = 5;   // pairs of 4 x 4 blocks per dimension the LDS slice is sized for
+  constexpr int TM = (RBX + 1) / 2, TN = (CBX + 1) / 2;   // pairs of 4 x 4 blocks per dimension the LDS slice is sized for
   constexpr int MID_PB = MID_KSL + 4, KL = MID_KSL / 2, CPR = 64 / KL;
   constexpr int ABYTES = mid_a_bytes(TM, MID_KSL);
   constexpr int RA = (ABYTES + 1023) / 1024, RB_ = (8 * TN + CPR - 1) / CPR;
   const int lane = threadIdx.x;
   const int pos = xcd_remap(blockIdx.x, gridDim.x);
-  const int64_t cb = order[pos];
-  if (cb < 0 || cb >= nblk) return;
-  const Desc d = descs[cb];
+  Desc d;
+  uint32_t fa_lo = 0, fb_lo = 0, fw = 1;   // the block's first product, when the launch-order record carried it
+  bool have_first = false;
+  if (work) {   // launch-order records (build_work): descriptor and first product in one read -- no order[] -> descs[] -> entries[] chain
+    const Work w = work[pos];
+    if (w.prod_cnt < 0) return;  // padding position
+    d.c_off = w.c_off, d.cin_off = w.cin_off, d.prod_start = w.prod_start, d.prod_cnt = w.prod_cnt, d.m = w.m, d.n = w.n;
+    fa_lo = w.a_lo, fb_lo = w.b_lo, fw = w.w;
+    have_first = w.prod_cnt > 0;
+  } else {
+    const int64_t cb = order[pos];
+    if (cb < 0 || cb >= nblk) return;
+    d = descs[cb];
+  }
   if ((flags & 1) && d.prod_cnt == 0) return;
   const int m = __builtin_amdgcn_readfirstlane((int)d.m), n = __builtin_amdgcn_readfirstlane((int)d.n), cnt = __builtin_amdgcn_readfirstlane(d.prod_cnt);
   const int own_r = (m + 3) >> 2, own_c = (n + 3) >> 2;   // the block in units of 4 x 4
@@ -198,14 +209,18 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) mm
   };
   int p = 0, k0 = 0;
   uint32_t ea = 0, eb = 0, ew = 1, na = 0, nb = 0, nw = 1;   // the current product and the one after it (plain scalars: a struct handed to the lambda lands in scratch)
-  if (cnt > 0) ea = e[0].a_lo, eb = e[0].b_lo, ew = e[0].w;
-  {
-    const int i1 = cnt > 1 ? 1 : 0;
-    if (cnt > 0) na = e[i1].a_lo, nb = e[i1].b_lo, nw = e[i1].w;
-  }
+  if (have_first)
+    ea = fa_lo, eb = fb_lo, ew = fw;
+  else if (cnt > 0)
+    ea = e[0].a_lo, eb = e[0].b_lo, ew = e[0].w;
+  ea = (uint32_t)__builtin_amdgcn_readfirstlane((int)ea), eb = (uint32_t)__builtin_amdgcn_readfirstlane((int)eb), ew = (uint32_t)__builtin_amdgcn_readfirstlane((int)ew);
   auto a_of = [](uint32_t lo, uint32_t w) { return (uint64_t)lo | ((uint64_t)((w >> 16) & 0xffu) << 32); };
   auto b_of = [](uint32_t lo, uint32_t w) { return (uint64_t)lo | ((uint64_t)(w >> 24) << 32); };
   if (cnt > 0) issue(a_of(ea, ew), b_of(eb, ew), (int)(ew & 0xffffu), 0);
+  {   // (the second product's record: requested after the first operands are on their way)
+    const int i1 = cnt > 1 ? 1 : 0;
+    if (cnt > 0) na = e[i1].a_lo, nb = e[i1].b_lo, nw = e[i1].w;
+  }
   // (a block smaller than RBX x CBX units -- only under <10, 10> -- multiplies a few blocks of 4 x 4 nobody stores)
   {
     typedef BigSub<RBX, CBX> Sub;
@@ -243,16 +258,47 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) mm
       p = p2;
       k0 = k2;
     }
-    double* C = c_out + d.c_off;
-    const bool has_in = d.cin_off >= 0;
-    const double* Ci = c_in + (has_in ? d.cin_off : 0);
-    S.drain(lane, own_r, own_c, [&](int row, int col, double sum) {
-      if (row < m && col < n) {
-        double v = alpha * sum;
-        if (has_in) v += beta * Ci[row + (size_t)m * col];
-        C[row + (size_t)m * col] = v;
+    if constexpr (RBX <= 8 && CBX <= 8) {
+      // C epilogue through LDS (as the exact-size kernels, mm_numeric_f64.h): the block is laid out as stored (column-major, contiguous) in the wave's
+      // slice -- up to 32 x 32: it fits the slabs' 9 KB -- and leaves in whole 1 KiB pieces, 16 bytes per lane, with the streaming hint.  These shapes
+      // are the classes of a mixed-size multiply with FEW products per C block (config 3: 3.6), where C's traffic counts: 7.25 against 7.6 ms there.
+      double* lds_c = reinterpret_cast<double*>(smem);
+      S.drain(lane, own_r, own_c, [&](int row, int col, double sum) {
+        if (row < m && col < n) lds_c[row + m * col] = alpha * sum;
+      });
+      const bool has_in = d.cin_off >= 0;
+      const int cbytes = m * n * 8;
+      const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc((void*)(c_out + d.c_off), 0, cbytes, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rsi = __builtin_amdgcn_make_buffer_rsrc((void*)(c_in + (has_in ? d.cin_off : 0)), 0, has_in ? cbytes : 0, 0x00020000);
+      typedef double f64x2 __attribute__((ext_vector_type(2)));
+      constexpr int CC = (8 * TM * 8 * TN * 8 + 1023) / 1024;
+      static_assert(CC * 1024 <= mid_lds_bytes(TM, TN, MID_KSL), "the C block must fit the wave's slice");
+#pragma unroll
+      for (int c = 0; c < CC; ++c) {
+        if (c * 1024 < cbytes) {   // (wave-uniform)
+          f64x2 v = *reinterpret_cast<const f64x2*>(smem + c * 1024 + lane * 16);
+          if (has_in) {
+            const f64x2 w = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(rsi, lane * 16, c * 1024, 0));
+            v[0] += beta * w[0];
+            v[1] += beta * w[1];
+          }
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsc, lane * 16, c * 1024, 2);
+        }
       }
-    });
+    } else {
+      // beyond 32: C leaves straight from the accumulators, 8-byte stores, 4 rows x 8 columns of the block per instruction.  (Measured, session r06_14:
+      // the epilogue above needs a 12.8 KB slice for 40 x 40 and was 3-5 % SLOWER at 20 products per C block: 40^3 8.5 against 8.2 ms.)
+      double* C = c_out + d.c_off;
+      const bool has_in = d.cin_off >= 0;
+      const double* Ci = c_in + (has_in ? d.cin_off : 0);
+      S.drain(lane, own_r, own_c, [&](int row, int col, double sum) {
+        if (row < m && col < n) {
+          double v = alpha * sum;
+          if (has_in) v += beta * Ci[row + (size_t)m * col];
+          C[row + (size_t)m * col] = v;
+        }
+      });
+    }
   }
 }
 

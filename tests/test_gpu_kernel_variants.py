@@ -65,7 +65,11 @@ VARIANTS = [
     ({"DBCSR_AMD_MM_CLASSES": "2"}, H2O, "mm_numeric_f64_class["),
     ({"DBCSR_AMD_MM_CLASSES": "2"}, CONFIG3, "mm_numeric_f64_class["),
     ({"DBCSR_AMD_MM_CLASSES": "2"}, POW2, "mm_numeric_f64_class["),
-    ({"DBCSR_AMD_MM_CLASSES": "2"}, CONFIG3_37, "mm_numeric_f64_class[9 jit + 1 generic"),
+    # (round 6: the classes (32, 32), (32, 23), (23, 32) take the one-wave slab kernels mm_numeric_f64_mid<8,8> / <8,6> / <6,8>; DBCSR_AMD_MM_MID=0: all
+    # nine through the class kernels; DBCSR_AMD_MM_MID=3: only (32, 32) through the slab kernel)
+    ({"DBCSR_AMD_MM_CLASSES": "2"}, CONFIG3_37, "mm_numeric_f64_class[6 jit + 3 slab + 1 generic"),
+    ({"DBCSR_AMD_MM_CLASSES": "2", "DBCSR_AMD_MM_MID": "0"}, CONFIG3_37, "mm_numeric_f64_class[9 jit + 1 generic"),
+    ({"DBCSR_AMD_MM_CLASSES": "2", "DBCSR_AMD_MM_MID": "3"}, CONFIG3_37, "mm_numeric_f64_class[8 jit + 1 slab + 1 generic"),
     ({"DBCSR_AMD_MM_CLASSES": "0"}, CONFIG3_37, "mm_numeric_f64_pipe<4>"),
     # the class kernels with a wave walking 8 / 4 consecutive C blocks of its class (product pipeline across block boundaries)
     ({"DBCSR_AMD_MM_CLASSES": "2", "DBCSR_AMD_MM_CLASS_G": "8"}, CONFIG3_37, "mm_numeric_f64_class[9 jit + 1 generic"),
@@ -78,14 +82,14 @@ VARIANTS = [
     ({"DBCSR_AMD_MM_WG_WAVES": "1"}, H2O, "mm_numeric_f64_hot<23,23,23>"),
     ({"DBCSR_AMD_MM_WG_WAVES": "1", "DBCSR_AMD_MM_KERNEL": "lds1", "DBCSR_AMD_MM_HOT": "0"}, MIXED, "mm_numeric_f64_lds"),
     ({"DBCSR_AMD_MM_WG_WAVES": "4", "DBCSR_AMD_MM_KERNEL": "lds1", "DBCSR_AMD_MM_HOT": "0"}, MIXED, "mm_numeric_f64_lds"),
-    ({"DBCSR_AMD_MM_WG_WAVES": "4", "DBCSR_AMD_MM_CLASSES": "2"}, CONFIG3_37, "mm_numeric_f64_class[9 jit + 1 generic"),
+    ({"DBCSR_AMD_MM_WG_WAVES": "4", "DBCSR_AMD_MM_CLASSES": "2"}, CONFIG3_37, "mm_numeric_f64_class[6 jit + 3 slab + 1 generic"),
     ({"DBCSR_AMD_MM_WG_WAVES": "2", "DBCSR_AMD_MM_CLASSES": "2"}, MIXED, "mm_numeric_f64_class["),
     # without the launch-order work records (the default has them): order[] -> descs[] -> entries[]
     ({"DBCSR_AMD_MM_WORK": "0"}, H2O, "mm_numeric_f64_hot<23,23,23>"),
-    ({"DBCSR_AMD_MM_WORK": "0", "DBCSR_AMD_MM_CLASSES": "2"}, CONFIG3_37, "mm_numeric_f64_class[9 jit + 1 generic"),
+    ({"DBCSR_AMD_MM_WORK": "0", "DBCSR_AMD_MM_CLASSES": "2"}, CONFIG3_37, "mm_numeric_f64_class[6 jit + 3 slab + 1 generic"),
     ({"DBCSR_AMD_MM_WORK": "0", "DBCSR_AMD_MM_CLASSES": "2"}, MIXED, "mm_numeric_f64_class["),
     # the class launches of one multiply spread over several streams
-    ({"DBCSR_AMD_MM_CLASS_STREAMS": "3", "DBCSR_AMD_MM_CLASSES": "2"}, CONFIG3_37, "mm_numeric_f64_class[9 jit + 1 generic"),
+    ({"DBCSR_AMD_MM_CLASS_STREAMS": "3", "DBCSR_AMD_MM_CLASSES": "2"}, CONFIG3_37, "mm_numeric_f64_class[6 jit + 3 slab + 1 generic"),
     ({"DBCSR_AMD_MM_CLASS_STREAMS": "4", "DBCSR_AMD_MM_CLASSES": "2"}, MIXED, "mm_numeric_f64_class["),
 ]
 
@@ -95,7 +99,7 @@ LAB_SWITCHES = ("DBCSR_AMD_MM_HOT_VARIANT", "DBCSR_AMD_MM_HOT_PERSISTENT", "DBCS
 
 
 def run_case(monkeypatch, env, case, dtype, tol, expect, alpha=0.7, beta=1.3, retain=False, in_place_twice=False):
-    for k in ("DBCSR_AMD_MM_KERNEL", "DBCSR_AMD_MM_HOT", "DBCSR_AMD_MM_TINY", "DBCSR_AMD_MM_PIPE_G", "DBCSR_AMD_MM_SYMBOLIC", "DBCSR_AMD_MM_CLASSES", "DBCSR_AMD_MM_CLASS_G", "DBCSR_AMD_MM_WORK", "DBCSR_AMD_MM_WG_WAVES", "DBCSR_AMD_MM_CLASS_STREAMS", "DBCSR_AMD_MM_HOT_VARIANT", "DBCSR_AMD_MM_HOT_PERSISTENT", "DBCSR_AMD_MM_HOT_XCDS", "DBCSR_AMD_MM_F32_DIRECT", "DBCSR_AMD_MM_BIG"):
+    for k in ("DBCSR_AMD_MM_KERNEL", "DBCSR_AMD_MM_HOT", "DBCSR_AMD_MM_TINY", "DBCSR_AMD_MM_PIPE_G", "DBCSR_AMD_MM_SYMBOLIC", "DBCSR_AMD_MM_CLASSES", "DBCSR_AMD_MM_CLASS_G", "DBCSR_AMD_MM_WORK", "DBCSR_AMD_MM_WG_WAVES", "DBCSR_AMD_MM_CLASS_STREAMS", "DBCSR_AMD_MM_HOT_VARIANT", "DBCSR_AMD_MM_HOT_PERSISTENT", "DBCSR_AMD_MM_HOT_XCDS", "DBCSR_AMD_MM_F32_DIRECT", "DBCSR_AMD_MM_BIG", "DBCSR_AMD_MM_MID"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
