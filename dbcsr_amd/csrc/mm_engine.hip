@@ -646,11 +646,11 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
       // (one wave, in-order LDS queue) -- and only B's part is rounded up to whole chunks.  For 23x23 blocks this is
       // 9.5 KB per wave instead of 10 KB, which is what lets a 4th workgroup (16 waves) fit the CU's 160 KB.
       int lds_a = (E->max_m * ((E->max_k + 3) & ~3) + 1) & ~1, lds_b = ((E->max_k * E->max_n + 127) / 128) * 128;
-      if (E->hot_m > 0 && E->hot_m == E->hot_n && E->hot_m == E->hot_k && E->hot_m % 16 == 0) {
-        // the exact-size kernel stages columns of 16 / 32 doubles with a pitch of + 2 (mm_numeric_f64.h: cblock_f64_exact): its A image has hot_m + 2
-        // rows per column, its B image 16 more bytes per column (128 per KiB piece at most)
+      if (E->hot_m > 0 && E->hot_m == E->hot_n && E->hot_m == E->hot_k && E->hot_m % 8 == 0) {
+        // the exact-size kernel stages columns of 16 / 32 doubles (B: 24 too) with a pitch of + 2 (mm_numeric_f64.h: cblock_f64_exact): its A image has
+        // hot_m + 2 rows per column, its B image 16 more bytes per column (128 per KiB piece at most)
         const int S = E->hot_m, cb = (S * S * 8 + 1023) / 1024;
-        lds_a = std::max(lds_a, (S + 2) * S);
+        if (S % 16 == 0) lds_a = std::max(lds_a, (S + 2) * S);
         lds_b = std::max(lds_b, cb * (1024 + 128) / 8 + 2);
       }
       const int lds_wave = lds_a + lds_b;

@@ -193,9 +193,12 @@ __device__ __forceinline__ void cblock_f64_exact(const Desc& d, const Entry firs
   // Columns of 16 or 32 doubles are staged with a pitch of + 2 doubles (round 6; the run-time compiled class kernels have had it since round 2,
   // mm_exact.h: Pitch): with a column stride of 128 or 256 bytes the 8 columns of a B fragment read -- and the k index of an A fragment read -- all
   // fall into the same LDS banks.  Measured on 32^3 blocks (profiles/r06_slab_kernel.txt): hot<32,32,32> 25.0 ms where hot<30,30,30> scales to 15.1.
-  constexpr int APAD = (M % 16 == 0) ? 2 : 0, BPAD = (K % 16 == 0) ? 2 : 0, AP = M + APAD, BP = K + BPAD;
-  static_assert(APAD == 0 || 128 % M == 0, "a padded column must not straddle two lanes' 16-byte granules");
-  static_assert(BPAD == 0 || 128 % K == 0, "a padded column must not straddle two lanes' 16-byte granules");
+  // (B columns of 24 doubles too: a stride of 192 bytes leaves 4 distinct bank groups for 8 columns, 2-way conflicts)
+  // (23 x 23: columns of 46 dwords leave one pair of banks shared by two of the eight columns of a B fragment read; reading at a conflict-free pitch of
+  // 25 -- timing only, session r06_20 -- gave 19.20 -> 19.04 ms on config 2: not worth staging B in 8-byte granules)
+  constexpr int APAD = (M % 16 == 0) ? 2 : 0, BPAD = (K % 8 == 0) ? 2 : 0, AP = M + APAD, BP = K + BPAD;
+  static_assert(APAD == 0 || M % 2 == 0, "a lane's 16-byte granule (two doubles) must not straddle two padded columns");
+  static_assert(BPAD == 0 || K % 2 == 0, "a lane's 16-byte granule (two doubles) must not straddle two padded columns");
   double acc[MA][NC];
 #pragma unroll
   for (int a = 0; a < MA; ++a)
