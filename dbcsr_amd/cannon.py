@@ -32,6 +32,12 @@ Three schedules are offered:
     chunks, and chunk q of C is multiplied as soon as chunk q of B is complete while chunk q + 1 is on the links.
     Every C block is written once (the chunks land in slices of one buffer under a merged index), the exposed
     transfer is one chunk of one image per link, and odd chunks are multiplied on a second stream.
+  * ``mode="colpipe2d"`` (round 6; chosen at construction): the same pipeline on the 2-D grid of the other schedules
+    (``MPI_Dims_create``: 4 x 2 for eight ranks -- the redistribution the reference's Cannon loop uses,
+    dbcsr_mm_cannon.F:1376-1463, 1497-1586).  The A images a rank misses (its process row's) come with the first batch;
+    the B images of its process column travel in column chunks of its OWN block columns and chunk q of its C tile is
+    multiplied when chunk q of every image has landed.  Per link the same bytes as on the N x 1 grid (one image per
+    peer), in total fewer (a rank needs its row panel of A and its column panel of B, not all of B).
 
 The local engine is duck-typed (``symbolic``, ``init_c``, ``accumulate``,
 ``fill_random_dist`` of dbcsr_amd.multiply.MultiplyEngine) so that the
@@ -336,7 +342,8 @@ class CannonMultiply:
         # mode "colpipe": world x 1 grid -- every rank keeps its block rows of A and of C and needs ALL of B, which then travels over
         # all links at once, in column chunks that are multiplied as they arrive (see _multiply_colpipe)
         self.grid = grid or (Grid(world, rank, nprows=world, npcols=1) if mode == "colpipe" else Grid(world, rank))
-        self._col_chunks = max(1, int(col_chunks)) if mode == "colpipe" else 0
+        # mode "colpipe2d": the same column-chunk pipeline on the default 2-D grid (the A images of the process row come with the first chunk)
+        self._col_chunks = max(1, int(col_chunks)) if mode in ("colpipe", "colpipe2d") else 0
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.dtype = dtype
         if engine is None:
@@ -949,9 +956,9 @@ class CannonMultiply:
                                                    filter_eps=filter_eps or 0.0)
             self._launched(self.eng, getattr(self.eng, "last_launch_flop", counts.flop))
             return Cout, counts
-        if self.mode == "colpipe":
+        if self.mode in ("colpipe", "colpipe2d"):
             if self._cbounds is None:
-                raise ValueError("CannonMultiply: mode 'colpipe' must be chosen at construction (the images are laid out for it)")
+                raise ValueError("CannonMultiply: mode '%s' must be chosen at construction (the images are laid out for it)" % self.mode)
             return self._multiply_colpipe(alpha, beta)
         if self.mode == "gather":
             return self._multiply_gather(alpha, beta)

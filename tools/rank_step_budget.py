@@ -24,7 +24,10 @@ def main():
     p.add_argument("--steps", type=int, default=10)
     p.add_argument("--colpipe", type=int, default=0, help="N x 1 grid and the colpipe schedule with this many column chunks (its whole compute path, "
                                                           "exchange left out): kernel_ms is then the SUM over the chunk multiplies")
+    p.add_argument("--colpipe2d", type=int, default=0, help="the same column-chunk pipeline on the default 2-D grid (round 6) with this many chunks")
     a = p.parse_args()
+    if a.colpipe2d:
+        a.colpipe = a.colpipe2d
     import bench
     from dbcsr_amd import cannon
     from dbcsr_amd.multiply import MultiplyEngine
@@ -34,9 +37,9 @@ def main():
     print("# ranks grid  C_blocks  products   GFLOP   wall_ms  kernel_ms  fill_ms  non_kernel_ms  kernel")
     for n in [int(x) for x in a.ranks.split(",")]:
         eng = MultiplyEngine()
-        g = cannon.Grid(n, 0, nprows=n, npcols=1) if a.colpipe else cannon.Grid(n, 0)
-        plan = cannon.CannonMultiply(M, N, K, (1 - fill,) * 3, mix, dtype=dtype, engine=eng, grid=g, mode="colpipe" if a.colpipe else "gather",
-                                     col_chunks=max(1, a.colpipe))
+        g = cannon.Grid(n, 0, nprows=n, npcols=1) if (a.colpipe and not a.colpipe2d) else cannon.Grid(n, 0)
+        plan = cannon.CannonMultiply(M, N, K, (1 - fill,) * 3, mix, dtype=dtype, engine=eng, grid=g,
+                                     mode="colpipe2d" if a.colpipe2d else ("colpipe" if a.colpipe else "gather"), col_chunks=max(1, a.colpipe))
         # images owned by other ranks: synthetic values in place (what would have arrived over xGMI)
         for buf in (plan._a_all, plan._b_all):
             buf.uniform_(0.0, 1.0)

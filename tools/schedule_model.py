@@ -8,16 +8,19 @@ multiply; colpipe's chunk multiplies), the one-GPU step.  Every image travels ov
    python tools/schedule_model.py [--link-gbs 50,64,76]"""
 import argparse
 
-# measured on one MI355X (profiles/r03_rank_step_budget_*.txt, r03_final_bench_line.json); ms
+# measured on one MI355X, one rank's share ALONE on the device (tools/rank_step_budget.py; round 6: gpurun_out/r06_s21 = profiles/r06_rank_step_budget.txt,
+# round 3 where the round-6 session's colpipe walls were disturbed by an outlier step: profiles/r03_rank_step_budget_*.txt); ms
 WORKLOADS = {
     "config2_32768_23x23_fill10_fp64": dict(
-        one_gpu=18.85, a_gb=0.859, b_gb=0.859, c_gb_per_rank={2: 4.3, 4: 2.15, 8: 1.07},
-        gather={2: 9.59, 4: 4.90, 8: 2.64},          # rank 0's whole multiply, default grid (2x1, 2x2, 4x2)
-        colpipe8={2: 10.28, 4: 5.38, 8: 2.94}),      # N x 1 grid, eight column chunks on two streams, panels in place
+        one_gpu=18.90, a_gb=0.859, b_gb=0.859, c_gb_per_rank={2: 4.3, 4: 2.15, 8: 1.07},
+        gather={2: 9.71, 4: 4.91, 8: 2.65},          # rank 0's whole multiply, default grid (2x1, 2x2, 4x2)
+        colpipe8={2: 10.28, 4: 5.38, 8: 2.92},       # N x 1 grid, eight column chunks on two streams, panels in place
+        colpipe2d={4: 5.35, 8: 2.82}),               # 2-D grid (2x2, 4x2), column chunks of the rank's own block columns (round 6)
     "config4_131072_23x23_fill1_fp64": dict(
-        one_gpu=22.74, a_gb=1.374, b_gb=1.374, c_gb_per_rank={2: 30.3, 4: 15.2, 8: 7.6},
-        gather={2: 11.22, 4: 5.73, 8: 3.04},
-        colpipe8={2: 11.39, 4: 5.84, 8: None}),      # (8 ranks: not measured cleanly, see profiles/r03_rank_step_budget_colpipe.txt)
+        one_gpu=22.35, a_gb=1.374, b_gb=1.374, c_gb_per_rank={2: 30.3, 4: 15.2, 8: 7.6},
+        gather={2: 11.13, 4: 5.69, 8: 2.96},
+        colpipe8={2: 11.31, 4: 5.75, 8: 3.10},
+        colpipe2d={4: 5.78, 8: 2.97}),
 }
 GRID = {2: (2, 1), 4: (2, 2), 8: (4, 2)}
 HBM_TBS = 5.0   # read + write of C in an in-place pass
@@ -40,6 +43,13 @@ def model(w, n, link):
         b_per_link = w["b_gb"] / n                                          # N x 1 grid: one k-image per rank, every image on its own link
         t_chunk = b_per_link / 8 / link * 1e3
         out["colpipe (8 chunks)"] = t_chunk + max(cp, 8 * t_chunk)
+    cp2 = w.get("colpipe2d", {}).get(n)
+    if cp2 is not None and pc > 1:
+        # 2-D grid: the A images a rank misses (its process row's: a_gb / n from each of the pc - 1 row peers, one link each) come with the first batch
+        # and are NOT chunked -- every column chunk needs the whole row panel of A --, then B's images of the process column in 8 column chunks
+        t_a = w["a_gb"] / n / link * 1e3
+        t_chunk = w["b_gb"] / n / 8 / link * 1e3
+        out["colpipe2d (8 chunks)"] = max(t_a, t_chunk) + max(cp2, 8 * t_chunk)
     return out
 
 
