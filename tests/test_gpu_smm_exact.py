@@ -93,3 +93,31 @@ def test_short_stacks_of_an_unseen_triplet_do_not_compile():
     rc, c = run_stack(stack, a, b, np.zeros(nc * m * n), m, n, k, L.dbcsr_type_real_8)
     assert rc >= 0 and last_kernel().startswith("smm_stack_f64_lds(11,12,10")
     assert np.array_equal(c, c_ref)
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("DBCSR_AMD_SWEEP_EXACT_STACKS", "24"))))
+def test_random_triplets_through_the_exact_kernel(seed):
+    """random (m, n, k) up to 32 (every one compiles its kernel: ~0.4 s), stacks of 256 ... 3000 entries sorted, binned or shuffled, B transposed or
+    as stored: integer-valued inputs, so the result must be EXACT whatever the summation order"""
+    rng = np.random.default_rng(4200 + seed)
+    m, n, k = (int(x) for x in rng.integers(1, 33, size=3))
+    while m * n * k < 512:
+        m, n, k = (int(x) for x in rng.integers(4, 33, size=3))
+    nstack = int(rng.choice([256, 257, 271, 1000, 1023, 3000]))
+    na, nb = int(rng.integers(1, 80)), int(rng.integers(1, 80))
+    nc = int(rng.integers(1, max(2, nstack // 8)))
+    a = O.mat_init(na, m, k, 42)
+    b = O.mat_init(nb, k, n, 24)
+    stack = O.stack_init(nstack, nc, na, nb, m, n, k, rseed=int(rng.integers(1, 1000)))
+    order = seed % 3
+    if order:   # 1: shuffled entries (runs of length one), 2: binned by c offset as the host does for small blocks
+        ent = np.asarray(stack, np.int32).reshape(-1, 3)
+        ent = ent[rng.permutation(len(ent))] if order == 1 else ent[np.argsort((ent[:, 2].astype(np.int64) * (ent[:, 2] + 3)) % 4096, kind="stable")]
+        stack = np.ascontiguousarray(ent.reshape(-1))
+    bt = bool(seed % 2)
+    c_ref = np.zeros(nc * m * n)
+    O.stack_calc(stack, c_ref, a, b, m, n, k, b_transposed=False)
+    rc, c = run_stack(stack, a, b, np.zeros(nc * m * n), m, n, k, L.dbcsr_type_real_8, max_kernel_dim=80 if bt else 0, transpose_b=bt)
+    assert rc >= 0
+    assert last_kernel().startswith("smm_stack_f64_exact<%d,%d,%d" % (m, n, k)), last_kernel()
+    assert np.array_equal(c, c_ref), (m, n, k, nstack, order, bt)
