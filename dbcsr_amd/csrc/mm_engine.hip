@@ -488,14 +488,14 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
   // the one-wave slab kernel (mm_numeric_f64_mid.h): fp64 C blocks whose dominant (else largest) size has a dimension of 33 ... 40 and the other of
   // 21 ... 40 (mid_f64_serves), any inner dimension; its second launch takes the blocks of another size.  Mixed-size multiplies (cls_mode) ask per class below.
   int mid_rb = 0, mid_cb = 0;
-  if (datatype == dbcsr_type_real_8 && E->use_big && E->use_mid && E->use_lds && !E->cls_mode && E->max_m <= 40 && E->max_n <= 40 && E->min_m >= 1 &&
+  if (datatype == dbcsr_type_real_8 && E->use_big && E->use_mid && E->use_lds && !E->cls_mode && E->max_m <= 48 && E->max_n <= 48 && E->min_m >= 1 &&
       E->min_n >= 1 && E->min_k >= 1 && E->order_len > 0 && !(E->dbg & ~32) && !E->dma_stages && !E->hot_persistent && E->hot_variant == 0 && E->use_hot &&
       E->use_pipe != 1) {
     // (without a dominant size -- the size statistics stop at 32 -- the largest size is multiplied exactly when the blocks go beyond 32, where the
     // alternative is the workgroup kernel, or when every block is in the range: the second launch pads the others to 40 x 40)
     const bool dom = E->hot_m > 0 && E->hot_n > 0, all_in = (E->min_m > 24 && E->min_n > 24) || E->max_m > 32 || E->max_n > 32;
-    const int ur = dom ? (E->hot_m + 3) / 4 : (all_in ? (E->max_m + 3) / 4 : 0), uc = dom ? (E->hot_n + 3) / 4 : (all_in ? (E->max_n + 3) / 4 : 0);
-    if (mid_f64_serves(ur, uc, 0)) mid_rb = ur, mid_cb = uc;
+    const int dm = dom ? E->hot_m : (all_in ? E->max_m : 0), dn = dom ? E->hot_n : (all_in ? E->max_n : 0);
+    if (dm > 0 && dn > 0 && mid_f64_serves(dm, dn, 0)) mid_rb = (dm + 3) / 4, mid_cb = (dn + 3) / 4;
   }
   const Work* hot_work = nullptr;
   {
@@ -543,7 +543,7 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
     } else if (mid_rb && launch_mid_f64(mid_rb, mid_cb, E->min_m != E->max_m || E->min_n != E->max_n, (unsigned)(8 * E->order_len), st, E->descs.p, nblk,
                                          E->entries.p, static_cast<const double*>(a->data), static_cast<const double*>(b->data),
                                          static_cast<double*>(c_out->data), static_cast<const double*>(c_in->data), alpha, beta, skip_empty, E->order.p,
-                                         hot_work)) {
+                                         hot_work, (std::max(E->max_m, E->max_n) + 3) / 4)) {
       // blocks of 25 ... 40 in both dimensions: one wave per C block, operands in slabs (mm_numeric_f64_mid.h); the dominant size (else the largest)
       // multiplied exactly, the blocks of another size by the second launch.  (It leaves no block norms: a filtered multiply computes them.)
       snprintf(E->last_kernel, sizeof E->last_kernel, "mm_numeric_f64_mid<%d,%d>", mid_rb, mid_cb);
@@ -581,10 +581,11 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
         const int cm = c < 9 ? E->cls_m[c / 3] : 0, cn = c < 9 ? E->cls_n[c % 3] : 0;
         // classes of 29 ... 32 rows and columns, or 21 ... 24 in one of them (DBCSR_AMD_MM_MID=3: not those): the one-wave slab kernel -- half the LDS of
         // the class kernel, which stages whole blocks (17.9 KB per wave for (32, 32), 15 KB for (32, 23): two waves per SIMD)
-        if (c < 9 && E->use_mid && E->use_big && E->class_g == 1 && mid_f64_serves((cm + 3) / 4, (cn + 3) / 4, E->use_mid == 3 ? 3 : 1) &&
+        if (c < 9 && E->use_mid && E->use_big && E->class_g == 1 && mid_f64_serves(cm, cn, E->use_mid == 3 ? 3 : 1) &&
             launch_mid_f64((cm + 3) / 4, (cn + 3) / 4, false, (unsigned)(8 * E->cls_len[c]), st, E->descs.p, nblk, E->entries.p,
                            static_cast<const double*>(a->data), static_cast<const double*>(b->data), static_cast<double*>(c_out->data),
-                           static_cast<const double*>(c_in->data), alpha, beta, skip_empty, ord, hot_work ? hot_work + E->cls_off[c] : nullptr)) {
+                           static_cast<const double*>(c_in->data), alpha, beta, skip_empty, ord, hot_work ? hot_work + E->cls_off[c] : nullptr,
+                           (std::max(cm, cn) + 3) / 4)) {
           ++nmid;
         } else if (c < 9 && cm > 0 && cn > 0 && jit_class_kernel(cm, cn, E->cls_k[0], E->cls_k[1], E->cls_k[2], E->class_g, &ck) == 0) {
           const Desc* p_descs = E->descs.p;

@@ -127,12 +127,13 @@ static inline constexpr int mid_lds_bytes(int TM, int TN, int KSL) {
   return ar > ab ? ar : ab;
 }
 
-// RBX x CBX: the C blocks this launch multiplies, in units of 4 x 4 (9 or 10 per dimension: 33 ... 40 rows / columns), exactly.  A multiply whose dominant
-// block is not 10 x 10 takes two launches over the same order[]: <RBX, CBX> for the dominant blocks, then <10, 10> -- which covers any block up to 40 x 40 --
+// RBX x CBX: the C blocks this launch multiplies, in units of 4 x 4 (6 ... 12 per dimension), exactly.  A multiply whose dominant block is not the
+// largest shape (10 x 10 up to 40, 12 x 12 up to 48) takes two launches over the same order[]: <RBX, CBX> for the dominant blocks, then the largest shape -- which covers any block of the multiply --
 // with bit 4 of `flags` for all the others (the matrix's tail row / column, other sizes of a mix); a wave that finds a block of the other launch leaves
 // after reading its descriptor.  (Two variants behind a wave-uniform branch in ONE kernel keep both register sets live side by side under LLVM's CFG
 // structurizer -- 169 registers where either needs 144 or fewer -- and nine variants spill.)
-// flags: bit 0: C blocks without products stay as they are (in-place accumulation); bit 4: skip the blocks of (bits 8-11) x (bits 12-15) units instead
+// flags: bit 0: C blocks without products stay as they are (in-place accumulation); bit 4: the launch for "all the others" -- skip the blocks of
+// (bits 8-11) x (bits 12-15) units; bit 5: the only launch -- take every block (the dominant size IS the largest shape); neither: blocks of RBX x CBX only
 template <int RBX, int CBX, int MID_KSL>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) mm_numeric_f64_mid(const Desc* __restrict__ descs, int64_t nblk,
                                                           const Entry* __restrict__ entries, const double* __restrict__ a_data,
@@ -166,8 +167,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) mm
   const int own_r = (m + 3) >> 2, own_c = (n + 3) >> 2;   // the block in units of 4 x 4
   if (flags & 16) {
     if (own_r == ((flags >> 8) & 15) && own_c == ((flags >> 12) & 15)) return;   // the exact launch multiplied it
-  } else if (RBX != 10 || CBX != 10) {
-    if (own_r != RBX || own_c != CBX) return;                                      // the <10, 10> launch multiplies it
+  } else if (!(flags & 32)) {
+    if (own_r != RBX || own_c != CBX) return;                                      // the other launch multiplies it
   }
   const Entry* e = entries + d.prod_start;
   // copy roles: A -- lane l moves bytes [1024 r + 16 l, + 16) of the slab; B -- lane l moves k = 2 (l mod KL), + 1 of column CPR r + l / KL

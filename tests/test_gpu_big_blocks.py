@@ -41,6 +41,13 @@ CASES = {
     "36cube_tails": ((36 * 6 + 20, 36 * 6 + 7, 36 * 6 + 30, 0.4, 0.4, 0.5, [1, 36], [1, 36], [1, 36]), "mm_numeric_f64_mid<9,9>"),
     "mix_33_to_40": ((36 * 8, 36 * 8, 300, 0.5, 0.5, 0.5, [1, 33, 1, 40, 1, 37, 1, 36], [1, 40, 1, 34, 1, 38], [1, 40, 1, 5, 1, 33, 1, 17]), "mm_numeric_f64_mid<10,10>"),
     "mostly_34_some_small": ((34 * 12 + 13, 34 * 12 + 40, 34 * 8, 0.5, 0.5, 0.5, [12, 34, 1, 13], [12, 34, 1, 40], [1, 34]), "mm_numeric_f64_mid<"),
+    # ... and 41 ... 48 (11 / 12 units): the largest shape is then <12,12>
+    "44cube": ((44 * 7, 44 * 6, 44 * 8, 0.5, 0.5, 0.5, [1, 44], [1, 44], [1, 44]), "mm_numeric_f64_mid<11,11>"),
+    "48cube_tails": ((48 * 6 + 20, 48 * 6 + 45, 48 * 6 + 30, 0.4, 0.4, 0.5, [1, 48], [1, 48], [1, 48]), "mm_numeric_f64_mid<12,12>"),
+    "41x47_k33": ((41 * 7, 47 * 6, 33 * 9, 0.5, 0.5, 0.5, [1, 41], [1, 47], [1, 33]), "mm_numeric_f64_big<3,3>"),   # (both above 40, not multiples of 4: the workgroup kernel)
+    "44x48_k33": ((44 * 7, 48 * 6, 33 * 9, 0.5, 0.5, 0.5, [1, 44], [1, 48], [1, 33]), "mm_numeric_f64_mid<11,12>"),
+    "36x45_k80": ((36 * 8, 45 * 7, 80 * 4, 0.5, 0.5, 0.5, [1, 36], [1, 45], [1, 80]), "mm_numeric_f64_mid<9,12>"),
+    "mix_30_to_48": ((400, 410, 300, 0.5, 0.5, 0.5, [1, 33, 1, 48, 1, 41, 1, 30], [1, 44, 1, 34, 1, 48], [1, 40, 1, 5, 1, 33, 1, 17]), "mm_numeric_f64_mid<12,12>"),
     # the workgroup kernel beside it: every parity of ceil(m / 8) tiles split between the two wave rows / columns
     "41x49x20": ((41 * 7, 49 * 6, 20 * 12, 0.5, 0.5, 0.5, [1, 41], [1, 49], [1, 20]), "mm_numeric_f64_big<3,4>"),
     "53x64x41": ((53 * 6, 64 * 5, 41 * 7, 0.5, 0.5, 0.5, [1, 53], [1, 64], [1, 41]), "mm_numeric_f64_big<4,4>"),
@@ -77,7 +84,7 @@ def test_big_block_kernel_matches_oracle(monkeypatch, name, alpha, beta):
     check(dev_to_bcsr(dC), ref)
 
 
-@pytest.mark.parametrize("name", ["72cube", "45x67x78", "mixed_sizes", "sparse_lists", "36cube_tails", "mix_33_to_40"])
+@pytest.mark.parametrize("name", ["72cube", "45x67x78", "mixed_sizes", "sparse_lists", "36cube_tails", "mix_33_to_40", "48cube_tails", "mix_30_to_48"])
 def test_big_block_kernel_retain_and_in_place(monkeypatch, name):
     """retain_sparsity, then a second product accumulated in place (C blocks without products in the call stay untouched: skip_empty)"""
     for k in ENV:

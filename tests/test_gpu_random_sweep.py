@@ -63,8 +63,8 @@ def test_random_multiply_matches_oracle(seed):
 BIG_MIXES = [[1, 45], [1, 72], [1, 67, 1, 5], [1, 40, 1, 23], [1, 80], [2, 33, 1, 13], [1, 64], [1, 55, 1, 3], [1, 78, 1, 32], [1, 23]]
 
 
-# round 6: C blocks of 33 ... 40 in both dimensions (the one-wave kernel mm_numeric_f64_mid and its second launch for the blocks of another size)
-MID_MIXES = [[1, 33], [1, 36], [1, 40], [1, 37, 1, 34], [3, 35, 1, 8], [1, 39, 1, 40], [1, 38]]
+# round 6: C blocks of 33 ... 48 in both dimensions (the one-wave kernel mm_numeric_f64_mid and its second launch for the blocks of another size)
+MID_MIXES = [[1, 33], [1, 36], [1, 40], [1, 37, 1, 34], [3, 35, 1, 8], [1, 39, 1, 40], [1, 38], [1, 44], [1, 48], [1, 41, 1, 47], [4, 45, 1, 30]]
 
 
 def make_big_case(seed, mixes=BIG_MIXES, k_mixes=BIG_MIXES):
