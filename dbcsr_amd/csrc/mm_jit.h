@@ -25,7 +25,8 @@ struct StackKernel {
   hipFunction_t fn = nullptr;
   int wave_lds = 0;
 };
-int jit_stack_kernel(int m, int n, int k, bool bt, StackKernel* out);
+// compile = false: only a kernel another call (any thread) compiled before; 1 when there is none
+int jit_stack_kernel(int m, int n, int k, bool bt, StackKernel* out, bool compile = true);
 
 }  // namespace dbcsr_amd
 #endif

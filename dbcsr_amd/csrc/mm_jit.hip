@@ -164,7 +164,7 @@ int jit_class_kernel(int m, int n, int k0, int k1, int k2, int g, ClassKernel* o
 }
 
 
-int jit_stack_kernel(int m, int n, int k, bool bt, StackKernel* out) {
+int jit_stack_kernel(int m, int n, int k, bool bt, StackKernel* out, bool compile) {
   if (!out || m < 1 || n < 1 || k < 1 || m > 32 || n > 32 || k > 32) return -1;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return -1;
@@ -176,6 +176,7 @@ int jit_stack_kernel(int m, int n, int k, bool bt, StackKernel* out) {
     *out = it->second.k;
     return 0;
   }
+  if (!compile) return 1;   // (not there, and the caller does not want to pay for it now)
   CachedStack& c = g_stack_cache[key];
   c.failed = true;
   hipDeviceProp_t prop;

@@ -24,6 +24,7 @@
 #include "mm_types.h"
 #include "smm_core.h"
 #include "mm_numeric_f64_big.h"   // slab geometry of the workgroup-per-C-block kernel (BIG_KSL, BIG_PB, big_*_bytes)
+#include "mm_numeric_f64_mid.h"   // BigSub: a wave's block covered in units of 4 x 4 (the one-wave slab kernels)
 #include "mm_jit.h"               // jit_stack_kernel: the exact-size kernel of smm_exact.h, compiled per (m, n, k) at run time
 
 namespace dbcsr_amd {
@@ -521,6 +522,137 @@ static int launch_f64_big(bool bt, hipStream_t st, const int* stack, int nstack,
   return dbcsr_amd::check(hipGetLastError(), "smm_stack_f64_big launch", __FILE__, __LINE__);
 }
 
+// Blocks of 33 ... 40 in both dimensions under the acc ABI (round 6): the one-wave slab dataflow of mm_numeric_f64_mid.h on a parameter stack.  A WAVE
+// (a workgroup of 64 threads) takes `group` consecutive entries, owns the whole C block in units of 4 x 4 (BigSub<RBX, CBX>: 21 MFMAs per k step for
+// 33 ... 36 instead of the 25 of a block padded to 40), keeps the sums across runs of equal C offsets and adds them to C with fp64 atomics at the end of a
+// run; an entry's operands arrive in slabs of 8 inner indices through 5-6 KB of LDS, the next slab in flight in registers.  B as libsmm_acc_transpose
+// leaves it (n x k: its slab is as contiguous as A's) or as stored (k x n: n runs of 64 bytes at a pitch of 12 doubles).  The workgroup kernel above is
+// LDS-bound at these sizes (profiles/r06_big_blocks_sub4_experiment.txt, r06_mid_blocks.txt).
+template <int RBX, int CBX, bool BT>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) smm_stack_f64_mid(const int* __restrict__ stack, int nstack,
+                                                          const double* __restrict__ a_data, const double* __restrict__ b_data,
+                                                          double* __restrict__ c_data, int m, int n, int k, int group) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int KSL = 8, TM = (RBX + 1) / 2, TN = (CBX + 1) / 2, PB = KSL + 4, KL = KSL / 2, CPR = 64 / KL;
+  constexpr int ABYTES = mid_a_bytes(TM, KSL);
+  constexpr int RA = (ABYTES + 1023) / 1024, RB_ = BT ? (mid_a_bytes(TN, KSL) + 1023) / 1024 : (8 * TN + CPR - 1) / CPR;
+  const int lane = threadIdx.x;
+  const int first = blockIdx.x * group;
+  if (first >= nstack) return;
+  const int last = min(first + group, nstack);
+  const int bk = 2 * (lane & (KL - 1)), bc = lane / KL;
+  u32x4 ga[RA], gb[RB_];
+  int k0_cur = 0;
+  auto issue = [&](int s, int k0) __attribute__((always_inline)) {
+    const int ao = __builtin_amdgcn_readfirstlane(stack[3 * s]) - 1, bo = __builtin_amdgcn_readfirstlane(stack[3 * s + 1]) - 1;
+    const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)(a_data + ao), 0, m * k * 8, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)(b_data + bo), 0, k * n * 8, 0x00020000);
+    const int abase = lane * 16 + k0 * m * 8;   // (the whole offset in the bounds-checked operand: the k tail must arrive as zeros)
+#pragma unroll
+    for (int r = 0; r < RA; ++r) ga[r] = __builtin_amdgcn_raw_buffer_load_b128(rsa, abase + r * 1024, 0, 0);
+    if constexpr (BT) {
+      const int bbase = lane * 16 + k0 * n * 8;
+#pragma unroll
+      for (int r = 0; r < RB_; ++r) gb[r] = __builtin_amdgcn_raw_buffer_load_b128(rsb, bbase + r * 1024, 0, 0);
+    } else {
+#pragma unroll
+      for (int r = 0; r < RB_; ++r) {
+        const int col = CPR * r + bc;
+        const int off = col < n ? (col * k + k0 + bk) * 8 : 0x7ffffff0;
+        gb[r] = __builtin_amdgcn_raw_buffer_load_b128(rsb, off, 0, 0);
+      }
+    }
+    k0_cur = k0;
+  };
+  auto stage = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int r = 0; r < RA; ++r) *reinterpret_cast<u32x4*>(smem + r * 1024 + lane * 16) = ga[r];
+    DBCSR_AMD_LDS_ORDER();
+    if constexpr (BT) {
+#pragma unroll
+      for (int r = 0; r < RB_; ++r) *reinterpret_cast<u32x4*>(smem + ABYTES + r * 1024 + lane * 16) = gb[r];
+    } else {
+      const bool k0ok = k0_cur + bk < k, k1ok = k0_cur + bk + 1 < k;
+#pragma unroll
+      for (int r = 0; r < RB_; ++r) {
+        u32x4 v = gb[r];
+        if (!k0ok) v[0] = 0u, v[1] = 0u;
+        if (!k1ok) v[2] = 0u, v[3] = 0u;
+        if (CPR * r + bc < 8 * TN) *reinterpret_cast<u32x4*>(smem + ABYTES + ((CPR * r + bc) * PB + bk) * 8) = v;
+      }
+    }
+  };
+  typedef BigSub<RBX, CBX> Sub;
+  Sub S;
+  S.init(0, 0, m, n, lane, ABYTES / 8, BT ? 1 : PB, BT ? n : 1);
+  const int own_r = (m + 3) >> 2, own_c = (n + 3) >> 2;
+  auto flush = [&](int co) __attribute__((always_inline)) {
+    double* C = c_data + (co - 1);
+    S.drain(lane, own_r, own_c, [&](int row, int col, double sum) {
+      if (row < m && col < n) unsafeAtomicAdd(C + row + (size_t)m * col, sum);
+    });
+  };
+  const double* la = reinterpret_cast<const double*>(smem);
+  const int astep = 4 * m, bstep = BT ? 4 * n : 4;
+  int s = first, k0 = 0;
+  int cur_c = __builtin_amdgcn_readfirstlane(stack[3 * first + 2]);
+  issue(first, 0);
+  while (s < last) {
+    if (k0 == 0) {   // a new entry: the end of a run of equal C offsets?
+      const int co = __builtin_amdgcn_readfirstlane(stack[3 * s + 2]);
+      if (co != cur_c) {
+        flush(cur_c);
+        cur_c = co;
+      }
+    }
+    const int rem = (k - k0 + 3) >> 2;
+    const int nst = rem < KSL / 4 ? rem : KSL / 4;
+    stage();
+    int s2 = s, k2 = k0 + KSL;
+    if (k2 >= k) s2 = s + 1, k2 = 0;
+    if (s2 < last) issue(s2, k2);
+    // (one operand set: a step's fragments are fetched right before its MFMAs -- with two sets the 9 x 10 shapes do not fit three waves per SIMD here)
+    double av[Sub::NA > 0 ? Sub::NA : 1], bv[Sub::NB > 0 ? Sub::NB : 1];
+#pragma unroll
+    for (int st_ = 0; st_ < KSL / 4; ++st_) {
+      if (st_ < nst) {
+        S.fetch(la, astep * st_, bstep * st_, av, bv);
+        S.mma(av, bv);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    s = s2;
+    k0 = k2;
+  }
+  flush(cur_c);
+}
+
+template <int RBX, int CBX>
+static int launch_f64_mid(bool bt, hipStream_t st, const int* stack, int nstack, const double* a, const double* b, double* c, int m, int n, int k) {
+  constexpr int TM = (RBX + 1) / 2, TN = (CBX + 1) / 2;
+  const int group = 8;   // entries per wave (as the workgroup kernel: runs of equal C offsets of the host's stacks are about that long)
+  const dim3 grid((unsigned)((nstack + group - 1) / group));
+  const size_t a_b = (size_t)mid_a_bytes(TM, 8), lds_t = a_b + (size_t)((mid_a_bytes(TN, 8) + 1023) / 1024) * 1024,
+               lds_s = std::max((a_b + 1023) / 1024 * 1024, a_b + (size_t)mid_b_bytes(TN, 8));
+  if (bt)
+    hipLaunchKernelGGL((smm_stack_f64_mid<RBX, CBX, true>), grid, dim3(64), std::max(lds_t, (a_b + 1023) / 1024 * 1024), st, stack, nstack, a, b, c, m, n, k, group);
+  else
+    hipLaunchKernelGGL((smm_stack_f64_mid<RBX, CBX, false>), grid, dim3(64), lds_s, st, stack, nstack, a, b, c, m, n, k, group);
+  return dbcsr_amd::check(hipGetLastError(), "smm_stack_f64_mid launch", __FILE__, __LINE__);
+}
+
+// 1: not a shape of the one-wave kernel
+static int process_stack_f64_mid(const int* dev_stack, int nstack, const double* a, const double* b, double* c, int m, int n, int k, bool bt, hipStream_t st) {
+  const int rb = (m + 3) / 4, cb = (n + 3) / 4;
+  switch (rb * 16 + cb) {
+#define DBCSR_MID_STACK(A_, B_) \
+  case A_ * 16 + B_: return launch_f64_mid<A_, B_>(bt, st, dev_stack, nstack, a, b, c, m, n, k);
+    DBCSR_MID_STACK(9, 9) DBCSR_MID_STACK(9, 10) DBCSR_MID_STACK(10, 9) DBCSR_MID_STACK(10, 10)
+#undef DBCSR_MID_STACK
+    default: return 1;
+  }
+}
+
 static int process_stack_f64_big(const int* dev_stack, int nstack, const double* a, const double* b, double* c, int m, int n, int k, bool bt,
                                  hipStream_t st) {
   const int tm = std::max(2, ((m + 7) / 8 + 1) / 2), tn = std::max(2, ((n + 7) / 8 + 1) / 2);
@@ -559,9 +691,9 @@ static int process_stack_f64_exact(const int* dev_stack, int nstack, const doubl
   for (const Hit& h : last)
     if (h.dev == dev && h.m == m && h.n == n && h.k == k && h.bt == (int)bt) sk = &h.sk;
   if (!sk) {
-    if (mode < 0 && nstack < 256) return 1;
+    // a short stack of a triplet this thread has not met: the kernel another thread compiled, if any -- never a compilation of its own
     Hit& h = last[next];
-    if (jit_stack_kernel(m, n, k, bt, &h.sk) != 0) {
+    if (jit_stack_kernel(m, n, k, bt, &h.sk, !(mode < 0 && nstack < 256)) != 0) {
       h.dev = -1;
       return 1;
     }
@@ -593,6 +725,13 @@ int process_stack_f64(const int* dev_stack, int nstack, const double* a, const d
   // 8 x 8: for 5 x 5 x 64 three of them would stage slabs and wait at barriers for nothing; those stay with the wave-per-entry kernels below)
   const bool wide = m > 32 || n > 32 || (k > 32 && ((m + 7) / 8) * ((n + 7) / 8) >= 4);
   if (!big_off && wide && m <= 80 && n <= 80 && (int64_t)m * k * 8 < (1ll << 30) && (int64_t)n * k * 8 < (1ll << 30)) {
+    // blocks of 33 ... 40 in both dimensions: one wave per group of entries, the block in units of 4 x 4 (DBCSR_AMD_SMM_MID=0: the workgroup kernel)
+    static const bool mid_off = getenv("DBCSR_AMD_SMM_MID") != nullptr && atoi(getenv("DBCSR_AMD_SMM_MID")) == 0;
+    if (!mid_off && m > 32 && n > 32 && m <= 40 && n <= 40) {
+      note_kernel("smm_stack_f64_mid(%d,%d,%d%s)", m, n, k, bt);
+      const int rc = process_stack_f64_mid(dev_stack, nstack, a, b, c, m, n, k, bt, st);
+      if (rc <= 0) return rc;
+    }
     note_kernel("smm_stack_f64_big(%d,%d,%d%s)", m, n, k, bt);
     return process_stack_f64_big(dev_stack, nstack, a, b, c, m, n, k, bt, st);
   }

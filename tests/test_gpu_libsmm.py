@@ -246,3 +246,21 @@ def test_large_block_stack_with_b_as_stored_and_random_order(m, n, k):
     rc, c = run_stack(st, a, b, c0.copy(), m, n, k, L.dbcsr_type_real_8)
     assert rc >= 0
     assert rel_err(c, c_ref) <= 1e-10
+
+
+@pytest.mark.parametrize("bt", [True, False])
+@pytest.mark.parametrize("m,n,k", [(33, 33, 33), (36, 40, 35), (40, 37, 9), (34, 35, 80)])
+def test_blocks_of_33_to_40_take_the_one_wave_stack_kernel(m, n, k, bt):
+    """round 6: homogeneous stacks of blocks with 33 ... 40 rows and columns (any inner dimension) run smm_stack_f64_mid -- a wave per group of entries, the block
+    covered in units of 4 x 4, operand slabs of 8 inner indices --, B transposed or as stored; integer inputs: EXACT"""
+    na, nb, nc, nstack = 60, 70, 9, 403
+    a = O.mat_init(na, m, k, 42)
+    b = O.mat_init(nb, k, n, 24)
+    stack = O.stack_init(nstack, nc, na, nb, m, n, k, rseed=13)
+    c_ref = np.zeros(nc * m * n)
+    O.stack_calc(stack, c_ref, a, b, m, n, k, b_transposed=False)
+    rc, c = run_stack(stack, a, b, np.zeros(nc * m * n), m, n, k, L.dbcsr_type_real_8, max_kernel_dim=80 if bt else 0, transpose_b=bt)
+    assert rc >= 0
+    name = L.load_library().dbcsr_amd_smm_last_kernel().decode()
+    assert name.startswith("smm_stack_f64_mid(%d,%d,%d" % (m, n, k)) and ("transposed" in name) == bt, name
+    assert np.array_equal(c, c_ref)
