@@ -33,13 +33,6 @@
 #ifndef DBCSR_EXACT_SCHED_BARRIER
 #define DBCSR_EXACT_SCHED_BARRIER 1
 #endif
-//  DBCSR_EXACT_DIRECT_A     1 (round 6; DBCSR_AMD_MM_CLASS_DIRECT=1): A's fragments go STRAIGHT from global memory (the block row is
-//                              L2-resident) into the MFMA operand registers -- one 8-byte bounds-checked load per tile row and k step, the k tail arrives as
-//                              zeros --, only B is staged in LDS: the wave's slice halves (23 x 23 with k up to 32: 6.2 instead of 12.8 KB).  The operands of
-//                              step s of the NEXT product are requested right after step s of the current one has used its registers.
-#ifndef DBCSR_EXACT_DIRECT_A
-#define DBCSR_EXACT_DIRECT_A 0
-#endif
 
 namespace dbcsr_amd {
 
@@ -57,7 +50,7 @@ struct IntC {
 
 // LDS bytes one wave needs for class (m, n) with inner sizes k0, k1, k2 (0 = absent): also evaluated at run time by the host
 // (mm_jit.hip) to size the launch
-constexpr int class_wave_lds(int m, int n, int k0, int k1, int k2, int direct_a = DBCSR_EXACT_DIRECT_A) {
+constexpr int class_wave_lds(int m, int n, int k0, int k1, int k2) {
   int a_lds = 0, cb_max = 0, bpad = 0;
   const int ks[3] = {k0, k1, k2};
   for (int i = 0; i < 3; ++i) {
@@ -68,7 +61,7 @@ constexpr int class_wave_lds(int m, int n, int k0, int k1, int k2, int direct_a 
     cb_max = cmax(cb_max, (k * n * 8 + 1023) / 1024);
     if (k % 16 == 0) bpad = 128;
   }
-  a_lds = direct_a ? 0 : (a_lds + 15) & ~15;
+  a_lds = (a_lds + 15) & ~15;
   const int c_lds = ((m * n * 8 + 1023) / 1024) * 1024;
   // B is written in whole 1 KiB pieces; with a padded pitch (columns of 16 or 32 elements) a piece spans up to 8 columns,
   // each shifted by 16 bytes more than the one before: 128 extra bytes per piece at most
@@ -90,9 +83,7 @@ struct KShape<M, N, 0> {
 template <int M, int N, int K0, int K1, int K2>
 struct ClassShape {
   static constexpr int MA = (M + 7) / 8, NC = (N + 7) / 8;
-  static constexpr int A_LDS_STAGED = (cmax(KShape<M, N, K0>::A_LDS, cmax(KShape<M, N, K1>::A_LDS, KShape<M, N, K2>::A_LDS)) + 15) & ~15;
-  static constexpr int A_LDS = DBCSR_EXACT_DIRECT_A ? 0 : A_LDS_STAGED;
-  static constexpr int KSMAX = cmax(KShape<M, N, K0>::KS, cmax(KShape<M, N, K1>::KS, KShape<M, N, K2>::KS));
+  static constexpr int A_LDS = (cmax(KShape<M, N, K0>::A_LDS, cmax(KShape<M, N, K1>::A_LDS, KShape<M, N, K2>::A_LDS)) + 15) & ~15;
   static constexpr int CAMAX = cmax(KShape<M, N, K0>::CA, cmax(KShape<M, N, K1>::CA, KShape<M, N, K2>::CA));
   static constexpr int CBMAX = cmax(KShape<M, N, K0>::CB, cmax(KShape<M, N, K1>::CB, KShape<M, N, K2>::CB));
   // B is written in whole 1 KiB pieces (plus the pitch padding of its columns); A's last piece may spill into B's region,
@@ -101,7 +92,7 @@ struct ClassShape {
   static constexpr int B_REGION = CBMAX * (1024 + BPAD) + 16;
   static constexpr int C_LDS = ((M * N * 8 + 1023) / 1024) * 1024;
   static constexpr int WAVE_LDS = (cmax(A_LDS + B_REGION, C_LDS) + 15) & ~15;
-  static_assert(WAVE_LDS == class_wave_lds(M, N, K0, K1, K2, DBCSR_EXACT_DIRECT_A), "host and device disagree on the LDS size of a class");
+  static_assert(WAVE_LDS == class_wave_lds(M, N, K0, K1, K2), "host and device disagree on the LDS size of a class");
 };
 
 // byte offset inside the staged image of the 16-byte granule that lane `lane` of piece `c` carries (two consecutive elements
@@ -321,215 +312,6 @@ __device__ __forceinline__ void cblock_f64_classes(const Desc& d, const Entry fi
   }
 }
 
-// ---- the same with A straight into the operand registers (DBCSR_EXACT_DIRECT_A) ------------------------------------------------------------
-// Only B goes through LDS.  A's fragment of tile row a at k step s is ONE 8-byte element per lane -- A[8a + rowl][kq + 4s] --, loaded with a
-// bounds-checked buffer load whose descriptor covers exactly the block: rows stay inside by clamping, inner indices past the block's k extent come
-// back as zeros (no zero padding to write, no tail code).  Per product MA x ceil(k / 4) loads instead of CA 1 KiB pieces + as many LDS copies + MA
-// fragment reads per step; the lanes of the two column halves (q) request the same element: twice the block's bytes at the L1, none more at the L2.
-// Registers: av[KSMAX][MA] hold the product being multiplied; the operands of step s of the NEXT product are requested right after step s has issued
-// its MFMAs (the registers are free then), so one set suffices and a whole product's A is in flight under the current product's multiplies.
-template <int M, int N, int K0, int K1, int K2>
-__device__ __forceinline__ void cblock_f64_classes_direct(const Desc& d, const Entry first, bool have_first, const Entry* __restrict__ entries,
-                                                          const double* __restrict__ a_data, const double* __restrict__ b_data,
-                                                          double* __restrict__ c_out, const double* __restrict__ c_in, double alpha, double beta,
-                                                          const LaneMap& L, int lane, char* lds, double* __restrict__ norm_out) {
-  typedef ClassShape<M, N, K0, K1, K2> CS;
-  constexpr int MA = CS::MA, NC = CS::NC, KSMAX = CS::KSMAX;
-  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-  char* lds_b = lds;
-  double acc[MA][NC];
-#pragma unroll
-  for (int a = 0; a < MA; ++a)
-#pragma unroll
-    for (int c = 0; c < NC; ++c) acc[a][c] = 0.0;
-  const Entry* e = entries + d.prod_start;
-  const int cnt = d.prod_cnt;
-  const int voff = lane * 16;
-  u32x4 rb[CS::CBMAX];
-  double av[KSMAX][MA];
-  int aoff[MA], colc[NC];
-#pragma unroll
-  for (int a = 0; a < MA; ++a) {
-    int row = 8 * a + L.rowl;
-    row = row < M ? row : M - 1;
-    aoff[a] = 8 * (row + M * L.kq);
-  }
-#pragma unroll
-  for (int c = 0; c < NC; ++c) {
-    int col = 8 * c + L.coll;
-    colc[c] = col < N ? col : N - 1;
-  }
-  // product list: one vector load (lane l holds entry base + l), handed out with v_readlane
-  int ebase = 0;
-  uint32_t ev0 = 0, ev1 = 0, ev2 = 1;
-  auto load_window = [&](int base) {
-    ebase = base;
-    if (cnt <= 0) return;
-    const int i = base + lane < cnt ? base + lane : cnt - 1;
-    ev0 = e[i].a_lo;
-    ev1 = e[i].b_lo;
-    ev2 = e[i].w;
-  };
-  load_window(0);
-  auto entry_at = [&](int i) {
-    if (i - ebase >= 64) load_window(i);
-    const int j = __builtin_amdgcn_readfirstlane(i - ebase);
-    Entry en;
-    en.a_lo = (uint32_t)__builtin_amdgcn_readlane((int)ev0, j);
-    en.b_lo = (uint32_t)__builtin_amdgcn_readlane((int)ev1, j);
-    en.w = (uint32_t)__builtin_amdgcn_readlane((int)ev2, j);
-    return en;
-  };
-  auto in_set = [](int ks) { return ks == K0 || (K1 != 0 && ks == K1) || (K2 != 0 && ks == K2); };
-  auto next_in_set = [&](int i) {
-    while (i < cnt && !in_set(entry_at(i).ks())) ++i;
-    return i;
-  };
-  auto issue_b = [&](const Entry& en) {
-    const int bbytes = __builtin_amdgcn_readfirstlane(en.ks() * N * 8);
-    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)(b_data + en.b_off()), 0, bbytes, 0x00020000);
-#pragma unroll
-    for (int c = 0; c < CS::CBMAX; ++c) rb[c] = __builtin_amdgcn_raw_buffer_load_b128(rsb, voff, c * 1024, 0);
-  };
-  auto rsrc_a = [&](const Entry& en) {
-    const int abytes = __builtin_amdgcn_readfirstlane(M * en.ks() * 8);
-    return __builtin_amdgcn_make_buffer_rsrc((void*)(a_data + en.a_off()), 0, abytes, 0x00020000);
-  };
-  // A operands of k step s of the product behind `rsa` (nks steps: later ones are not requested -- nobody multiplies them).  The whole offset travels
-  // in the bounds-checked VGPR / immediate part of the address: the k tail MUST come back as zeros.
-  auto load_a_step = [&](const __amdgpu_buffer_rsrc_t& rsa, int s, int nks) __attribute__((always_inline)) {
-    if (s < nks) {   // (wave-uniform)
-#pragma unroll
-      for (int a = 0; a < MA; ++a) av[s][a] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsa, aoff[a] + 32 * M * s, 0, 0));
-    }
-  };
-  auto store_b = [&](int ks) {
-    // B's columns have ks elements: padded pitch when ks is a multiple of 16 (then ks is 16 or 32 and divides 128)
-    const int sh = __builtin_amdgcn_readfirstlane((ks & 15) == 0 ? (ks == 16 ? 4 : 5) : 31);
-#pragma unroll
-    for (int c = 0; c < CS::CBMAX; ++c) *reinterpret_cast<u32x4*>(lds_b + c * 1024 + lane * 16 + 16 * ((c * 128 + lane * 2) >> sh)) = rb[c];
-  };
-  auto compute_k = [&](auto kc, bool have_next, const __amdgpu_buffer_rsrc_t& rsa_next, int nks_next) __attribute__((always_inline)) {
-    constexpr int K = decltype(kc)::value;
-    typedef KShape<M, N, K> KSH;
-    constexpr int KS = KSH::KS, BP = KSH::BP;
-    const double* pb[NC];
-    const double* pbt[NC];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      pb[c] = reinterpret_cast<const double*>(lds_b) + L.kq + BP * colc[c];
-      const int kt = 4 * (KS - 1) + L.kq;  // last step when K is not a multiple of 4: lanes past the end read (0, col); A's operand is zero there
-      pbt[c] = reinterpret_cast<const double*>(lds_b) + (kt < K ? kt : 0) + BP * colc[c];
-    }
-    double bv[2][NC];
-    auto fetch = [&](int s, int buf) {
-#pragma unroll
-      for (int c = 0; c < NC; ++c) bv[buf][c] = (s == KS - 1 && (K & 3)) ? pbt[c][0] : pb[c][4 * s];
-    };
-    fetch(0, 0);
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      if (s + 1 < KS) fetch(s + 1, (s + 1) & 1);
-#pragma unroll
-      for (int a = 0; a < MA; ++a)
-#pragma unroll
-        for (int c = 0; c < NC; ++c) acc[a][c] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[s][a], bv[s & 1][c], acc[a][c], 0, 0, 0);
-      if (have_next) load_a_step(rsa_next, s, nks_next);   // this step's registers are free: the next product's operands of the same step
-      if (DBCSR_EXACT_SCHED_BARRIER) __builtin_amdgcn_sched_barrier(0);
-    }
-    if (have_next) {
-#pragma unroll
-      for (int s = KS; s < KSMAX; ++s) load_a_step(rsa_next, s, nks_next);
-    }
-  };
-
-  int i0;
-  Entry e0;
-  if (have_first && in_set(first.ks())) {
-    i0 = 0;
-    e0 = first;
-  } else {
-    i0 = next_in_set(0);
-    e0 = i0 < cnt ? entry_at(i0) : Entry::make(0, 0, K0);
-  }
-  if (i0 < cnt) {
-    issue_b(e0);
-    const __amdgpu_buffer_rsrc_t rsa0 = rsrc_a(e0);
-    const int nks0 = (e0.ks() + 3) >> 2;
-#pragma unroll
-    for (int s = 0; s < KSMAX; ++s) load_a_step(rsa0, s, nks0);
-  }
-  while (i0 < cnt) {
-    const int kcur = e0.ks();
-    const int i1 = next_in_set(i0 + 1);
-    const bool have_next = i1 < cnt;
-    const Entry e1 = have_next ? entry_at(i1) : e0;
-    store_b(kcur);
-    if (have_next) issue_b(e1);
-    const __amdgpu_buffer_rsrc_t rsa1 = rsrc_a(e1);
-    const int nks1 = (e1.ks() + 3) >> 2;
-    if (kcur == K0) compute_k(IntC<K0>(), have_next, rsa1, nks1);
-    if constexpr (K1 != 0)
-      if (kcur == K1) compute_k(IntC<K1>(), have_next, rsa1, nks1);
-    if constexpr (K2 != 0)
-      if (kcur == K2) compute_k(IntC<K2>(), have_next, rsa1, nks1);
-    i0 = i1;
-    e0 = e1;
-  }
-  for (int p = 0; p < cnt; ++p) {
-    const Entry ep = e[p];
-    if (!in_set(ep.ks())) block_product_f64<MA, NC, false>(acc, a_data + ep.a_off(), b_data + ep.b_off(), M, N, ep.ks(), L);
-  }
-
-  // C epilogue through LDS: the block leaves as stored, in whole 1 KiB pieces (16 B per lane), streaming hint
-  constexpr int CC = (M * N * 8 + 1023) / 1024;
-  double* lds_c = reinterpret_cast<double*>(lds);
-#pragma unroll
-  for (int a = 0; a < MA; ++a)
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      const int row = 8 * a + L.rowd, col = 8 * c + L.coll;
-      if (row < M && col < N) lds_c[row + M * col] = alpha * acc[a][c];
-    }
-  const bool has_in = d.cin_off >= 0;
-  const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc((void*)(c_out + d.c_off), 0, M * N * 8, 0x00020000);
-  typedef double f64x2 __attribute__((ext_vector_type(2)));
-  if (has_in) {
-    const __amdgpu_buffer_rsrc_t rsi = __builtin_amdgcn_make_buffer_rsrc((void*)(c_in + d.cin_off), 0, M * N * 8, 0x00020000);
-    u32x4 ci[CC];
-#pragma unroll
-    for (int c = 0; c < CC; ++c) ci[c] = __builtin_amdgcn_raw_buffer_load_b128(rsi, voff, c * 1024, 0);
-#pragma unroll
-    for (int c = 0; c < CC; ++c) {
-      f64x2 v = *reinterpret_cast<const f64x2*>(lds + c * 1024 + voff);
-      const f64x2 w = __builtin_bit_cast(f64x2, ci[c]);
-      v[0] += beta * w[0];
-      v[1] += beta * w[1];
-      if (norm_out) *reinterpret_cast<f64x2*>(lds + c * 1024 + voff) = v;
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsc, voff, c * 1024, 2);
-    }
-  } else {
-#pragma unroll
-    for (int c = 0; c < CC; ++c) {
-      const u32x4 v = *reinterpret_cast<const u32x4*>(lds + c * 1024 + voff);
-      __builtin_amdgcn_raw_buffer_store_b128(v, rsc, voff, c * 1024, 2);
-    }
-  }
-  if (norm_out) {
-    double ss = 0.0;
-#pragma unroll
-    for (int c = 0; c < CC; ++c) {
-      const f64x2 v = *reinterpret_cast<const f64x2*>(lds + c * 1024 + voff);
-      const int idx = c * 128 + 2 * lane;
-      if (idx < M * N) ss += v[0] * v[0];
-      if (idx + 1 < M * N) ss += v[1] * v[1];
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) ss += __shfl_down(ss, off, 64);
-    if (lane == 0) *norm_out = ss;
-  }
-}
-
 // one wave per C block; order[] holds the class's segment (per-XCD streams padded with -1, as for the other kernels)
 template <int M, int N, int K0, int K1, int K2>
 __device__ __forceinline__ void mm_class_kernel_body(const Desc* __restrict__ descs, int64_t nblk, const Entry* __restrict__ entries,
@@ -560,13 +342,8 @@ __device__ __forceinline__ void mm_class_kernel_body(const Desc* __restrict__ de
   }
   if (skip_empty && d.prod_cnt == 0) return;
   const LaneMap L(lane);
-#if DBCSR_EXACT_DIRECT_A
-  cblock_f64_classes_direct<M, N, K0, K1, K2>(d, first, have_first, entries, a_data, b_data, c_out, c_in, alpha, beta, L, lane,
-                                              smem + (size_t)wid * ClassShape<M, N, K0, K1, K2>::WAVE_LDS, norms ? norms + cbi : nullptr);
-#else
   cblock_f64_classes<M, N, K0, K1, K2>(d, first, have_first, entries, a_data, b_data, c_out, c_in, alpha, beta, L, lane,
                                        smem + (size_t)wid * ClassShape<M, N, K0, K1, K2>::WAVE_LDS, norms ? norms + cbi : nullptr);
-#endif
 }
 
 

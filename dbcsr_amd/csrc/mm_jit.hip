@@ -142,21 +142,16 @@ int jit_class_kernel(int m, int n, int k0, int k1, int k2, int g, ClassKernel* o
   c.failed = true;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
-  // DBCSR_AMD_MM_CLASS_DIRECT=1: A's fragments straight from global memory into the MFMA operand registers, only B staged in LDS (mm_exact.h:
-  // cblock_f64_classes_direct; the one-block-per-wave body only)
-  static const int direct_env = getenv("DBCSR_AMD_MM_CLASS_DIRECT") ? atoi(getenv("DBCSR_AMD_MM_CLASS_DIRECT")) : 0;
-  const int direct = (direct_env != 0 && g == 1) ? 1 : 0;
-  const int wave_lds = class_wave_lds(m, n, k0, k1, k2, direct);
+  const int wave_lds = class_wave_lds(m, n, k0, k1, k2);
   // waves per SIMD the LDS allows (4 waves per workgroup, 160 KiB per CU): the register allocation is asked to allow as many
   int wgs = (160 * 1024) / (4 * wave_lds);
   int minw = wgs > 4 ? 4 : (wgs < 1 ? 1 : wgs);
   if (g > 1 && minw > 1) --minw;  // the multi-block body keeps descriptors and two list windows in registers
-  if (direct && minw > 2) minw = 2;   // (the direct body holds a whole product's A operands in registers: 142 ... 237 of them, mm_exact.h)
   char defs[512];
   snprintf(defs, sizeof defs,
            "#define DBCSR_AMD_JIT_M %d\n#define DBCSR_AMD_JIT_N %d\n#define DBCSR_AMD_JIT_K0 %d\n#define DBCSR_AMD_JIT_K1 %d\n"
-           "#define DBCSR_AMD_JIT_K2 %d\n#define DBCSR_AMD_JIT_MINW %d\n#define DBCSR_AMD_JIT_G %d\n#define DBCSR_EXACT_DIRECT_A %d\n#include \"mm_exact.h\"\n",
-           m, n, k0, k1, k2, minw, g, direct);
+           "#define DBCSR_AMD_JIT_K2 %d\n#define DBCSR_AMD_JIT_MINW %d\n#define DBCSR_AMD_JIT_G %d\n#include \"mm_exact.h\"\n",
+           m, n, k0, k1, k2, minw, g);
   char what[96];
   snprintf(what, sizeof what, "class (%d, %d; %d, %d, %d)", m, n, k0, k1, k2);
   size_t cs = 0;
