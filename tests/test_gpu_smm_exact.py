@@ -121,3 +121,40 @@ def test_random_triplets_through_the_exact_kernel(seed):
     assert rc >= 0
     assert last_kernel().startswith("smm_stack_f64_exact<%d,%d,%d" % (m, n, k)), last_kernel()
     assert np.array_equal(c, c_ref), (m, n, k, nstack, order, bt)
+
+
+def test_host_threads_compile_and_run_different_triplets_at_once():
+    """what the real host does on its first multiply (src/mm/dbcsr_mm_accdrv.F: one stream per OpenMP thread, core/dbcsr_lib.F:248-262): several host threads
+    meet triplets nobody compiled yet AT THE SAME TIME -- the run-time compilation is serialised inside the library, every thread gets its kernel, every stack
+    its exact result"""
+    import threading
+    triplets = [(9 + 2 * t, 31 - 3 * t, 12 + t) for t in range(6)] + [(21, 21, 21), (21, 21, 21)]   # (two threads share a triplet)
+    results, errors = {}, []
+    start = threading.Barrier(len(triplets))
+
+    def worker(t):
+        try:
+            m, n, k = triplets[t]
+            na, nb, nc, nstack = 40, 50, 12, 700 + t
+            a = O.mat_init(na, m, k, 42 + t)
+            b = O.mat_init(nb, k, n, 24 + t)
+            stack = O.stack_init(nstack, nc, na, nb, m, n, k, rseed=7 + t)
+            c_ref = np.zeros(nc * m * n)
+            O.stack_calc(stack, c_ref, a, b, m, n, k, b_transposed=False)
+            start.wait()
+            rc, c = run_stack(stack, a, b, np.zeros(nc * m * n), m, n, k, L.dbcsr_type_real_8)
+            results[t] = (rc, np.array_equal(c, c_ref), last_kernel())
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+            start.abort()
+
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(len(triplets))]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join(timeout=300)
+    assert not errors, errors
+    for t, (m, n, k) in enumerate(triplets):
+        rc, same, name = results[t]
+        assert rc >= 0 and same, (t, m, n, k, name)
+        assert name.startswith("smm_stack_f64_exact<%d,%d,%d" % (m, n, k)), name
