@@ -38,6 +38,13 @@ Three schedules are offered:
     the B images of its process column travel in column chunks of its OWN block columns and chunk q of its C tile is
     multiplied when chunk q of every image has landed.  Per link the same bytes as on the N x 1 grid (one image per
     peer), in total fewer (a rank needs its row panel of A and its column panel of B, not all of B).
+  * ``mode="tilepipe"`` (round 6; chosen at construction; the 2-D grid): colpipe2d leaves the A images of the process row exposed
+    before the first multiply -- every column chunk needs the whole row panel of A.  Here A's missing images travel in ROW chunks
+    of the rank's own block rows next to B's column chunks (batch s = row chunk s of A + column chunk s of B, A and B on different
+    links), and step s multiplies the tiles of C that have become computable with batch s: the row strip
+    (row chunk s) x (column chunks 0 .. s) and the column strip (row chunks 0 .. s - 1) x (column chunk s), two launches on two
+    streams (disjoint C blocks, every C block written once).  Exposed: one chunk of one image per link; the work that can run
+    grows with the square of what has landed (1, 3, 5, ... of S^2 tiles).
 
 The local engine is duck-typed (``symbolic``, ``init_c``, ``accumulate``,
 ``fill_random_dist`` of dbcsr_amd.multiply.MultiplyEngine) so that the
@@ -343,7 +350,7 @@ class CannonMultiply:
         # all links at once, in column chunks that are multiplied as they arrive (see _multiply_colpipe)
         self.grid = grid or (Grid(world, rank, nprows=world, npcols=1) if mode == "colpipe" else Grid(world, rank))
         # mode "colpipe2d": the same column-chunk pipeline on the default 2-D grid (the A images of the process row come with the first chunk)
-        self._col_chunks = max(1, int(col_chunks)) if mode in ("colpipe", "colpipe2d") else 0
+        self._col_chunks = max(1, int(col_chunks)) if mode in ("colpipe", "colpipe2d", "tilepipe") else 0
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.dtype = dtype
         if engine is None:
@@ -399,10 +406,13 @@ class CannonMultiply:
         self.counters = {"C": c0 + 1, "A": c0 + 2, "B": c0 + 3}
         self.nbr_g, self.nbk_g, self.nbc_g = len(sm), len(sk), len(sn)
         r, c = g.myprow, g.mypcol
-        self._cbounds = None
+        self._cbounds = self._rbounds = None
         if self._col_chunks:
             ncl = len(P.cols_of[c])
             nch = max(1, min(self._col_chunks, ncl))
+            if mode == "tilepipe":   # as many row chunks of the C tile as column chunks, the same number on every rank (a batch is matched by its peers)
+                nch = max(1, min([self._col_chunks] + [len(x) for x in P.cols_of] + [len(x) for x in P.rows_of]))
+                self._rbounds = np.round(np.linspace(0, len(P.rows_of[r]), nch + 1)).astype(np.int64)
             self._cbounds = np.round(np.linspace(0, ncl, nch + 1)).astype(np.int64)
         t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt).to(self.device)
         self._rs = t(sm[P.rows_of[r]], torch.int32)
@@ -459,11 +469,31 @@ class CannonMultiply:
         self._merged = None
         self.colpipe_copies = 0
         self.colpipe_two_streams = os.environ.get("DBCSR_AMD_COLPIPE_STREAMS", "2") != "1"
-        self._side_stream = None
-        if self._cbounds is not None:
+        self._side_stream = self._arrival_stream = None
+        self._origins = None   # (first block row, first block column) of every part of C a step produces
+        if self._rbounds is not None:
+            # tilepipe: step s = the row strip (row chunk s) x (column chunks 0 .. s), then the column strip (row chunks 0 .. s - 1) x (column chunk s)
+            rb, cb, nk = self._rbounds, self._cbounds, len(sk)
+            self._tiles = []
+            for q in range(len(rb) - 1):
+                self._tiles.append((q, int(rb[q]), int(rb[q + 1]), 0, int(cb[q + 1])))
+                if q:
+                    self._tiles.append((q, 0, int(rb[q]), int(cb[q]), int(cb[q + 1])))
+            self._tiles = [t for t in self._tiles if t[2] > t[1] and t[4] > t[3]]
+            self._At = [self._sub_rc(self.A_panel, rlo, rhi, 0, nk) for _, rlo, rhi, _, _ in self._tiles]
+            self._Bc = [self._col_sub(self.B_panel, clo, chi) for _, _, _, clo, chi in self._tiles]
+            self._Cc = [self._sub_rc(self.C_in, rlo, rhi, clo, chi) for _, rlo, rhi, clo, chi in self._tiles]
+            self._origins = [(rlo, clo) for _, rlo, _, clo, _ in self._tiles]
+            for v in range(g.nvirt):   # an A image is stored by (row, column): a row chunk of it is one piece
+                img = self.A_img[v]
+                rp = img.row_p.detach().cpu().numpy().astype(np.int64)
+                bp = np.append(img.blk_p.detach().cpu().numpy().astype(np.int64), img.data_numel)
+                img.row_chunk_off = bp[rp[rb]]
+        elif self._cbounds is not None:
             nch = len(self._cbounds) - 1
             self._Bc = [self._col_sub(self.B_panel, int(self._cbounds[q]), int(self._cbounds[q + 1])) for q in range(nch)]
             self._Cc = [self._col_sub(self.C_in, int(self._cbounds[q]), int(self._cbounds[q + 1])) for q in range(nch)]
+            self._origins = [(0, int(self._cbounds[q])) for q in range(nch)]
         # double-buffered receive space for A and B panels
         amax = max([m.data_numel for v, m in self.A_img.items() if g.a_owner(r, v) != g.rank] + [0])
         bmax = max([m.data_numel for v, m in self.B_img.items() if g.b_owner(v, c) != g.rank] + [0])
@@ -603,6 +633,18 @@ class CannonMultiply:
         return DbcsrMatrix(full.row_blk_size, full.col_blk_size[lo:hi], t(np.cumsum(nrow_p), torch.int32), t(col_i[keep] - lo, torch.int32),
                            t(blk_p[keep], torch.int64), full.data, full.name)
 
+    def _sub_rc(self, full, rlo, rhi, clo, chi):
+        """`full` restricted to its block rows rlo .. rhi - 1 and block columns clo .. chi - 1, both numbered from 0: same data buffer."""
+        rs, cs, row_p, col_i, blk_p, _ = DbcsrMatrix(full.row_blk_size, full.col_blk_size, full.row_p, full.col_i, full.blk_p,
+                                                     full.row_p[:0]).to_host()
+        rows = np.repeat(np.arange(len(rs), dtype=np.int64), np.diff(row_p))
+        keep = (col_i >= clo) & (col_i < chi) & (rows >= rlo) & (rows < rhi)
+        nrow_p = np.zeros(rhi - rlo + 1, np.int64)
+        np.add.at(nrow_p, rows[keep] - rlo + 1, 1)
+        t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt).to(self.device)
+        return DbcsrMatrix(full.row_blk_size[rlo:rhi], full.col_blk_size[clo:chi], t(np.cumsum(nrow_p), torch.int32), t(col_i[keep] - clo, torch.int32),
+                           t(blk_p[keep], torch.int64), full.data, full.name)
+
     def _exchange(self, sends, recvs):
         """Posts one batch of (tensor, peer) sends and receives on the transport in use; returns (work handles, staged host copies)."""
         g = self.grid
@@ -721,8 +763,97 @@ class CannonMultiply:
         counts.c_nblks, counts.c_nze = sum(int(x[1].c_nblks) for x in sym), sum(int(x[1].c_nze) for x in sym)
         return self._merge_chunks(parts, out_all), counts
 
+    def _multiply_tilepipe(self, alpha, beta):
+        """2-D grid.  Batch s carries row chunk s of every A image this rank misses (from the owners in its process row) and column chunk
+        s of every B image it misses (from the owners in its process column); all batches are posted at once and carried out in order.
+        Step s multiplies what batch s made computable: (row chunk s) x (column chunks 0 .. s) on the first stream and
+        (row chunks 0 .. s - 1) x (column chunk s) on the second.  Every C block is written once, into its slice of one buffer."""
+        g, r, c = self.grid, self.grid.myprow, self.grid.mypcol
+        nch = len(self._cbounds) - 1
+        posted = []
+        for q in range(nch):
+            sends, recvs = [], []
+            for v in range(g.nvirt):
+                img, a_own = self.A_img[v], g.a_owner(r, v)
+                lo, hi = int(img.row_chunk_off[q]), int(img.row_chunk_off[q + 1])
+                if hi > lo:
+                    if a_own == g.rank:
+                        sends += [(img.data[lo:hi], g.rank_of(r, pc)) for pc in range(g.npcols) if pc != c]
+                    else:
+                        recvs.append((self._a_all[self._a_base[v] + lo:self._a_base[v] + hi], a_own))
+                img, b_own = self.B_img[v], g.b_owner(v, c)
+                lo, hi = int(img.chunk_off[q]), int(img.chunk_off[q + 1])
+                if hi > lo:
+                    if b_own == g.rank:
+                        sends += [(img.data[lo:hi], g.rank_of(pr, c)) for pr in range(g.nprows) if pr != r]
+                    else:
+                        recvs.append((self._b_all[self._b_base[v] + lo:self._b_base[v] + hi], b_own))
+            posted.append(self._exchange(sends, recvs))
+        nt = len(self._tiles)
+        engines = [self._engine(("tile", i)) for i in range(nt)]
+        # the structure of every strip of C needs the (replicated) index only: the symbolic phases run while the first batch travels
+        sym = [engines[i].symbolic(self._At[i], self._Bc[i], self._Cc[i], retain_sparsity=False) for i in range(nt)]
+        mg = self._merged
+        out_all = torch.empty(mg["nze"], dtype=self.dtype, device=self.device) if mg is not None else None
+        main = side = arr = None
+        if self.device.type == "cuda" and nt > 1 and self.colpipe_two_streams:
+            main = torch.cuda.current_stream()
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(device=self.device)
+            if self._arrival_stream is None:
+                self._arrival_stream = torch.cuda.Stream(device=self.device)
+            side, arr = self._side_stream, self._arrival_stream
+            side.wait_stream(main)   # the symbolic phases' results, and whatever used the output buffer's memory before
+            arr.wait_stream(main)
+        landed = []   # batch q has arrived: taken in on a stream of its own, so that neither multiply stream waits for the other's kernels
+        for q in range(nch):
+            if arr is not None:
+                with torch.cuda.stream(arr):
+                    self._arrived(*posted[q])
+                    ev = torch.cuda.Event()
+                    ev.record(arr)
+                landed.append(ev)
+            else:
+                landed.append(None)
+        taken = -1
+        parts, flop, nprod = [], 0, 0
+        for i, (q, rlo, rhi, clo, chi) in enumerate(self._tiles):
+            row_p, cnt = sym[i]
+            eng = self.last_engine = engines[i]
+            kw = {}
+            if out_all is not None and getattr(eng, "accepts_out_data", False):
+                kw["out_data"] = out_all[mg["off"][i]:mg["off"][i] + cnt.c_nze]
+            on_side = side is not None and clo > 0   # the column strips
+            with torch.cuda.stream(side if on_side else main) if main is not None else contextlib.nullcontext():
+                if arr is not None:
+                    (side if on_side else main).wait_event(landed[q])
+                else:
+                    while taken < q:
+                        taken += 1
+                        self._arrived(*posted[taken])
+                parts.append(eng.numeric_after_symbolic(alpha, self._At[i], self._Bc[i], beta, self._Cc[i], row_p, cnt, self.dtype, **kw))
+            flop += cnt.flop
+            nprod += cnt.nproducts
+            self._launched(eng, cnt.flop)
+        if arr is None:
+            while taken < nch - 1:   # (a batch no strip waited for: empty strips)
+                taken += 1
+                self._arrived(*posted[taken])
+        if side is not None:
+            main.wait_stream(side)
+            main.wait_stream(arr)
+            for i, Cq in enumerate(parts):
+                if self._tiles[i][3] > 0:   # made on the second stream, used by the caller on the first
+                    for t in (Cq.col_i, Cq.blk_p) + ((Cq.data,) if out_all is None else ()):
+                        if t.numel():
+                            t.record_stream(main)
+        counts = sym[0][1]
+        counts.flop, counts.nproducts = flop, nprod
+        counts.c_nblks, counts.c_nze = sum(int(x[1].c_nblks) for x in sym), sum(int(x[1].c_nze) for x in sym)
+        return self._merge_chunks(parts, out_all), counts
+
     def _merge_chunks(self, parts, out_all):
-        """The column chunks of C as ONE matrix of the local tile.  The patterns of a plan never change, so the merged index is made
+        """The column chunks (tilepipe: the strips) of C as ONE matrix of the local tile.  The patterns of a plan never change, so the merged index is made
         once; from the second multiply on the chunks were written straight into their slices of one buffer (no copy)."""
         if self._merged is None:
             rows_l, cols_l, off_l, base = [], [], [], 0
@@ -730,8 +861,8 @@ class CannonMultiply:
             for q, Cq in enumerate(parts):
                 rs, cs, row_p, col_i, blk_p, _ = DbcsrMatrix(Cq.row_blk_size, Cq.col_blk_size, Cq.row_p, Cq.col_i, Cq.blk_p, Cq.row_p[:0]).to_host()
                 rows = np.repeat(np.arange(len(rs), dtype=np.int64), np.diff(row_p))
-                rows_l.append(rows)
-                cols_l.append(col_i.astype(np.int64) + int(self._cbounds[q]))
+                rows_l.append(rows + self._origins[q][0])
+                cols_l.append(col_i.astype(np.int64) + self._origins[q][1])
                 off_l.append(blk_p.astype(np.int64) + base)
                 offs.append(base)
                 base += int(Cq.data.numel())
@@ -956,10 +1087,10 @@ class CannonMultiply:
                                                    filter_eps=filter_eps or 0.0)
             self._launched(self.eng, getattr(self.eng, "last_launch_flop", counts.flop))
             return Cout, counts
-        if self.mode in ("colpipe", "colpipe2d"):
-            if self._cbounds is None:
+        if self.mode in ("colpipe", "colpipe2d", "tilepipe"):
+            if self._cbounds is None or (self.mode == "tilepipe") != (self._rbounds is not None):
                 raise ValueError("CannonMultiply: mode '%s' must be chosen at construction (the images are laid out for it)" % self.mode)
-            return self._multiply_colpipe(alpha, beta)
+            return self._multiply_tilepipe(alpha, beta) if self.mode == "tilepipe" else self._multiply_colpipe(alpha, beta)
         if self.mode == "gather":
             return self._multiply_gather(alpha, beta)
         g, eng = self.grid, self.eng

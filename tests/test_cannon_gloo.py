@@ -67,14 +67,16 @@ def _worker(rank, world, port, alpha, beta, q, mode, retain=False, eps=None):
                                         (4, "ticks+dist"), (6, "gather+dist"), (2, "ticks+dist"), (8, "ticks"), (8, "gather+dist"),
                                         (2, "colpipe"), (3, "colpipe+given"), (4, "colpipe+dist"), (8, "colpipe"),
                                         # round 6: the column-chunk pipeline on the 2-D grid (2 x 2, 3 x 2, 4 x 2)
-                                        (4, "colpipe2d"), (6, "colpipe2d+given"), (8, "colpipe2d"), (4, "colpipe2d+dist")])
+                                        (4, "colpipe2d"), (6, "colpipe2d+given"), (8, "colpipe2d"), (4, "colpipe2d+dist"),
+                                        # ... and the row-chunk x column-chunk tile pipeline (A's images chunked too)
+                                        (4, "tilepipe"), (6, "tilepipe+given"), (8, "tilepipe"), (4, "tilepipe+dist"), (2, "tilepipe")])
 def test_cannon_matches_global_oracle(world, mode):
     _run_and_compare(world, mode)
 
 
 @pytest.mark.parametrize("world,mode,retain,eps", [(4, "gather", False, 60.0), (6, "ticks", False, 80.0), (4, "ticks+dist", True, None),
                                                   (2, "gather", True, 60.0), (3, "colpipe", False, 60.0), (2, "colpipe+dist", True, None),
-                                                  (4, "colpipe2d", False, 60.0)])
+                                                  (4, "colpipe2d", False, 60.0), (4, "tilepipe", False, 60.0), (6, "tilepipe", True, None)])
 def test_cannon_filter_and_retain_match_global_oracle(world, mode, retain, eps):
     """filter_eps / retain_sparsity on several ranks: every rank takes the decisions one rank would (row counts of the WHOLE block
     row enter the on-the-fly filter, dbcsr_mm_cannon.F:1040-1113), block structure and values equal the single-rank oracle's."""

@@ -25,7 +25,8 @@ def _free_port():
 
 @pytest.mark.parametrize("world,mode", [(2, "gather"), (2, "ticks"), (4, "ticks"), (4, "gather"), (4, "ticks+dist"), (2, "gather+dist"), (4, "gather+filter"), (2, "ticks+filter"), (8, "ticks"), (8, "gather+dist"),
                                         (2, "colpipe"), (4, "colpipe+dist"), (4, "colpipe+filter"), (8, "colpipe"),
-                                        (4, "colpipe2d"), (8, "colpipe2d"), (4, "colpipe2d+dist")])   # round 6: the column-chunk pipeline on the 2-D grid
+                                        (4, "colpipe2d"), (8, "colpipe2d"), (4, "colpipe2d+dist"),   # round 6: the column-chunk pipeline on the 2-D grid
+                                        (4, "tilepipe"), (8, "tilepipe"), (4, "tilepipe+dist"), (4, "tilepipe+filter")])   # ... and A's images in row chunks too
 def test_cannon_hip_engine_ranks_share_one_gpu(world, mode):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
@@ -35,7 +36,7 @@ def test_cannon_hip_engine_ranks_share_one_gpu(world, mode):
     assert "-> OK" in r.stdout, r.stdout[-2000:]
 
 
-@pytest.mark.parametrize("mode", ["gather", "ticks", "colpipe", "colpipe2d", "gather+dist"])
+@pytest.mark.parametrize("mode", ["gather", "ticks", "colpipe", "colpipe2d", "tilepipe", "gather+dist"])
 def test_cannon_native_transport_on_a_one_rank_communicator(mode):
     """every schedule with transport="native" on the one GPU of the box: librccl is loaded, a one-rank RCCL communicator is made, its
     self-test runs, the ranks' agreement on the transport goes through torch's communicator, and the schedule's exchange code runs with

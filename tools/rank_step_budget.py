@@ -25,9 +25,13 @@ def main():
     p.add_argument("--colpipe", type=int, default=0, help="N x 1 grid and the colpipe schedule with this many column chunks (its whole compute path, "
                                                           "exchange left out): kernel_ms is then the SUM over the chunk multiplies")
     p.add_argument("--colpipe2d", type=int, default=0, help="the same column-chunk pipeline on the default 2-D grid (round 6) with this many chunks")
+    p.add_argument("--tilepipe", type=int, default=0, help="the row-chunk x column-chunk tile pipeline on the 2-D grid with this many chunks per side: "
+                                                           "kernel_ms is the SUM over the strips, the per-strip times are printed too")
     a = p.parse_args()
     if a.colpipe2d:
         a.colpipe = a.colpipe2d
+    if a.tilepipe:
+        a.colpipe = a.tilepipe
     import bench
     from dbcsr_amd import cannon
     from dbcsr_amd.multiply import MultiplyEngine
@@ -37,9 +41,9 @@ def main():
     print("# ranks grid  C_blocks  products   GFLOP   wall_ms  kernel_ms  fill_ms  non_kernel_ms  kernel")
     for n in [int(x) for x in a.ranks.split(",")]:
         eng = MultiplyEngine()
-        g = cannon.Grid(n, 0, nprows=n, npcols=1) if (a.colpipe and not a.colpipe2d) else cannon.Grid(n, 0)
+        g = cannon.Grid(n, 0, nprows=n, npcols=1) if (a.colpipe and not a.colpipe2d and not a.tilepipe) else cannon.Grid(n, 0)
         plan = cannon.CannonMultiply(M, N, K, (1 - fill,) * 3, mix, dtype=dtype, engine=eng, grid=g,
-                                     mode="colpipe2d" if a.colpipe2d else ("colpipe" if a.colpipe else "gather"), col_chunks=max(1, a.colpipe))
+                                     mode="tilepipe" if a.tilepipe else "colpipe2d" if a.colpipe2d else ("colpipe" if a.colpipe else "gather"), col_chunks=max(1, a.colpipe))
         # images owned by other ranks: synthetic values in place (what would have arrived over xGMI)
         for buf in (plan._a_all, plan._b_all):
             buf.uniform_(0.0, 1.0)
@@ -55,11 +59,15 @@ def main():
             plan._exchange = lambda sends, recvs: ([], [])   # nothing travels here: the panels are in place
 
             def step():
-                return plan._multiply_colpipe(1.0, 1.0)
+                return plan.multiply(1.0, 1.0)
+
+            per_strip = []
 
             def kernel_time():
-                engines = [plan._engine(("col", q)) for q in range(len(plan._cbounds) - 1)]
+                engines = [plan._engine(("tile", i)) for i in range(len(plan._tiles))] if a.tilepipe else \
+                    [plan._engine(("col", q)) for q in range(len(plan._cbounds) - 1)]
                 t = [e.last_timing() for e in engines]
+                per_strip[:] = [round(x[1], 3) for x in t]
                 return sum(x[0] for x in t), sum(x[1] for x in t)
 
         for _ in range(3):
@@ -79,6 +87,9 @@ def main():
         km, fm = sum(ks) / len(ks), sum(fs) / len(fs)
         print("%7d %dx%d %9d %9d %8.1f %9.3f %9.3f %8.3f %12.3f   %s" % (n, g.nprows, g.npcols, counts.c_nblks, counts.nproducts, counts.flop / 1e9, wall, km,
                                                                        fm, wall - km, eng.last_kernel()))
+        if a.tilepipe:
+            print("#   strips (step, rows, columns): %s" % ", ".join("(%d, %d-%d, %d-%d)" % t for t in plan._tiles))
+            print("#   kernel ms per strip: %s" % per_strip)
         del plan, eng, out
         torch.cuda.empty_cache()
 

@@ -47,7 +47,7 @@ def main():
     for _ in range(2):
         Cout, counts = plan.multiply(0.5, 2.0, filter_eps=eps) if eps else plan.multiply(0.5, 2.0)
     torch.cuda.synchronize()
-    if plan.mode in ("colpipe", "colpipe2d") and not eps:   # the chunks of the second multiply went straight into their slices of one buffer
+    if plan.mode in ("colpipe", "colpipe2d", "tilepipe") and not eps:   # the chunks of the second multiply went straight into their slices of one buffer
         assert plan.colpipe_copies == 1, plan.colpipe_copies
     parts = plan.gather_global(Cout)
     fl = torch.tensor([counts.flop], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")

@@ -15,12 +15,19 @@ WORKLOADS = {
         one_gpu=18.90, a_gb=0.859, b_gb=0.859, c_gb_per_rank={2: 4.3, 4: 2.15, 8: 1.07},
         gather={2: 9.71, 4: 4.91, 8: 2.65},          # rank 0's whole multiply, default grid (2x1, 2x2, 4x2)
         colpipe8={2: 10.28, 4: 5.38, 8: 2.92},       # N x 1 grid, eight column chunks on two streams, panels in place
-        colpipe2d={4: 5.35, 8: 2.82}),               # 2-D grid (2x2, 4x2), column chunks of the rank's own block columns (round 6)
+        colpipe2d={4: 5.35, 8: 2.82},                # 2-D grid (2x2, 4x2), column chunks of the rank's own block columns (round 6)
+        # tile pipeline on the 2-D grid, S chunks per side (session r06_33): wall of the rank's step alone on the device, kernel ms of step 0 .. S - 1 (row + column strip)
+        tilepipe={4: {4: (5.313, [0.356, 1.012, 1.63, 2.518]), 6: (6.167, [0.197, 0.507, 0.743, 1.043, 1.354, 1.877])},
+                  8: {4: (2.974, [0.191, 0.533, 0.871, 1.484]), 6: (3.027, [0.099, 0.306, 0.433, 0.574, 0.729, 1.235]),
+                      8: (3.159, [0.067, 0.189, 0.288, 0.376, 0.453, 0.548, 0.641, 1.095])}}),
     "config4_131072_23x23_fill1_fp64": dict(
         one_gpu=22.35, a_gb=1.374, b_gb=1.374, c_gb_per_rank={2: 30.3, 4: 15.2, 8: 7.6},
         gather={2: 11.13, 4: 5.69, 8: 2.96},
         colpipe8={2: 11.31, 4: 5.75, 8: 3.10},
-        colpipe2d={4: 5.78, 8: 2.97}),
+        colpipe2d={4: 5.78, 8: 2.97},
+        tilepipe={4: {4: (6.16, [0.418, 1.788, 3.124, 3.784]), 6: (6.265, [0.182, 0.52, 1.123, 1.634, 2.449, 3.001])},
+                  8: {4: (3.256, [0.207, 0.655, 1.121, 1.775]), 6: (3.281, [0.094, 0.279, 0.445, 0.618, 0.776, 1.112]),
+                      8: (3.389, [0.056, 0.201, 0.279, 0.359, 0.473, 0.558, 0.636, 0.755])}}),
 }
 GRID = {2: (2, 1), 4: (2, 2), 8: (4, 2)}
 HBM_TBS = 5.0   # read + write of C in an in-place pass
@@ -50,6 +57,20 @@ def model(w, n, link):
         t_a = w["a_gb"] / n / link * 1e3
         t_chunk = w["b_gb"] / n / 8 / link * 1e3
         out["colpipe2d (8 chunks)"] = max(t_a, t_chunk) + max(cp2, 8 * t_chunk)
+    tp = w.get("tilepipe", {}).get(n)
+    if tp and pc > 1:
+        # batch s = row chunk s of the A images a rank misses (a_gb / n / S from each row peer, one link each) next to column chunk s of B's images (b_gb / n / S per
+        # column peer, other links): lands at (s + 1) * t_chunk; step s (its two strips share the device: the step's share of the measured wall) starts when batch s has
+        # landed and step s - 1 is done
+        best = None
+        for S, (wall, steps) in tp.items():
+            t_chunk = max(w["a_gb"], w["b_gb"]) / n / S / link * 1e3
+            scale, t = wall / sum(steps), 0.0
+            for q, k in enumerate(steps):
+                t = max(t, (q + 1) * t_chunk) + k * scale
+            if best is None or t < best[0]:
+                best = (t, S)
+        out["tilepipe (%d chunks)" % best[1]] = best[0]
     return out
 
 
