@@ -199,7 +199,7 @@ def test_random_triplets_and_stacks_exact(seed):
     """(off by default: set DBCSR_AMD_SWEEP_STACKS=N; 120 seeds run on MI355X in round 3, tools/gpu_sessions/r03_27_stack_sweeps.sh.)  libsmm_acc_process on random (m, n, k) up to 45 (beyond
     32: the direct kernel), random stack lengths around the group sizes and c offsets sorted, binned or shuffled: integer-valued inputs, so
     the result must be EXACT whatever the summation order."""
-    rng = np.random.default_rng(900 + seed)
+    rng = np.random.default_rng(900 + seed + int(__import__("os").environ.get("DBCSR_AMD_SWEEP_OFFSET", "0")))
     m, n, k = (int(x) for x in rng.integers(1, 46, size=3))
     if seed % 4 == 0:   # the LDS-staged range
         m, n, k = (int(x) for x in rng.integers(1, 33, size=3))

@@ -18,8 +18,12 @@ pytestmark = pytest.mark.gpu
 MIXES = [[1, 23], [1, 13, 1, 23, 1, 32], [1, 5], [1, 4], [1, 32], [2, 7, 1, 32], [1, 1, 1, 3], [1, 16, 1, 8], [3, 9, 1, 2], [1, 29, 1, 31]]
 
 
+# a soak with cases no earlier walk has seen: DBCSR_AMD_SWEEP_OFFSET shifts every generator seed
+SWEEP_OFFSET = int(os.environ.get("DBCSR_AMD_SWEEP_OFFSET", "0"))
+
+
 def make_case(seed):
-    rng = np.random.default_rng(seed)
+    rng = np.random.default_rng(seed + SWEEP_OFFSET)
     mix_m, mix_n, mix_k = (MIXES[int(rng.integers(len(MIXES)))] for _ in range(3))
     symm_c = "N" if rng.random() < 0.8 else ("S" if rng.random() < 0.7 else "A")
     if symm_c != "N":
@@ -68,7 +72,7 @@ MID_MIXES = [[1, 33], [1, 36], [1, 40], [1, 37, 1, 34], [3, 35, 1, 8], [1, 39, 1
 
 
 def make_big_case(seed, mixes=BIG_MIXES, k_mixes=BIG_MIXES):
-    rng = np.random.default_rng(seed)
+    rng = np.random.default_rng(seed + SWEEP_OFFSET)
     mix_m, mix_n = (mixes[int(rng.integers(len(mixes)))] for _ in range(2))
     mix_k = k_mixes[int(rng.integers(len(k_mixes)))]
     symm_c = "N" if rng.random() < 0.85 else ("S" if rng.random() < 0.7 else "A")
