@@ -41,6 +41,7 @@
 #include "mm_symbolic.h"
 #include "mm_numeric_f64.h"
 #include "mm_numeric_f64_big.h"
+#include "mm_numeric_f64_small.h"
 #include "mm_mid.h"   // the one-wave slab kernels of the blocks of 25 ... 40 (mm_numeric_f64_mid.h, mm_mid.hip)
 #include "mm_numeric_f32.h"
 #include "mm_aux.h"
@@ -497,15 +498,19 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
     const int dm = dom ? E->hot_m : (all_in ? E->max_m : 0), dn = dom ? E->hot_n : (all_in ? E->max_n : 0);
     if (dm > 0 && dn > 0 && mid_f64_serves(dm, dn, 0)) mid_rb = (dm + 3) / 4, mid_cb = (dn + 3) / 4;
   }
+  // every block dimension at most 8 (and not the packed 4 x 4 case): one 8 x 8 tile per wave, several products in flight (mm_numeric_f64_small.h)
+  const bool tiny4 = E->use_tiny && E->max_m <= 4 && E->max_n <= 4;
+  const bool small8 = datatype == dbcsr_type_real_8 && E->use_small > 0 && E->use_lds && !tiny4 && E->max_m <= 8 && E->max_n <= 8 && E->max_k <= 8 && E->min_m >= 1 &&
+                      E->min_n >= 1 && E->min_k >= 1 && !(E->dbg & ~32) && !E->dma_stages && !E->hot_persistent && E->hot_variant == 0 && E->use_pipe != 1;
   const Work* hot_work = nullptr;
   {
     const bool small64 = datatype == dbcsr_type_real_8 && E->use_lds && E->max_m <= 32 && E->max_k <= 32 && E->max_n <= 32 && E->min_m >= 1 &&
-                         E->min_k >= 1 && E->min_n >= 1 && !(E->use_tiny && E->max_m <= 4 && E->max_n <= 4);
+                         E->min_k >= 1 && E->min_n >= 1 && !tiny4 && !small8;
     // (the ahead-of-time exact-size kernel reads nothing else; the class kernels keep the order[] -> descs[] path for DBCSR_AMD_MM_WORK=0)
     const bool exact = E->cls_mode ? (E->class_g == 1 && E->use_work)
                                    : (E->use_hot && E->use_pipe != 1 && E->hot_m > 0 && E->dma_stages == 0 && E->hot_m == E->hot_n && E->hot_m == E->hot_k);
     const int64_t npos = 8 * E->order_len;
-    if (((small64 && exact) || mid_rb) && npos > 0) {
+    if (((small64 && exact) || mid_rb || (small8 && E->use_work)) && npos > 0) {
       if (!(reuse && E->work_built)) {
         if (E->work.ensure((size_t)npos + 1)) return -1;
         hipLaunchKernelGGL(build_work, grid_for(npos), dim3(256), 0, st, E->order.p, npos, E->descs.p, nblk, E->entries.p, E->work.p);
@@ -518,7 +523,7 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
   // then skips its pass over C)
   double* epi_norms = nullptr;
   E->norms_data = nullptr;
-  if ((hot_work || (E->cls_mode && E->class_g == 1)) && datatype == dbcsr_type_real_8 && E->filter.a_norms && !skip_empty && !E->retain) {
+  if ((hot_work || (E->cls_mode && E->class_g == 1)) && !small8 && datatype == dbcsr_type_real_8 && E->filter.a_norms && !skip_empty && !E->retain) {
     if (E->norms64.ensure((size_t)nblk + 1)) return -1;
     epi_norms = E->norms64.p;
     if (E->dbg & 8) epi_norms = nullptr;  // (profiling epilogue of the exact-size kernel: it leaves no norms, the filter then computes them)
@@ -539,6 +544,19 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
       if (nwg_t > 0) {
         auto tiny = E->max_k > 4 ? mm_numeric_f64_tiny<false> : mm_numeric_f64_tiny<true>;
         hipLaunchKernelGGL(tiny, dim3(nwg_t), dim3(256), 0, st, E->descs.p, nblk, E->entries.p, ad, bd, cd, cid, alpha, beta, skip_empty, E->order.p);
+      }
+    } else if (small8) {
+      const unsigned nwg_s = (unsigned)(8 * E->order_len / 4);
+      const int depth = E->use_small == 3 || E->use_small == 4 || E->use_small == 6 || E->use_small == 8 ? E->use_small : 2;
+      snprintf(E->last_kernel, sizeof E->last_kernel, "mm_numeric_f64_small<%d>", depth);
+      if (nwg_s > 0) {
+        auto kern = hot_work ? (depth == 2 ? mm_numeric_f64_small<2, true> : depth == 3 ? mm_numeric_f64_small<3, true> : depth == 4 ? mm_numeric_f64_small<4, true> :
+                                depth == 6 ? mm_numeric_f64_small<6, true> : mm_numeric_f64_small<8, true>)
+                             : (depth == 2 ? mm_numeric_f64_small<2, false> : depth == 3 ? mm_numeric_f64_small<3, false> : depth == 4 ? mm_numeric_f64_small<4, false> :
+                                depth == 6 ? mm_numeric_f64_small<6, false> : mm_numeric_f64_small<8, false>);
+        hipLaunchKernelGGL(kern, dim3(nwg_s), dim3(256), 0, st, E->descs.p, nblk, E->entries.p, static_cast<const double*>(a->data),
+                           static_cast<const double*>(b->data), static_cast<double*>(c_out->data), static_cast<const double*>(c_in->data), alpha, beta,
+                           skip_empty, E->order.p, hot_work);
       }
     } else if (mid_rb && launch_mid_f64(mid_rb, mid_cb, E->min_m != E->max_m || E->min_n != E->max_n, (unsigned)(8 * E->order_len), st, E->descs.p, nblk,
                                          E->entries.p, static_cast<const double*>(a->data), static_cast<const double*>(b->data),

@@ -69,6 +69,7 @@ struct Engine {
   bool crop_pending = false;
   int hot_m = 0, hot_n = 0, hot_k = 0;  // dominant block sizes of the last symbolic phase (0: none)
   int use_tiny = 1;                     // DBCSR_AMD_MM_TINY=0: no packed kernel for blocks of at most 4 x 4
+  int use_small = 2;                    // DBCSR_AMD_MM_SMALL=0: no one-tile kernel for multiplies whose block dimensions are all <= 8 (mm_numeric_f64_small.h); 2 (default) / 3 / 4 / 6 / 8: products in flight per wave
   int use_hot = 1;                      // DBCSR_AMD_MM_HOT=0: never use the exact-size kernels
   int lds_pad = 0;                      // DBCSR_AMD_MM_LDS_PAD: extra LDS bytes per workgroup (occupancy experiments)
   int64_t panel_bytes = 256ll << 20;  // DBCSR_AMD_MM_PANEL_MB: target size of a B column panel (config 2, round 3: 160 / 200 / 256 / 320 / 400 MB ->
