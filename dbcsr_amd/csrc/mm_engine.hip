@@ -18,6 +18,7 @@
 // zero-fill pass, bitwise reproducible).  Kernels, chosen per launch by the host code at the end of this file:
 //   mm_numeric_f64_hot<M,N,K> / mm_numeric_f32_hot<M,N,K>  exact-size kernels, one (m, n, k) dominates (cubes 9..32)
 //   mm_numeric_f64_tiny                                    C blocks of at most 4 x 4: four C blocks per wave
+//   mm_numeric_f64_small<D>                                every block dimension at most 8: one 8 x 8 tile per wave, whole blocks per 8-byte load (mm_numeric_f64_small.h)
 //   mm_numeric_f64_lds<MAXT> / mm_numeric_f64_pipe<MAXT>   any sizes up to 32 (pipe: mixed sizes, few products per block)
 //   mm_numeric_f32_lds                                     fp32, any sizes up to 32
 //   mm_numeric_f64 / mm_numeric_f32                        blocks above 32 (32 x 32 tiles, fragments from global memory)
