@@ -502,7 +502,7 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
   // every block dimension at most 8 (and not the packed 4 x 4 case): one 8 x 8 tile per wave, several products in flight (mm_numeric_f64_small.h)
   const bool tiny4 = E->use_tiny && E->max_m <= 4 && E->max_n <= 4;
   const bool small8 = datatype == dbcsr_type_real_8 && E->use_small > 0 && E->use_lds && !tiny4 && E->max_m <= 8 && E->max_n <= 8 && E->max_k <= 8 && E->min_m >= 1 &&
-                      E->min_n >= 1 && E->min_k >= 1 && !(E->dbg & ~32) && !E->dma_stages && !E->hot_persistent && E->hot_variant == 0 && E->use_pipe != 1;
+                      E->min_n >= 1 && E->min_k >= 1 && !(E->dbg & ~32) && !E->dma_stages && !E->hot_persistent && E->hot_variant == 0 && E->use_pipe < 0;  // (DBCSR_AMD_MM_KERNEL=lds1 | pipe ask for those kernels)
   const Work* hot_work = nullptr;
   {
     const bool small64 = datatype == dbcsr_type_real_8 && E->use_lds && E->max_m <= 32 && E->max_k <= 32 && E->max_n <= 32 && E->min_m >= 1 &&
