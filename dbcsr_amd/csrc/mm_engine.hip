@@ -134,7 +134,7 @@ int dbcsr_amd_mm_destroy(void* handle) {
   E->plan_words.release(); E->plan_c_col_i.release(); E->plan_c_blk_p.release(); E->plan_flag.release(); E->work.release();
   if (E->cls_host_hist) (void)hipHostFree(E->cls_host_hist);
   if (E->cls_host_lens) (void)hipHostFree(E->cls_host_lens);
-  E->cls_hist.release(); E->cls_row.release(); E->cls_col.release(); E->cls_col_bm.release(); E->cls_lens.release();
+  E->cls_hist.release(); E->cls_row.release(); E->cls_col.release(); E->cls_col_bm.release(); E->cls_lens.release(); E->cls_vpos.release(); E->cls_vrow.release();
   for (int i = 0; i < 3; ++i)
     if (E->ev[i]) (void)hipEventDestroy(E->ev[i]);
   for (int i = 0; i < 3; ++i) {
@@ -353,12 +353,13 @@ int dbcsr_amd_mm_symbolic_filtered(void* handle, libsmm_acc_data_t datatype, dou
   if (E->order_cnt.ensure((size_t)nkeys + 1) || E->order_base.ensure((size_t)nkeys + 1)) return -1;
   if (E->cls_mode) {
     if (E->cls_row.ensure((size_t)nbr + 1) || E->cls_col.ensure((size_t)nbc + 1) || E->cls_col_bm.ensure((size_t)4 * W + 1) ||
-        E->cls_lens.ensure(2 * kNumClasses + 1))
+        E->cls_lens.ensure(2 * kNumClasses + 1) || E->cls_vpos.ensure((size_t)nbr + 1) || E->cls_vrow.ensure((size_t)nbr + 1))
       return -1;
     hipLaunchKernelGGL(class_ids, grid_for(nbr), dim3(256), 0, st, a->row_blk_size, nbr, E->cls_m[0], E->cls_m[1], E->cls_m[2], E->cls_row.p);
     hipLaunchKernelGGL(class_ids, grid_for(nbc), dim3(256), 0, st, b->col_blk_size, nbc, E->cls_n[0], E->cls_n[1], E->cls_n[2], E->cls_col.p);
     hipLaunchKernelGGL(class_col_bitmaps, grid_for(W), dim3(256), 0, st, E->cls_col.p, nbc, W, E->cls_col_bm.p);
-    hipLaunchKernelGGL(order_count_cls, grid_for(nkeys), dim3(256), 0, st, E->c_bm.p, E->cls_row.p, E->cls_col_bm.p, nbr, W, PW, NP, R,
+    hipLaunchKernelGGL(class_row_deal, dim3(1), dim3(256), 0, st, E->cls_row.p, nbr, E->cls_vpos.p, E->cls_vrow.p);
+    hipLaunchKernelGGL(order_count_cls, grid_for(nkeys), dim3(256), 0, st, E->c_bm.p, E->cls_row.p, E->cls_col_bm.p, E->cls_vrow.p, nbr, W, PW, NP, R,
                        E->order_cnt.p);
     if (exclusive_scan<int64_t>(E, E->order_cnt.p, nkeys, E->order_base.p, nullptr, false, st)) return -1;
     hipLaunchKernelGGL(order_len_cls, dim3(1), dim3(1), 0, st, E->order_base.p, c_nblks, NP, R, E->cls_lens.p);
@@ -409,7 +410,7 @@ int dbcsr_amd_mm_symbolic_filtered(void* handle, libsmm_acc_data_t datatype, dou
     if (total > 0) {
       ACC_CHECK(hipMemsetAsync(E->order.p, 0xff, sizeof(int) * ((size_t)total + 64), st));
       hipLaunchKernelGGL(order_fill_cls, grid_for((int64_t)nbr * W), dim3(256), 0, st, E->c_bm.p, E->c_pre.p, c_out_row_p, E->cls_row.p,
-                         E->cls_col_bm.p, E->order_base.p, E->cls_lens.p, nbr, W, PW, NP, R, E->order.p);
+                         E->cls_col_bm.p, E->order_base.p, E->cls_lens.p, E->cls_vpos.p, nbr, W, PW, NP, R, E->order.p);
     }
   } else {
   if (E->order.ensure((size_t)(8 * E->order_len) + 64)) return -1;

@@ -156,6 +156,7 @@ struct Engine {
   int64_t cls_len[kNumClasses] = {0}, cls_off[kNumClasses] = {0};
   DevBuf<int> cls_hist;
   DevBuf<unsigned char> cls_row, cls_col;
+  DevBuf<int> cls_vpos, cls_vrow;   // class mode: the rows numbered again class after class (class_row_deal, mm_symbolic.h) and the inverse
   DevBuf<uint32_t> cls_col_bm;
   DevBuf<int64_t> cls_lens;
   int* cls_host_hist = nullptr;       // pinned: 3 x 33 size histograms

@@ -655,7 +655,7 @@ __global__ void order_len(const int64_t* __restrict__ base, int64_t total, int N
 // kernel compiled for its (m, n, k).  Here a C block is the unit of work, so C blocks are bucketed by (m, n): class
 // c = 3 * rank(m) + rank(n) for the three most common row and column block sizes (ranks 0..2), class 9 = everything else.
 // order[] becomes ten segments, each laid out like the single list of the other kernels (eight XCD streams padded to a
-// common length, column panels, row i on XCD i mod 8), and each segment is one launch of the kernel for its class.
+// common length, column panels, the rows of a row class dealt to the XCDs in turn: class_row_deal), and each segment is one launch of the kernel for its class.
 // ----------------------------------------------------------------------------
 constexpr int kNumClasses = 10;
 
@@ -699,16 +699,57 @@ __device__ __forceinline__ uint32_t class_mask(int cls, int rc, const uint32_t* 
   return rc == 3 ? 0xffffffffu : ncls_bm[(size_t)3 * W + w];
 }
 
-// key = ((cls * 8 + x) * NP + p) * R + g : the C blocks of class cls in row i = 8 g + x inside column panel p
+// Rows dealt to the XCDs class by class (round 6): with "row i on XCD i mod 8" a size pattern whose period divides 8 -- two atom kinds alternating: 5, 13,
+// 5, 13 ... -- puts every row class on HALF of the XCDs, and each class launch then runs on half of the chip (measured: 9.4 ms where the run-time-size
+// kernel, one launch over all rows, takes 7.2).  The rows are numbered again, class after class in row order (vpos[i] = virtual row of row i,
+// vrow[] its inverse); virtual row j goes to XCD j mod 8, so the rows of every class are spread over all eight.  One workgroup.
+__global__ void __launch_bounds__(256) class_row_deal(const unsigned char* __restrict__ rowcls, int nbr, int* __restrict__ vpos, int* __restrict__ vrow) {
+  __shared__ int cnt[256][4];
+  __shared__ int cls_off[4];
+  const int t = threadIdx.x, chunk = (nbr + 255) / 256, i0 = t * chunk, i1 = min(nbr, i0 + chunk);
+  int c[4] = {0, 0, 0, 0};
+  for (int i = i0; i < i1; ++i) ++c[rowcls[i]];
+  for (int q = 0; q < 4; ++q) cnt[t][q] = c[q];
+  __syncthreads();
+  if (t < 4) {  // exclusive prefix of class t over the threads
+    int run = 0;
+    for (int u = 0; u < 256; ++u) {
+      const int v = cnt[u][t];
+      cnt[u][t] = run;
+      run += v;
+    }
+    cls_off[t] = run;  // (total of the class, for now)
+  }
+  __syncthreads();
+  if (t == 0) {
+    int run = 0;
+    for (int q = 0; q < 4; ++q) {
+      const int v = cls_off[q];
+      cls_off[q] = run;
+      run += v;
+    }
+  }
+  __syncthreads();
+  int at[4];
+  for (int q = 0; q < 4; ++q) at[q] = cls_off[q] + cnt[t][q];
+  for (int i = i0; i < i1; ++i) {
+    const int j = at[rowcls[i]]++;
+    vpos[i] = j;
+    vrow[j] = i;
+  }
+}
+
+// key = ((cls * 8 + x) * NP + p) * R + g : the C blocks of class cls in row i = vrow[8 g + x] inside column panel p
 __global__ void __launch_bounds__(256) order_count_cls(const uint32_t* __restrict__ c_bm, const unsigned char* __restrict__ rowcls,
-                                                       const uint32_t* __restrict__ ncls_bm, int nbr, int W, int PW, int NP, int R,
+                                                       const uint32_t* __restrict__ ncls_bm, const int* __restrict__ vrow, int nbr, int W, int PW, int NP, int R,
                                                        int* __restrict__ cnt) {
   const int key = blockIdx.x * blockDim.x + threadIdx.x;
   if (key >= kNumClasses * 8 * NP * R) return;
   const int g = key % R, p = (key / R) % NP, x = (key / (R * NP)) % 8, cls = key / (R * NP * 8);
-  const int i = 8 * g + x;
+  const int j = 8 * g + x;
   int c = 0;
-  if (i < nbr) {
+  if (j < nbr) {
+    const int i = vrow[j];
     const int rc = rowcls[i];
     const int w1 = min(W, (p + 1) * PW);
     for (int w = p * PW; w < w1; ++w) c += __popc(c_bm[(size_t)i * W + w] & class_mask(cls, rc, ncls_bm, W, w));
@@ -738,14 +779,15 @@ __global__ void order_len_cls(const int64_t* __restrict__ base, int64_t total, i
 __global__ void __launch_bounds__(256) order_fill_cls(const uint32_t* __restrict__ c_bm, const int* __restrict__ c_pre,
                                                       const int* __restrict__ c_row_p, const unsigned char* __restrict__ rowcls,
                                                       const uint32_t* __restrict__ ncls_bm, const int64_t* __restrict__ base,
-                                                      const int64_t* __restrict__ lens, int nbr, int W, int PW, int NP, int R,
-                                                      int* __restrict__ order) {
+                                                      const int64_t* __restrict__ lens, const int* __restrict__ vpos, int nbr, int W, int PW, int NP,
+                                                      int R, int* __restrict__ order) {
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= (int64_t)nbr * W) return;
   const int i = (int)(tid / W), w = (int)(tid % W);
   uint32_t v = c_bm[tid];
   if (!v) return;
-  const int x = i & 7, g = i >> 3, p = w / PW, rc = rowcls[i];
+  const int j = vpos[i];  // (class_row_deal: the row's place among the rows of its class decides its XCD)
+  const int x = j & 7, g = j >> 3, p = w / PW, rc = rowcls[i];
   // blocks of each column class that precede word w inside the panel (class 9 of a row whose own size is unranked: all of them)
   int before[4] = {0, 0, 0, 0};
   for (int ww = p * PW; ww < w; ++ww) {
