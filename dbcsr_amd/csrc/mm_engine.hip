@@ -307,8 +307,11 @@ int dbcsr_amd_mm_symbolic_filtered(void* handle, libsmm_acc_data_t datatype, dou
   // (m, n) classes: blocks of at most 32 in every dimension, no single dominant size (that case has its ahead-of-time
   // kernel), not the packed 4 x 4 case, and enough C blocks to pay for compiling the class kernels (forced with
   // DBCSR_AMD_MM_CLASSES=2)
+  // (a dominant triplet that is NOT a cube of 9 ... 32 has no ahead-of-time kernel: uniform rectangular blocks -- 5 x 13 x 23, 23 x 23 x 5 -- took the
+  //  run-time-size kernel until round 6, session 43; they are one class with one inner size)
+  const bool hot_cube = E->hot_m >= 9 && E->hot_m == E->hot_n && E->hot_m == E->hot_k;
   if (E->use_classes > 0 && E->max_m <= 32 && E->max_k <= 32 && E->max_n <= 32 && E->min_m >= 1 && E->min_k >= 1 && E->min_n >= 1 &&
-      !(E->max_m <= 4 && E->max_n <= 4) && (E->use_classes > 1 || (E->hot_m == 0 && c_nblks >= 200000))) {
+      !(E->max_m <= 4 && E->max_n <= 4) && (E->use_classes > 1 || (!hot_cube && c_nblks >= 200000))) {
     auto top3 = [](const int* hist, int* out) {
       int used[3] = {-1, -1, -1};
       for (int r = 0; r < 3; ++r) {

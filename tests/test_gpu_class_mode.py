@@ -1,0 +1,57 @@
+"""When the (m, n)-class kernels (run-time compiled exact-size kernels, one launch per class: the reference compiles one kernel per (m, n, k) too,
+src/acc/libsmm_acc/libsmm_acc.cpp:90-195) are chosen WITHOUT being forced, on multiplies with at least 200 000 C blocks -- round 6:
+  * uniform RECTANGULAR triplets (a dominant (m, n, k) that is not a cube has no ahead-of-time kernel: one class with one inner size),
+  * two block sizes ALTERNATING (a size pattern whose period divides 8: the rows of a class are dealt to the XCDs class by class, mm_symbolic.h: class_row_deal),
+  * a cube of 9 ... 32 keeps its ahead-of-time kernel, a cube below 9 the one-tile kernel.
+Against the CPU oracle: index bit-exact, flop equal, values 1e-10 relative."""
+import numpy as np
+import pytest
+import torch
+
+from dbcsr_amd.multiply import MultiplyEngine, dbcsr_multiply
+from oracle import oracle as O
+from tests.gpu_util import dev_to_bcsr, rel_err, to_dev
+
+pytestmark = pytest.mark.gpu
+
+ENV = ("DBCSR_AMD_MM_KERNEL", "DBCSR_AMD_MM_HOT", "DBCSR_AMD_MM_TINY", "DBCSR_AMD_MM_SYMBOLIC", "DBCSR_AMD_MM_CLASSES", "DBCSR_AMD_MM_WG_WAVES",
+       "DBCSR_AMD_MM_SMALL", "DBCSR_AMD_MM_KCHUNKS", "DBCSR_AMD_MM_WORK", "DBCSR_AMD_MM_MID", "DBCSR_AMD_MM_BIG")
+
+# (M, N, K, sparsity A, B, C, mix m, mix n, mix k), expected kernel (prefix)
+CASES = {
+    "2x9x3": ((2 * 470, 9 * 450, 3 * 100, 0.7, 0.7, 0.5, [1, 2], [1, 9], [1, 3]), "mm_numeric_f64_class[1 jit + 0 generic"),
+    "13x5x23": ((13 * 470, 5 * 450, 23 * 40, 0.6, 0.6, 0.5, [1, 13], [1, 5], [1, 23]), "mm_numeric_f64_class[1 jit + 0 generic"),
+    "9x32x9_tails": ((9 * 470 + 4, 32 * 450 + 7, 9 * 60 + 5, 0.6, 0.6, 0.5, [1, 9], [1, 32], [1, 9]), "mm_numeric_f64_class["),
+    "alternating_5_13": ((18 * 240, 18 * 235, 18 * 25, 0.6, 0.6, 0.5, [1, 5, 1, 13], [1, 5, 1, 13], [1, 5, 1, 13]), "mm_numeric_f64_class[4 jit + 0 generic"),
+    "period_4": ((28 * 120, 28 * 118, 28 * 14, 0.6, 0.6, 0.5, [1, 5, 1, 9, 1, 5, 1, 9], [1, 9, 1, 5], [1, 5, 2, 9, 1, 5]), "mm_numeric_f64_class[4 jit + 0 generic"),
+    "alternating_3_13_rows_only": ((16 * 250, 7 * 480, 11 * 40, 0.6, 0.6, 0.5, [1, 3, 1, 13], [1, 7], [1, 11]), "mm_numeric_f64_class[2 jit + 0 generic"),
+    "cube_13": ((13 * 470, 13 * 450, 13 * 60, 0.6, 0.6, 0.5, [1, 13], [1, 13], [1, 13]), "mm_numeric_f64_hot<13,13,13>"),
+    "cube_6": ((6 * 470, 6 * 450, 6 * 100, 0.7, 0.7, 0.5, [1, 6], [1, 6], [1, 6]), "mm_numeric_f64_small<2>"),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_class_mode_is_chosen_and_matches_oracle(monkeypatch, name):
+    for k in ENV:
+        monkeypatch.delenv(k, raising=False)
+    case, expect = CASES[name]
+    A, B, Cm = O.perf_case(*case)
+    alpha, beta = 0.6, 1.4
+    ref, info = O.multiply("N", "N", alpha, A, B, beta, Cm)
+    assert ref.nblks >= 200000, ref.nblks   # (the case must reach the threshold the engine applies)
+    eng = MultiplyEngine()
+    dA, dB, dC = to_dev(A), to_dev(B), to_dev(Cm)
+    flop = [0]
+    dbcsr_multiply("N", "N", alpha, dA, dB, beta, dC, flop=flop, engine=eng)
+    torch.cuda.synchronize()
+    assert eng.last_kernel().startswith(expect), (eng.last_kernel(), expect)
+    assert flop[0] == info["flop"]
+    out = dev_to_bcsr(dC)
+    assert np.array_equal(out.row_p, ref.row_p) and np.array_equal(out.col_i, ref.col_i) and np.array_equal(out.blk_p, ref.blk_p)
+    assert rel_err(out.data, ref.data) <= 1e-10
+    # the same plan again, in place (skip_empty) -- the launch order is reused
+    ref2, _ = O.multiply("N", "N", -0.5, A, B, 1.0, ref, retain_sparsity=True)
+    dbcsr_multiply("N", "N", -0.5, dA, dB, 1.0, dC, retain_sparsity=True, engine=eng)
+    torch.cuda.synchronize()
+    out2 = dev_to_bcsr(dC)
+    assert np.array_equal(out2.col_i, ref2.col_i) and rel_err(out2.data, ref2.data) <= 1e-10
