@@ -55,3 +55,43 @@ def test_class_mode_is_chosen_and_matches_oracle(monkeypatch, name):
     torch.cuda.synchronize()
     out2 = dev_to_bcsr(dC)
     assert np.array_equal(out2.col_i, ref2.col_i) and rel_err(out2.data, ref2.data) <= 1e-10
+
+
+def test_jit_cache_directory_is_filled_and_used(tmp_path):
+    """DBCSR_AMD_JIT_CACHE=<dir>: the first process compiles the class kernels and leaves their code objects there, the second loads them (no hiprtc
+    compile: its log says so), a truncated file is compiled again and written over; the results of all three agree with the oracle."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import numpy as np, torch\n"
+        "from dbcsr_amd.multiply import MultiplyEngine, dbcsr_multiply\n"
+        "from oracle import oracle as O\n"
+        "from tests.gpu_util import dev_to_bcsr, rel_err, to_dev\n"
+        "A, B, Cm = O.perf_case(18 * 30, 18 * 28, 18 * 12, 0.5, 0.5, 0.5, [1, 5, 1, 13], [1, 13, 1, 5], [1, 5, 1, 13])\n"
+        "ref, info = O.multiply('N', 'N', 1.0, A, B, 1.0, Cm)\n"
+        "eng = MultiplyEngine(); dA, dB, dC = to_dev(A), to_dev(B), to_dev(Cm)\n"
+        "dbcsr_multiply('N', 'N', 1.0, dA, dB, 1.0, dC, engine=eng); torch.cuda.synchronize()\n"
+        "out = dev_to_bcsr(dC)\n"
+        "assert eng.last_kernel().startswith('mm_numeric_f64_class[4 jit'), eng.last_kernel()\n"
+        "assert np.array_equal(out.col_i, ref.col_i) and rel_err(out.data, ref.data) <= 1e-10\n"
+        "print('multiply ok')\n")
+    env = dict(os.environ, DBCSR_AMD_JIT_CACHE=str(tmp_path), DBCSR_AMD_MM_CLASSES="2", DBCSR_AMD_MM_VERBOSE="1", PYTHONPATH=root)
+
+    def run():
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "multiply ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+        return r.stderr
+
+    log1 = run()
+    files = sorted(p for p in os.listdir(tmp_path) if p.endswith(".co"))
+    assert len(files) == 4 and log1.count("compiled class kernel") == 4 and " from " + str(tmp_path) not in log1, (files, log1[-1500:])
+    log2 = run()
+    assert log2.count("compiled class kernel") == 0 and log2.count(" from " + str(tmp_path)) == 4, log2[-1500:]
+    victim = os.path.join(tmp_path, files[0])
+    with open(victim, "r+b") as f:
+        f.truncate(100)
+    log3 = run()
+    assert log3.count("compiled class kernel") == 1 and log3.count(" from " + str(tmp_path)) == 3, log3[-1500:]
+    assert os.path.getsize(victim) > 1000 and not [p for p in os.listdir(tmp_path) if p.endswith(".tmp")]
