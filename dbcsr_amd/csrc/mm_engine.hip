@@ -272,6 +272,10 @@ int dbcsr_amd_mm_symbolic_filtered(void* handle, libsmm_acc_data_t datatype, dou
     hipLaunchKernelGGL(mode_of, dim3(1), dim3(256), 0, st, a->row_blk_size, nbr, md + 0);
     hipLaunchKernelGGL(mode_of, dim3(1), dim3(256), 0, st, a->col_blk_size, nbk, md + 2);
     hipLaunchKernelGGL(mode_of, dim3(1), dim3(256), 0, st, b->col_blk_size, nbc, md + 4);
+    // ... and the most frequent size in units of 4 of C's rows and columns (the slab kernels' exact launch when no size dominates)
+    int* um = reinterpret_cast<int*>(E->dev_scalars.p + 11);
+    hipLaunchKernelGGL(units_mode_of, dim3(1), dim3(256), 0, st, a->row_blk_size, nbr, um + 0);
+    hipLaunchKernelGGL(units_mode_of, dim3(1), dim3(256), 0, st, b->col_blk_size, nbc, um + 2);
   }
   // block-size histograms (sizes 1..32) of the three dimensions: the (m, n) classes of a mixed-size multiply
   E->cls_mode = false;
@@ -284,7 +288,7 @@ int dbcsr_amd_mm_symbolic_filtered(void* handle, libsmm_acc_data_t datatype, dou
     ACC_CHECK(hipMemcpyAsync(E->cls_host_hist, E->cls_hist.p, 3 * 33 * sizeof(int), hipMemcpyDeviceToHost, st));
   }
   // need c_nblks (and the block-size extrema) on the host to size per-block work arrays
-  ACC_CHECK(hipMemcpyAsync(E->host_scalars, dsc, 11 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+  ACC_CHECK(hipMemcpyAsync(E->host_scalars, dsc, 13 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
   ACC_CHECK(hipStreamSynchronize(st));
   const int64_t c_nblks = E->host_scalars[0];
   {
@@ -303,6 +307,8 @@ int dbcsr_amd_mm_symbolic_filtered(void* handle, libsmm_acc_data_t datatype, dou
     E->hot_k = dominant ? md[2] : 0;
     E->hot_n = dominant ? md[4] : 0;
     E->hot_cnt_m = md[1], E->hot_cnt_k = md[3], E->hot_cnt_n = md[5];
+    const int* um = reinterpret_cast<const int*>(E->host_scalars + 11);
+    E->units_m = um[0], E->units_cnt_m = um[1], E->units_n = um[2], E->units_cnt_n = um[3];
   }
   // (m, n) classes: blocks of at most 32 in every dimension, no single dominant size (that case has its ahead-of-time
   // kernel), not the packed 4 x 4 case, and enough C blocks to pay for compiling the class kernels (forced with
@@ -502,6 +508,19 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
     const bool dom = E->hot_m > 0 && E->hot_n > 0, all_in = (E->min_m > 24 && E->min_n > 24) || E->max_m > 32 || E->max_n > 32;
     const int dm = dom ? E->hot_m : (all_in ? E->max_m : 0), dn = dom ? E->hot_n : (all_in ? E->max_n : 0);
     if (dm > 0 && dn > 0 && mid_f64_serves(dm, dn, 0)) mid_rb = (dm + 3) / 4, mid_cb = (dn + 3) / 4;
+    if (mid_rb && !dom) {
+      // No dominant size: the exact launch would serve a minority and the second launch -- the largest shape, 10 x 10 or 12 x 12 units -- pads everything
+      // else (30 / 36 mixed: 43 ms against 29 through the workgroup kernel, session r06_47).  The slab kernel stays when ONE launch serves every block -- the
+      // largest blocks ARE the largest shape (30 / 40, 34 / 40, 23 / 40: +14-17 %) -- or when at least 80 % of C's rows and of its columns have the exact
+      // launch's units (33 / 36: +17 %; 36 with a tail block).
+      const int mu = (std::max(E->max_m, E->max_n) + 3) / 4, fb = (mu > 10 || mid_rb > 10 || mid_cb > 10) ? 12 : 10;
+      const bool single = mid_rb == fb && mid_cb == fb;
+      const bool most = 10ll * E->units_cnt_m >= 8ll * nbr && 10ll * E->units_cnt_n >= 8ll * b->nblkcols && mid_f64_serves(4 * E->units_m, 4 * E->units_n, 0);
+      if (most)
+        mid_rb = E->units_m, mid_cb = E->units_n;   // (the exact launch takes the most frequent shape, the second launch the rest)
+      else if (!single)
+        mid_rb = mid_cb = 0;
+    }
   }
   // every block dimension at most 8 (and not the packed 4 x 4 case): one 8 x 8 tile per wave, several products in flight (mm_numeric_f64_small.h)
   const bool tiny4 = E->use_tiny && E->max_m <= 4 && E->max_n <= 4;

@@ -744,6 +744,29 @@ __global__ void __launch_bounds__(256) max_of(const int* __restrict__ v, int n, 
   }
 }
 
+// most frequent size IN UNITS OF 4 ((s + 3) / 4, sizes 1 ... 48) among the entries of v: out[0] = units (0: none), out[1] = how often -- the share of the
+// blocks the exact launch of the one-wave slab kernels (mm_numeric_f64_mid.h) would multiply when no size dominates
+__global__ void __launch_bounds__(256) units_mode_of(const int* __restrict__ v, int n, int* __restrict__ out) {
+  __shared__ int h[13];
+  if (threadIdx.x < 13) h[threadIdx.x] = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int s = v[i];
+    if (s >= 1 && s <= 48) atomicAdd(&h[(s + 3) >> 2], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int best = 0, cnt = 0;
+    for (int u = 12; u >= 1; --u)   // (ties: the larger shape)
+      if (h[u] > cnt) {
+        cnt = h[u];
+        best = u;
+      }
+    out[0] = best;
+    out[1] = cnt;
+  }
+}
+
 // most frequent value among the entries of v that lie in 1..32: out[0] = value (0: none), out[1] = how often
 __global__ void __launch_bounds__(256) mode_of(const int* __restrict__ v, int n, int* __restrict__ out) {
   __shared__ int h[33];

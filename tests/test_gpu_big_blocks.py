@@ -41,6 +41,10 @@ CASES = {
     "36cube_tails": ((36 * 6 + 20, 36 * 6 + 7, 36 * 6 + 30, 0.4, 0.4, 0.5, [1, 36], [1, 36], [1, 36]), "mm_numeric_f64_mid<9,9>"),
     "mix_33_to_40": ((36 * 8, 36 * 8, 300, 0.5, 0.5, 0.5, [1, 33, 1, 40, 1, 37, 1, 36], [1, 40, 1, 34, 1, 38], [1, 40, 1, 5, 1, 33, 1, 17]), "mm_numeric_f64_mid<10,10>"),
     "mostly_34_some_small": ((34 * 12 + 13, 34 * 12 + 40, 34 * 8, 0.5, 0.5, 0.5, [12, 34, 1, 13], [12, 34, 1, 40], [1, 34]), "mm_numeric_f64_mid<"),
+    # no dominant size: the slab kernel only when ONE launch serves every block (round 6, session 47: 30 / 36 mixed lost 0.68 against the workgroup kernel)
+    "mix_30_36": ((33 * 8, 33 * 8, 33 * 7, 0.5, 0.5, 0.5, [1, 30, 1, 36], [1, 36, 1, 30], [1, 30, 1, 36]), "mm_numeric_f64_big<3,3>"),
+    "mix_33_36": ((35 * 8, 35 * 8, 35 * 7, 0.5, 0.5, 0.5, [1, 33, 1, 36], [1, 36, 1, 33], [1, 33, 1, 36]), "mm_numeric_f64_mid<9,9>"),
+    "mix_23_40": ((32 * 8, 32 * 8, 32 * 7, 0.5, 0.5, 0.5, [1, 23, 1, 40], [1, 40, 1, 23], [1, 23, 1, 40]), "mm_numeric_f64_mid<10,10>"),
     # ... and 41 ... 48 (11 / 12 units): the largest shape is then <12,12>
     "44cube": ((44 * 7, 44 * 6, 44 * 8, 0.5, 0.5, 0.5, [1, 44], [1, 44], [1, 44]), "mm_numeric_f64_mid<11,11>"),
     "48cube_tails": ((48 * 6 + 20, 48 * 6 + 45, 48 * 6 + 30, 0.4, 0.4, 0.5, [1, 48], [1, 48], [1, 48]), "mm_numeric_f64_mid<12,12>"),
