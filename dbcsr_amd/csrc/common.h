@@ -22,7 +22,7 @@ hipError_t pool_free(void* p);
 // handle; an operand whose index_stamp is 0 ("unknown generation", include/dbcsr_amd_mm.h) is never remembered.
 struct KPassMemo {
   const void *row_p = nullptr, *blk_p = nullptr;
-  int64_t nblks = -1;
+  int64_t nblks = -1, b_nblks = -1;   // (B's block count: its fill enters the estimate of the products per C block)
   uint64_t stamp = 0;
   int dt = 0, nblkrows = 0, nblkcols = 0, npass = 1;
 };

@@ -148,7 +148,7 @@ int symbolic_numeric(void* h, libsmm_acc_data_t dt, double alpha, const dbcsr_am
 // L2 blocking over k (see MultiplyEngine.multiply_local in dbcsr_amd/multiply.py for the measurements): when A's average block
 // row is larger than 1 MB neither operand stays L2-resident; the product is then formed as one symbolic product of the whole
 // operands (C's final structure, C = beta*C_in on it) followed by passes over k ranges that accumulate in place.
-int k_passes(void* h, libsmm_acc_data_t dt, const dbcsr_amd_bcsr* a, double filter_eps, void* stream) {
+int k_passes(void* h, libsmm_acc_data_t dt, const dbcsr_amd_bcsr* a, const dbcsr_amd_bcsr* b, double filter_eps, void* stream) {
   if (filter_eps > 0.0) return 1;  // the on-the-fly filter counts the blocks of a whole A row
   if (const char* f = getenv("DBCSR_AMD_MM_KCHUNKS")) return atoi(f) > 1 ? atoi(f) : 1;
   if (a->nblkcols < 64 || a->nblkrows < 1) return 1;
@@ -159,12 +159,12 @@ int k_passes(void* h, libsmm_acc_data_t dt, const dbcsr_amd_bcsr* a, double filt
   KPassMemo* memo = engine_kpass_memo(h);
   const bool stamped = memo && a->index_stamp != 0;  // stamp 0 = the owner does not track its index arrays: never trusted
   if (stamped && memo->row_p == a->row_p && memo->blk_p == a->blk_p && memo->nblks == (int64_t)a->nblks && memo->stamp == (uint64_t)a->index_stamp &&
-      memo->dt == (int)dt && memo->nblkrows == a->nblkrows && memo->nblkcols == a->nblkcols)
+      memo->dt == (int)dt && memo->nblkrows == a->nblkrows && memo->nblkcols == a->nblkcols && memo->b_nblks == (b ? (int64_t)b->nblks : -1))
     return memo->npass;
   auto remember = [&](int n) {
     if (stamped) {
       memo->row_p = a->row_p, memo->blk_p = a->blk_p, memo->nblks = (int64_t)a->nblks, memo->stamp = (uint64_t)a->index_stamp;
-      memo->dt = (int)dt, memo->nblkrows = a->nblkrows, memo->nblkcols = a->nblkcols, memo->npass = n;
+      memo->dt = (int)dt, memo->nblkrows = a->nblkrows, memo->nblkcols = a->nblkcols, memo->npass = n, memo->b_nblks = b ? (int64_t)b->nblks : -1;
     }
     return n;
   };
@@ -175,6 +175,11 @@ int k_passes(void* h, libsmm_acc_data_t dt, const dbcsr_amd_bcsr* a, double filt
   const double row_bytes = (double)nz * (double)elem_size(dt) / (double)a->nblkrows;
   if (row_bytes <= 1.0 * 1048576.0) return remember(1);      // (round 5: 23 x 23 at 20 % fill, rows of 1.2 MB, gains 7 % from two passes)
   if (nb > 0 && nz > 1024 * nb) return remember(1);           // blocks above 32 x 32 on average: the workgroup-per-C-block kernel shares its operands in LDS
+  // (round 6, session r06_49: a pass costs C's bytes and saves the operands': it pays only when a C block collects many products -- 32^3 at 10 % fill, 14 per
+  //  C block: 44.0 ms in one pass against 53.0 in two; 23^3 at 20 %, 57: 83.5 against 75.3 -- at least 48, estimated from the operands' fills)
+  const double fill_a = (double)nb / ((double)a->nblkrows * (double)a->nblkcols);
+  const double fill_b = b && b->nblkrows > 0 && b->nblkcols > 0 ? (double)b->nblks / ((double)b->nblkrows * (double)b->nblkcols) : fill_a;
+  if ((double)a->nblkcols * fill_a * fill_b < 48.0) return remember(1);
   const int n = (int)std::ceil(row_bytes / 1048576.0);
   return remember(n > 8 ? 8 : n);
 }
@@ -335,7 +340,7 @@ int dbcsr_amd_multiply(void* handle, char transa, char transb, libsmm_acc_data_t
   // the product (with the on-the-fly filter), then the final block filter
   Owned prod;
   dbcsr_amd_mm_counts counts;
-  const int npass = k_passes(handle, datatype, A, filter_eps, stream);
+  const int npass = k_passes(handle, datatype, A, B, filter_eps, stream);
   if (npass > 1) {
     if ((rc = multiply_in_k_passes(handle, datatype, alpha, A, B, beta_eff, Cin, retain_sparsity, npass, prod, &counts, stream))) return rc;
   } else if ((rc = symbolic_numeric(handle, datatype, alpha, A, B, beta_eff, Cin, retain_sparsity, filter_eps, prod, &counts, stream))) {

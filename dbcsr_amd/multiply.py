@@ -334,9 +334,14 @@ class MultiplyEngine:
     # passes, 2357 ms in 8, tools/kchunk_probe.py).  The price -- C re-read and re-written per pass -- is why this is not
     # done for small A rows.
     # (round 5, gpurun_out/r05_s03/sweeps.jsonl: 32768^2 of 23 x 23 at 20 % fill, A rows of 1.2 MB: 83.0 ms in one pass, 77.2 in two)
+    # (round 6, session r06_49: after the exact-size kernels' padded LDS pitches a single pass over 32 x 32 blocks is fast, and passes only pay when a C block
+    #  collects many products -- the price of a pass is C's bytes, its gain the operands': 32^3 at 10 % fill (14 products per C block, 1.17 MB rows) 44.0 ms in one
+    #  pass against 53.0 in two; 32^3 at 20 % (41) 63.6 against 66.3; 28^3 at 15 % (32) 80.6 against 84.3; 23^3 at 20 % (57) 83.5 against 75.3; config 5 (164): four
+    #  passes.  Hence the second condition: at least KCHUNK_MIN_PRODUCTS products per C block, estimated from the operands' fills.)
     KCHUNK_ROW_BYTES = 1.0 * 2 ** 20
+    KCHUNK_MIN_PRODUCTS = 48.0
 
-    def _auto_kchunks(self, A, filter_eps):
+    def _auto_kchunks(self, A, filter_eps, B=None):
         if filter_eps and filter_eps > 0:  # the on-the-fly filter counts the blocks of a whole A row (dbcsr_mm_cannon.F:1100-1110)
             return 1
         forced = os.environ.get("DBCSR_AMD_MM_KCHUNKS")
@@ -344,6 +349,10 @@ class MultiplyEngine:
             return max(1, int(forced))
         row_bytes = A.data.numel() * A.data.element_size() / max(1, A.nblkrows)
         if row_bytes <= self.KCHUNK_ROW_BYTES or A.nblkcols < 64:
+            return 1
+        fill_a = A.nblks / max(1.0, float(A.nblkrows) * A.nblkcols)
+        fill_b = fill_a if B is None else B.nblks / max(1.0, float(B.nblkrows) * B.nblkcols)
+        if A.nblkcols * fill_a * fill_b < self.KCHUNK_MIN_PRODUCTS:   # (expected products per C block)
             return 1
         if A.data.numel() > 1024 * max(1, A.nblks):
             # blocks above 32 x 32 on average: the workgroup-per-C-block kernel (mm_numeric_f64_big.h) shares its operand slabs through LDS and
@@ -398,7 +407,7 @@ class MultiplyEngine:
 
     def multiply_local(self, alpha, A, B, beta, Cm, retain_sparsity=False, stream=None, filter_eps=0.0, kchunks=None):
         """C_out = beta*Cm + alpha*A*B for already-oriented operands; returns (C_out, counts)."""
-        n = self._auto_kchunks(A, filter_eps) if kchunks is None else int(kchunks)
+        n = self._auto_kchunks(A, filter_eps, B) if kchunks is None else int(kchunks)
         if filter_eps and filter_eps > 0.0 and n > 1:
             raise ValueError("multiply_local: k passes cannot be combined with filter_eps (the on-the-fly filter counts the blocks of a whole A row)")
         if n > 1 and A.nblkcols >= n:
