@@ -3,13 +3,16 @@
 // The sizes libsmm_acc serves with its "tiny" dataflow (src/acc/libsmm_acc/kernels/smm_acc_dnt_tiny.h: the whole A and B block of a product in
 // shared memory, one thread per C element; 5 x 5 x 5 ... 8 x 8 x 8 are tuned triplets of its parameter files).  Here: one wave per C block, the block
 // ONE 8 x 8 tile of the 2 x 2 arrangement of v_mfma_f64_4x4x4_4b (two instructions per product: k in fours).  A block of at most 8 x 8 doubles is at
-// most 512 bytes: ONE bounds-checked 8-byte buffer load per lane fetches all of A, a second all of B -- two VGPR pairs per product in flight, so a
-// wave keeps D products in flight (the exact-size kernels for 9 ... 32 keep one: their blocks take 2 ... 16 registers per lane each) and sixteen
-// waves fit a SIMD's register file.  Such a multiply is a chain of memory round trips, not arithmetic: 128 ... 1024 flop per product.
-// The records of up to 64 products come with one vector load (lane t holds entry t of the list) and are handed out with v_readlane.
+// most 512 bytes: ONE bounds-checked 8-byte buffer load per lane fetches all of A, a second all of B -- two VGPR pairs per product in flight (the
+// exact-size kernels for 9 ... 32 carry 2 ... 16 registers per lane and operand).  D products are in flight per wave; measured, D = 2 is best: eight waves
+// per SIMD hide the latency, a deeper ring only adds requests behind the end of a 14-product list.  Such a multiply is instruction issue, not arithmetic
+// (128 ... 1024 flop per product): the records of up to 62 products come with one vector load (lane t holds record t), every lane prepares the byte
+// addresses and counts of ITS record, and a request is six v_readlane into the two buffer resources -- the first form computed them on the scalar unit,
+// 46 instructions per product on the ONE scalar unit a CU's waves share, and that was the whole run time.
 // LDS: 1 KiB per wave, the blocks as they lie (A: column-major m x ks, B: ks x n); lanes past the end of a block receive zeros from the bounds check.
 //
-// Measured (tools/gpu_sessions/r06_37_small_blocks.sh; 1425 block rows, fill 0.1 -- the benchmark's structure at every size): profiles/r06_small_blocks.txt.
+// Measured (tools/gpu_sessions/r06_37_small_blocks.sh; 1425 block rows, fill 0.1 -- the benchmark's structure at every size): profiles/r06_small_blocks.txt
+// (5^3 ... 8^3: 5.25 -> 2.2-2.4 ms against the run-time-size kernel).
 #ifndef DBCSR_AMD_MM_NUMERIC_F64_SMALL_H
 #define DBCSR_AMD_MM_NUMERIC_F64_SMALL_H
 #include "mm_numeric_f64.h"  // load_desc_uniform, LaneMap (smm_core.h), Desc / Entry (mm_types.h)
