@@ -261,32 +261,15 @@ int dbcsr_amd_mm_symbolic_filtered(void* handle, libsmm_acc_data_t datatype, dou
   hipLaunchKernelGGL(row_prefix, grid_for((int64_t)nbr * 64), dim3(256), 0, st, E->c_bm.p, nbr, W, E->c_pre.p, E->row_nnz.p);
   int64_t* dsc = reinterpret_cast<int64_t*>(E->dev_scalars.p);
   if (exclusive_scan<int32_t>(E, E->row_nnz.p, nbr, c_out_row_p, dsc + 0, true, st)) return -1;
-  // block-size maxima (LDS slice size / kernel choice of the numeric phase)
-  {
-    int* mx = reinterpret_cast<int*>(E->dev_scalars.p + 4);
-    hipLaunchKernelGGL(max_of, dim3(1), dim3(256), 0, st, a->row_blk_size, nbr, mx + 0);
-    hipLaunchKernelGGL(max_of, dim3(1), dim3(256), 0, st, a->col_blk_size, nbk, mx + 2);
-    hipLaunchKernelGGL(max_of, dim3(1), dim3(256), 0, st, b->col_blk_size, nbc, mx + 4);
-    // ... and the most frequent block size per dimension (choice of an exact-size kernel)
-    int* md = reinterpret_cast<int*>(E->dev_scalars.p + 8);
-    hipLaunchKernelGGL(mode_of, dim3(1), dim3(256), 0, st, a->row_blk_size, nbr, md + 0);
-    hipLaunchKernelGGL(mode_of, dim3(1), dim3(256), 0, st, a->col_blk_size, nbk, md + 2);
-    hipLaunchKernelGGL(mode_of, dim3(1), dim3(256), 0, st, b->col_blk_size, nbc, md + 4);
-    // ... and the most frequent size in units of 4 of C's rows and columns (the slab kernels' exact launch when no size dominates)
-    int* um = reinterpret_cast<int*>(E->dev_scalars.p + 11);
-    hipLaunchKernelGGL(units_mode_of, dim3(1), dim3(256), 0, st, a->row_blk_size, nbr, um + 0);
-    hipLaunchKernelGGL(units_mode_of, dim3(1), dim3(256), 0, st, b->col_blk_size, nbc, um + 2);
-  }
-  // block-size histograms (sizes 1..32) of the three dimensions: the (m, n) classes of a mixed-size multiply
+  // block-size maxima (LDS slice size / kernel choice of the numeric phase), the most frequent block size per dimension (choice of an exact-size kernel), the most
+  // frequent size in units of 4 of C's rows and columns (the slab kernels' exact launch when no size dominates) and the histograms of the sizes 1 ... 32 (the
+  // (m, n) classes of a mixed-size multiply): one launch (block_size_stats)
   E->cls_mode = false;
-  if (E->use_classes > 0) {
-    if (E->cls_hist.ensure(3 * 33)) return -1;
-    ACC_CHECK(hipMemsetAsync(E->cls_hist.p, 0, 3 * 33 * sizeof(int), st));
-    hipLaunchKernelGGL(size_hist, grid_for(nbr), dim3(256), 0, st, a->row_blk_size, nbr, E->cls_hist.p);
-    hipLaunchKernelGGL(size_hist, grid_for(nbc), dim3(256), 0, st, b->col_blk_size, nbc, E->cls_hist.p + 33);
-    hipLaunchKernelGGL(size_hist, grid_for(nbk), dim3(256), 0, st, a->col_blk_size, nbk, E->cls_hist.p + 66);
-    ACC_CHECK(hipMemcpyAsync(E->cls_host_hist, E->cls_hist.p, 3 * 33 * sizeof(int), hipMemcpyDeviceToHost, st));
-  }
+  if (E->use_classes > 0 && E->cls_hist.ensure(3 * 33)) return -1;
+  hipLaunchKernelGGL(block_size_stats, dim3(3), dim3(256), 0, st, a->row_blk_size, nbr, a->col_blk_size, nbk, b->col_blk_size, nbc,
+                     reinterpret_cast<int*>(E->dev_scalars.p + 4), reinterpret_cast<int*>(E->dev_scalars.p + 8), reinterpret_cast<int*>(E->dev_scalars.p + 11),
+                     E->use_classes > 0 ? E->cls_hist.p : (int*)nullptr);
+  if (E->use_classes > 0) ACC_CHECK(hipMemcpyAsync(E->cls_host_hist, E->cls_hist.p, 3 * 33 * sizeof(int), hipMemcpyDeviceToHost, st));
   // need c_nblks (and the block-size extrema) on the host to size per-block work arrays
   ACC_CHECK(hipMemcpyAsync(E->host_scalars, dsc, 13 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
   ACC_CHECK(hipStreamSynchronize(st));

@@ -726,6 +726,56 @@ __global__ void __launch_bounds__(256) mm_numeric_f64_pipe(const Desc* __restric
   if (pending) pipe_flush<MAXT>(X, done, acc, L);
 }
 
+// The block-size statistics of a multiply in ONE launch (three workgroups: C's rows, the inner dimension, C's columns) instead of twelve -- max_of, mode_of,
+// units_mode_of, size_hist per dimension and a memset --, each a few microseconds of work behind a launch of its own on the path of a multiply whose plan is
+// not reused (round 6, session r06_52: 40 launches in front of the product kernel of config 1, 0.35 of its 0.86 ms).  Same results in the same places:
+// mx[2 d] = max, mx[2 d + 1] = -min; md[2 d] = most frequent size in 1 ... 32 (ties: the smallest), md[2 d + 1] = how often; um[0 .. 3] = most frequent size in
+// units of 4 (sizes 1 ... 48; ties: the largest) of C's rows and of its columns and how often; hist (may be null): 33 bins per dimension in the order rows,
+// columns, inner (bin 0: sizes outside 1 ... 32).
+__global__ void __launch_bounds__(256) block_size_stats(const int* __restrict__ rows, int nbr, const int* __restrict__ inner, int nbk,
+                                                        const int* __restrict__ cols, int nbc, int* __restrict__ mx, int* __restrict__ md,
+                                                        int* __restrict__ um, int* __restrict__ hist) {
+  __shared__ int h[33], hu[13], red[8];
+  const int d = blockIdx.x;  // 0: rows (m), 1: inner (k), 2: columns (n)
+  const int* v = d == 0 ? rows : (d == 1 ? inner : cols);
+  const int n = d == 0 ? nbr : (d == 1 ? nbk : nbc);
+  if (threadIdx.x < 33) h[threadIdx.x] = 0;
+  if (threadIdx.x < 13) hu[threadIdx.x] = 0;
+  __syncthreads();
+  int vmax = 0, vmin = -0x7fffffff;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int s = v[i];
+    vmax = max(vmax, s);
+    vmin = max(vmin, -s);
+    atomicAdd(&h[(s >= 1 && s <= 32) ? s : 0], 1);
+    if (s >= 1 && s <= 48) atomicAdd(&hu[(s + 3) >> 2], 1);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    vmax = max(vmax, __shfl_down(vmax, off, 64));
+    vmin = max(vmin, __shfl_down(vmin, off, 64));
+  }
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = vmax, red[4 + (threadIdx.x >> 6)] = vmin;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    mx[2 * d] = max(max(red[0], red[1]), max(red[2], red[3]));
+    mx[2 * d + 1] = max(max(red[4], red[5]), max(red[6], red[7]));
+    int best = 0, cnt = 0;
+    for (int s = 1; s <= 32; ++s)
+      if (h[s] > cnt) cnt = h[s], best = s;
+    md[2 * d] = best;
+    md[2 * d + 1] = cnt;
+    if (d != 1) {
+      best = 0, cnt = 0;
+      for (int u = 12; u >= 1; --u)
+        if (hu[u] > cnt) cnt = hu[u], best = u;
+      um[d] = best;        // (d = 0: um[0 .. 1], d = 2: um[2 .. 3])
+      um[d + 1] = cnt;
+    }
+  }
+  if (hist && threadIdx.x < 33) hist[(d == 0 ? 0 : (d == 2 ? 33 : 66)) + threadIdx.x] = h[threadIdx.x];
+}
+
 // max and (negated) min of an int array (block sizes): out[0] = max v, out[1] = max -v
 __global__ void __launch_bounds__(256) max_of(const int* __restrict__ v, int n, int* __restrict__ out) {
   int mx = 0, mn = -0x7fffffff;
