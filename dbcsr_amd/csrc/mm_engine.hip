@@ -568,9 +568,13 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
     } else if (mid_rb && launch_mid_f64(mid_rb, mid_cb, E->min_m != E->max_m || E->min_n != E->max_n, (unsigned)(8 * E->order_len), st, E->descs.p, nblk,
                                          E->entries.p, static_cast<const double*>(a->data), static_cast<const double*>(b->data),
                                          static_cast<double*>(c_out->data), static_cast<const double*>(c_in->data), alpha, beta, skip_empty, E->order.p,
-                                         hot_work, (std::max(E->max_m, E->max_n) + 3) / 4)) {
+                                         hot_work, (std::max(E->max_m, E->max_n) + 3) / 4, epi_norms)) {
       // blocks of 25 ... 40 in both dimensions: one wave per C block, operands in slabs (mm_numeric_f64_mid.h); the dominant size (else the largest)
-      // multiplied exactly, the blocks of another size by the second launch.  (It leaves no block norms: a filtered multiply computes them.)
+      // multiplied exactly, the blocks of another size by the second launch.  Every block leaves its norm to a filtered multiply (round 6, session 56).
+      if (epi_norms) {
+        E->norms_data = c_out->data;
+        E->norms_nblks = nblk;
+      }
       snprintf(E->last_kernel, sizeof E->last_kernel, "mm_numeric_f64_mid<%d,%d>", mid_rb, mid_cb);
     } else if (small && E->use_lds && E->cls_mode) {
       // one launch per (m, n) class on its segment of order[]: the run-time compiled exact-size kernel of the class
@@ -610,8 +614,9 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
             launch_mid_f64((cm + 3) / 4, (cn + 3) / 4, false, (unsigned)(8 * E->cls_len[c]), st, E->descs.p, nblk, E->entries.p,
                            static_cast<const double*>(a->data), static_cast<const double*>(b->data), static_cast<double*>(c_out->data),
                            static_cast<const double*>(c_in->data), alpha, beta, skip_empty, ord, hot_work ? hot_work + E->cls_off[c] : nullptr,
-                           (std::max(cm, cn) + 3) / 4)) {
+                           (std::max(cm, cn) + 3) / 4, epi_norms)) {
           ++nmid;
+          jit_mask |= 1 << c;   // (the class left its norms, as the run-time compiled kernels do: block_norms_unserved_classes passes it by)
         } else if (c < 9 && cm > 0 && cn > 0 && jit_class_kernel(cm, cn, E->cls_k[0], E->cls_k[1], E->cls_k[2], E->class_g, &ck) == 0) {
           const Desc* p_descs = E->descs.p;
           long p_nblk = (long)nblk;
@@ -768,10 +773,8 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
                          static_cast<const double*>(a->data), static_cast<const double*>(b->data), static_cast<double*>(c_out->data),
                          static_cast<const double*>(c_in->data), alpha, beta, lds_a, lds_wave, E->dbg | (skip_empty ? 32 : 0), E->order.p,
                          hot_work, ww, epi_norms, (E->dbg & ~32) ? 1 : E->hot_variant)) {
-        // launched: C blocks of the dominant size take the exact-size path, the others the generic one
-        if (epi_norms) {  // blocks of another size (tail block row / column) did not leave their norm: a pass over those only
-          hipLaunchKernelGGL(block_norms_other_sizes, grid_for(nblk * 64), dim3(256), 0, st, E->descs.p, nblk, static_cast<const double*>(c_out->data),
-                             E->hot_m, E->hot_n, epi_norms);
+        // launched: C blocks of the dominant size take the exact-size path, the others the generic one; both leave their norms
+        if (epi_norms) {
           E->norms_data = c_out->data;
           E->norms_nblks = nblk;
         }

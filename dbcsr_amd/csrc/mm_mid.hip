@@ -29,7 +29,7 @@ bool mid_f64_serves(int m, int n, int class_mode) {
 
 bool launch_mid_f64(int rb, int cb, bool other_sizes, unsigned npos, hipStream_t st, const Desc* descs, int64_t nblk, const Entry* entries,
                     const double* a_data, const double* b_data, double* c_out, const double* c_in, double alpha, double beta, int skip_empty,
-                    const int* order, const Work* work, int max_units) {
+                    const int* order, const Work* work, int max_units, double* norms) {
   if (npos == 0 || rb < 6 || cb < 6 || rb > 12 || cb > 12) return false;
   // the shape that covers every block of the multiply (the second launch; the only one when the dominant size is that shape)
   const int fb = (max_units > 10 || rb > 10 || cb > 10) ? 12 : 10;
@@ -40,7 +40,7 @@ bool launch_mid_f64(int rb, int cb, bool other_sizes, unsigned npos, hipStream_t
   case A_ * 16 + B_: {                                                                                                                           \
     constexpr int KSL = (A_ <= 8 && B_ <= 8) ? 16 : 8;                                                                                           \
     hipLaunchKernelGGL((mm_numeric_f64_mid<A_, B_, KSL>), dim3(npos), dim3(64), (size_t)mid_lds_bytes((A_ + 1) / 2, (B_ + 1) / 2, KSL), st, descs, nblk, \
-                       entries, a_data, b_data, c_out, c_in, alpha, beta, flags, order, work);                                                   \
+                       entries, a_data, b_data, c_out, c_in, alpha, beta, flags, order, work, norms);                                            \
   } break;
     DBCSR_MID_CASE(6, 8) DBCSR_MID_CASE(6, 9) DBCSR_MID_CASE(6, 10) DBCSR_MID_CASE(6, 11) DBCSR_MID_CASE(6, 12)
     DBCSR_MID_CASE(7, 9) DBCSR_MID_CASE(7, 10) DBCSR_MID_CASE(7, 11) DBCSR_MID_CASE(7, 12)
@@ -56,10 +56,10 @@ bool launch_mid_f64(int rb, int cb, bool other_sizes, unsigned npos, hipStream_t
     const int f2 = (skip_empty & 1) | 16 | (rb << 8) | (cb << 12);
     if (fb == 12)
       hipLaunchKernelGGL((mm_numeric_f64_mid<12, 12, 8>), dim3(npos), dim3(64), (size_t)mid_lds_bytes(6, 6, 8), st, descs, nblk, entries, a_data, b_data, c_out,
-                         c_in, alpha, beta, f2, order, work);
+                         c_in, alpha, beta, f2, order, work, norms);
     else
       hipLaunchKernelGGL((mm_numeric_f64_mid<10, 10, 8>), dim3(npos), dim3(64), (size_t)mid_lds_bytes(5, 5, 8), st, descs, nblk, entries, a_data, b_data, c_out,
-                         c_in, alpha, beta, f2, order, work);
+                         c_in, alpha, beta, f2, order, work, norms);
   }
   return true;
 }

@@ -13,7 +13,7 @@ template <int MA, int NC>
 __device__ __forceinline__ void cblock_f64(const Desc& d, const Entry* __restrict__ entries, const double* __restrict__ a_data,
                                            const double* __restrict__ b_data, double* __restrict__ c_out,
                                            const double* __restrict__ c_in, double alpha, double beta, const LaneMap& L, int row0,
-                                           int col0) {
+                                           int col0, double* __restrict__ norm_out = nullptr) {
   double acc[MA][NC];
 #pragma unroll
   for (int a = 0; a < MA; ++a)
@@ -28,6 +28,7 @@ __device__ __forceinline__ void cblock_f64(const Desc& d, const Entry* __restric
   double* C = c_out + d.c_off;
   const bool has_in = d.cin_off >= 0;
   const double* Ci = c_in + (has_in ? d.cin_off : 0);
+  double ss = 0.0;
 #pragma unroll
   for (int a = 0; a < MA; ++a)
 #pragma unroll
@@ -37,8 +38,15 @@ __device__ __forceinline__ void cblock_f64(const Desc& d, const Entry* __restric
         double v = alpha * acc[a][c];
         if (has_in) v += beta * Ci[row + (size_t)m * col];
         C[row + (size_t)m * col] = v;
+        ss += v * v;
       }
     }
+  // (one tile covers the whole block here: row0 = col0 = 0) the squared norm of the block as stored, for the final filter of a filtered multiply
+  if (norm_out) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_down(ss, off, 64);
+    if ((threadIdx.x & 63) == 0) *norm_out = ss;
+  }
 }
 
 __global__ void __launch_bounds__(256) mm_numeric_f64(const Desc* __restrict__ descs, int64_t nblk, const Entry* __restrict__ entries,
@@ -427,8 +435,9 @@ __global__ void __launch_bounds__(256) mm_numeric_f64_hot(const Desc* __restrict
                               norms ? norms + w.cb : nullptr);
     return;
   }
-  // the few blocks of another size (tail block row / column): straight from global memory, as one 32 x 32 tile
-  cblock_f64<4, 4>(d, entries, a_data, b_data, c_out, c_in, alpha, beta, L, 0, 0);
+  // the few blocks of another size (tail block row / column): straight from global memory, as one 32 x 32 tile (they leave their norm too: no pass over
+  // all descriptors afterwards to find them -- 0.98 ms of a filtered multiply on config 4's 14 M C blocks, session r06_55)
+  cblock_f64<4, 4>(d, entries, a_data, b_data, c_out, c_in, alpha, beta, L, 0, 0, norms ? norms + w.cb : nullptr);
 }
 
 // PERSISTENT form of the kernel above (DBCSR_AMD_MM_HOT_PERSISTENT=1; an experiment, and the groundwork of a launch that leaves some

@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) mm
                                                           const Entry* __restrict__ entries, const double* __restrict__ a_data,
                                                           const double* __restrict__ b_data, double* __restrict__ c_out,
                                                           const double* __restrict__ c_in, double alpha, double beta, int flags,
-                                                          const int* __restrict__ order, const Work* __restrict__ work) {
+                                                          const int* __restrict__ order, const Work* __restrict__ work, double* __restrict__ norms) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // rounds of the slab copies: A -- the wave moves 1 KiB per round; B -- a lane moves two k of a column: 128 / KSL columns per round
   constexpr int TM = (RBX + 1) / 2, TN = (CBX + 1) / 2;   // pairs of 4 x 4 blocks per dimension the LDS slice is sized for
@@ -151,16 +151,19 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) mm
   Desc d;
   uint32_t fa_lo = 0, fb_lo = 0, fw = 1;   // the block's first product, when the launch-order record carried it
   bool have_first = false;
+  int64_t cb_index = 0;   // the C block (its squared norm goes to norms[cb_index] when a filtered multiply asks for it)
   if (work) {   // launch-order records (build_work): descriptor and first product in one read -- no order[] -> descs[] -> entries[] chain
     const Work w = work[pos];
     if (w.prod_cnt < 0) return;  // padding position
     d.c_off = w.c_off, d.cin_off = w.cin_off, d.prod_start = w.prod_start, d.prod_cnt = w.prod_cnt, d.m = w.m, d.n = w.n;
     fa_lo = w.a_lo, fb_lo = w.b_lo, fw = w.w;
     have_first = w.prod_cnt > 0;
+    cb_index = w.cb;
   } else {
     const int64_t cb = order[pos];
     if (cb < 0 || cb >= nblk) return;
     d = descs[cb];
+    cb_index = cb;
   }
   if ((flags & 1) && d.prod_cnt == 0) return;
   const int m = __builtin_amdgcn_readfirstlane((int)d.m), n = __builtin_amdgcn_readfirstlane((int)d.n), cnt = __builtin_amdgcn_readfirstlane(d.prod_cnt);
@@ -259,6 +262,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) mm
       p = p2;
       k0 = k2;
     }
+    double ss = 0.0;
     if constexpr (RBX <= 8 && CBX <= 8) {
       // C epilogue through LDS (as the exact-size kernels, mm_numeric_f64.h): the block is laid out as stored (column-major, contiguous) in the wave's
       // slice -- up to 32 x 32: it fits the slabs' 9 KB -- and leaves in whole 1 KiB pieces, 16 bytes per lane, with the streaming hint.  These shapes
@@ -284,6 +288,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) mm
             v[1] += beta * w[1];
           }
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsc, lane * 16, c * 1024, 2);
+          const int idx = c * 128 + 2 * lane;
+          if (idx < m * n) ss += v[0] * v[0];
+          if (idx + 1 < m * n) ss += v[1] * v[1];
         }
       }
     } else {
@@ -297,8 +304,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) mm
           double v = alpha * sum;
           if (has_in) v += beta * Ci[row + (size_t)m * col];
           C[row + (size_t)m * col] = v;
+          ss += v * v;
         }
       });
+    }
+    // squared Frobenius norm of the block as it was stored: the final block filter of a filtered multiply reads it instead of C (as the exact-size kernels leave it)
+    if (norms) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) ss += __shfl_down(ss, off, 64);
+      if (lane == 0) norms[cb_index] = ss;
     }
   }
 }

@@ -95,3 +95,39 @@ def test_jit_cache_directory_is_filled_and_used(tmp_path):
     log3 = run()
     assert log3.count("compiled class kernel") == 1 and log3.count(" from " + str(tmp_path)) == 3, log3[-1500:]
     assert os.path.getsize(victim) > 1000 and not [p for p in os.listdir(tmp_path) if p.endswith(".tmp")]
+
+
+# A filtered multiply ends with the block filter on C's norms: the product kernels leave them behind (round 6: also the blocks of another size inside the exact-size
+# kernel's launch, the slab kernels and the slab classes of a mixed-size multiply) -- every case against the oracle's filtered product, the chosen kernel asserted
+FILTER_CASES = {
+    "hot23_tails": ((23 * 20 + 16, 23 * 18 + 9, 23 * 22 + 5, 0.6, 0.6, 0.6, [1, 23], [1, 23], [1, 23]), {}, "mm_numeric_f64_hot<23,23,23>"),
+    "classes_13_23_32": ((68 * 6, 68 * 5 + 13, 68 * 6 + 23, 0.6, 0.6, 0.6, [1, 13, 1, 23, 1, 32], [1, 32, 1, 13, 1, 23], [1, 23, 1, 32, 1, 13]),
+                         {"DBCSR_AMD_MM_CLASSES": "2"}, "mm_numeric_f64_class[6 jit + 3 slab"),
+    "mid36_tail": ((36 * 9 + 20, 36 * 8 + 7, 36 * 9 + 30, 0.6, 0.6, 0.6, [1, 36], [1, 36], [1, 36]), {}, "mm_numeric_f64_mid<9,9>"),
+    "mid_33_36": ((69 * 5, 69 * 5 + 33, 69 * 4, 0.6, 0.6, 0.6, [1, 33, 1, 36], [1, 36, 1, 33], [1, 33, 1, 36]), {}, "mm_numeric_f64_mid<9,9>"),
+    "mid_30_40": ((70 * 5, 70 * 5 + 30, 70 * 4, 0.6, 0.6, 0.6, [1, 30, 1, 40], [1, 40, 1, 30], [1, 30, 1, 40]), {}, "mm_numeric_f64_mid<10,10>"),
+}
+
+
+@pytest.mark.parametrize("name", sorted(FILTER_CASES))
+@pytest.mark.parametrize("eps", [150.0, 400.0, 1000.0])
+def test_filtered_multiply_with_the_kernels_norms(monkeypatch, name, eps):
+    for k in ENV:
+        monkeypatch.delenv(k, raising=False)
+    case, env, expect = FILTER_CASES[name]
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    A, B, Cm = O.perf_case(*case)
+    ref, info = O.multiply("N", "N", 1.0, A, B, 0.5, Cm, filter_eps=eps)
+    full, _ = O.multiply("N", "N", 1.0, A, B, 0.5, Cm)
+    assert ref.nblks < full.nblks, "the filter case does not filter"
+    eng = MultiplyEngine()
+    dA, dB, dC = to_dev(A), to_dev(B), to_dev(Cm)
+    flop = [0]
+    dbcsr_multiply("N", "N", 1.0, dA, dB, 0.5, dC, filter_eps=eps, flop=flop, engine=eng)
+    torch.cuda.synchronize()
+    assert eng.last_kernel().startswith(expect), (eng.last_kernel(), expect)
+    assert flop[0] == info["flop"]
+    out = dev_to_bcsr(dC)
+    assert np.array_equal(out.row_p, ref.row_p) and np.array_equal(out.col_i, ref.col_i) and np.array_equal(out.blk_p, ref.blk_p)
+    assert rel_err(out.data, ref.data) <= 1e-10
