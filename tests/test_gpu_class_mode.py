@@ -131,3 +131,32 @@ def test_filtered_multiply_with_the_kernels_norms(monkeypatch, name, eps):
     out = dev_to_bcsr(dC)
     assert np.array_equal(out.row_p, ref.row_p) and np.array_equal(out.col_i, ref.col_i) and np.array_equal(out.blk_p, ref.blk_p)
     assert rel_err(out.data, ref.data) <= 1e-10
+
+
+# A walk over (m, n) classes at full scale (>= 200 000 C blocks each: an event that hits one block in 500 shows; the small cases of the random sweep would miss it --
+# round 6: a variant of the class kernels' epilogue returned wrong LOW bits in 0.2 % of the (9, 32) blocks and only this scale caught it).  Off by default beyond the
+# first four shapes: DBCSR_AMD_CLASS_SHAPES=N takes the first N of the list.
+SHAPES = [(9, 32, 9), (32, 9, 13), (13, 23, 5), (23, 13, 32), (5, 32, 23), (32, 5, 7), (16, 16, 9), (10, 30, 17), (30, 10, 6), (7, 29, 12), (17, 17, 17), (12, 24, 8),
+          (24, 12, 31), (11, 27, 10), (8, 32, 16), (32, 8, 24), (6, 31, 14), (15, 20, 11), (20, 15, 26), (18, 14, 19), (9, 9, 32), (14, 22, 5), (22, 14, 29), (31, 10, 9)]
+
+
+@pytest.mark.parametrize("shape", SHAPES[:int(__import__("os").environ.get("DBCSR_AMD_CLASS_SHAPES", "4"))], ids=lambda s: "%dx%dx%d" % s)
+def test_class_kernels_at_scale_with_tails(monkeypatch, shape):
+    for k in ENV:
+        monkeypatch.delenv(k, raising=False)
+    m, n, k = shape
+    tail = lambda s, salt: 1 + (s * 7 + salt) % (s - 1)   # a tail block of another size in every dimension: more classes, a second inner size
+    A, B, Cm = O.perf_case(m * 470 + tail(m, 1), n * 450 + tail(n, 2), k * 60 + tail(k, 3), 0.6, 0.6, 0.5, [1, m], [1, n], [1, k])
+    alpha, beta = 0.6, 1.4
+    ref, info = O.multiply("N", "N", alpha, A, B, beta, Cm)
+    assert ref.nblks >= 200000, ref.nblks
+    eng = MultiplyEngine()
+    dA, dB, dC = to_dev(A), to_dev(B), to_dev(Cm)
+    flop = [0]
+    dbcsr_multiply("N", "N", alpha, dA, dB, beta, dC, flop=flop, engine=eng)
+    torch.cuda.synchronize()
+    assert eng.last_kernel().startswith("mm_numeric_f64_hot<" if m == n == k else "mm_numeric_f64_class["), eng.last_kernel()
+    assert flop[0] == info["flop"]
+    out = dev_to_bcsr(dC)
+    assert np.array_equal(out.row_p, ref.row_p) and np.array_equal(out.col_i, ref.col_i) and np.array_equal(out.blk_p, ref.blk_p)
+    assert rel_err(out.data, ref.data) <= 1e-12
