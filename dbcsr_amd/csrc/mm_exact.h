@@ -275,6 +275,8 @@ __device__ __forceinline__ void cblock_f64_classes(const Desc& d, const Entry fi
   const bool has_in = d.cin_off >= 0;
   const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc((void*)(c_out + d.c_off), 0, M * N * 8, 0x00020000);
   typedef double f64x2 __attribute__((ext_vector_type(2)));
+  double ss = 0.0;  // squared Frobenius norm of the stored block for the final filter of a filtered multiply: summed as the values leave
+  // (the stores below carry the piece offset in the vector / immediate offset, not in an SGPR soffset: see cblock_f64_exact in mm_numeric_f64.h -- the store-data hazard)
   if (has_in) {
     const __amdgpu_buffer_rsrc_t rsi = __builtin_amdgcn_make_buffer_rsrc((void*)(c_in + d.cin_off), 0, M * N * 8, 0x00020000);
     u32x4 ci[CC];
@@ -286,26 +288,27 @@ __device__ __forceinline__ void cblock_f64_classes(const Desc& d, const Entry fi
       const f64x2 w = __builtin_bit_cast(f64x2, ci[c]);
       v[0] += beta * w[0];
       v[1] += beta * w[1];
-      if (norm_out) *reinterpret_cast<f64x2*>(lds + c * 1024 + voff) = v;  // (the final values, for the norm below)
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsc, voff, c * 1024, 2);
+      if (norm_out) {
+        const int idx = c * 128 + 2 * lane;
+        if (idx < M * N) ss += v[0] * v[0];
+        if (idx + 1 < M * N) ss += v[1] * v[1];
+      }
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsc, voff + c * 1024, 0, 2);
     }
   } else {
 #pragma unroll
     for (int c = 0; c < CC; ++c) {
       const u32x4 v = *reinterpret_cast<const u32x4*>(lds + c * 1024 + voff);
-      __builtin_amdgcn_raw_buffer_store_b128(v, rsc, voff, c * 1024, 2);
+      if (norm_out) {
+        const f64x2 x = __builtin_bit_cast(f64x2, v);
+        const int idx = c * 128 + 2 * lane;
+        if (idx < M * N) ss += x[0] * x[0];
+        if (idx + 1 < M * N) ss += x[1] * x[1];
+      }
+      __builtin_amdgcn_raw_buffer_store_b128(v, rsc, voff + c * 1024, 0, 2);
     }
   }
-  // squared Frobenius norm of the stored block for the final filter of a filtered multiply (the block is still in LDS)
   if (norm_out) {
-    double ss = 0.0;
-#pragma unroll
-    for (int c = 0; c < CC; ++c) {
-      const f64x2 v = *reinterpret_cast<const f64x2*>(lds + c * 1024 + voff);
-      const int idx = c * 128 + 2 * lane;
-      if (idx < M * N) ss += v[0] * v[0];
-      if (idx + 1 < M * N) ss += v[1] * v[1];
-    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) ss += __shfl_down(ss, off, 64);
     if (lane == 0) *norm_out = ss;
@@ -581,13 +584,13 @@ __device__ __forceinline__ void mm_class_stream_body(const Desc* __restrict__ de
         const f64x2 w = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(rsi, voff, c * 1024, 0));
         v[0] += beta * w[0];
         v[1] += beta * w[1];
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsc, voff, c * 1024, 2);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsc, voff + c * 1024, 0, 2);
       }
     } else {
 #pragma unroll
       for (int c = 0; c < CC; ++c) {
         const u32x4 v = *reinterpret_cast<const u32x4*>(lds + c * 1024 + voff);
-        __builtin_amdgcn_raw_buffer_store_b128(v, rsc, voff, c * 1024, 2);
+        __builtin_amdgcn_raw_buffer_store_b128(v, rsc, voff + c * 1024, 0, 2);
       }
     }
   }

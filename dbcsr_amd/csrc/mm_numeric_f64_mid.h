@@ -287,7 +287,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) mm
             v[0] += beta * w[0];
             v[1] += beta * w[1];
           }
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsc, lane * 16, c * 1024, 2);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsc, lane * 16 + c * 1024, 0, 2);
           const int idx = c * 128 + 2 * lane;
           if (idx < m * n) ss += v[0] * v[0];
           if (idx + 1 < m * n) ss += v[1] * v[1];

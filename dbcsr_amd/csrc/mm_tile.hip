@@ -145,13 +145,13 @@ __device__ __forceinline__ void tile_store_block(const double (&acc)[3][3], char
       const f64x2 w = __builtin_bit_cast(f64x2, ci[c]);
       v[0] += beta * w[0];
       v[1] += beta * w[1];
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsc, voff, c * 1024, 2);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsc, voff + c * 1024, 0, 2);
     }
   } else {
 #pragma unroll
     for (int c = 0; c < CC; ++c) {
       const u32x4 v = *reinterpret_cast<const u32x4*>(stage + c * 1024 + voff);
-      __builtin_amdgcn_raw_buffer_store_b128(v, rsc, voff, c * 1024, 2);
+      __builtin_amdgcn_raw_buffer_store_b128(v, rsc, voff + c * 1024, 0, 2);
     }
   }
 }
