@@ -160,3 +160,33 @@ def test_class_kernels_at_scale_with_tails(monkeypatch, shape):
     out = dev_to_bcsr(dC)
     assert np.array_equal(out.row_p, ref.row_p) and np.array_equal(out.col_i, ref.col_i) and np.array_equal(out.blk_p, ref.blk_p)
     assert rel_err(out.data, ref.data) <= 1e-12
+
+
+# The same at scale for the other kernel families (exact-size cubes, slab kernels, one-tile kernel): a tail block in every dimension, tens to hundreds of thousands of
+# C blocks, 1e-12 against the oracle.  (nbr, nbc, nbk) chosen so that the CPU oracle takes seconds.
+FAMILY_SHAPES = [((13, 13, 13), (470, 450, 60), "mm_numeric_f64_hot<13,13,13>"), ((23, 23, 23), (330, 320, 50), "mm_numeric_f64_hot<23,23,23>"),
+                 ((32, 32, 32), (250, 240, 40), "mm_numeric_f64_hot<32,32,32>"), ((36, 36, 36), (200, 190, 30), "mm_numeric_f64_mid<9,9>"),
+                 ((40, 33, 37), (180, 190, 30), "mm_numeric_f64_mid<10,9>"), ((5, 5, 5), (470, 450, 100), "mm_numeric_f64_small<2>"),
+                 ((8, 7, 6), (470, 450, 100), "mm_numeric_f64_small<2>"), ((4, 4, 4), (470, 450, 100), "mm_numeric_f64_tiny")]
+
+
+@pytest.mark.parametrize("shape,counts,expect", FAMILY_SHAPES, ids=lambda v: "x".join(map(str, v)) if isinstance(v, tuple) and len(v) == 3 and isinstance(v[0], int) and v[0] < 100 else None)
+def test_kernel_families_at_scale_with_tails(monkeypatch, shape, counts, expect):
+    for k in ENV:
+        monkeypatch.delenv(k, raising=False)
+    m, n, k = shape
+    nbr, nbc, nbk = counts
+    tail = lambda s, salt: 1 + (s * 7 + salt) % (s - 1)
+    A, B, Cm = O.perf_case(m * nbr + tail(m, 1), n * nbc + tail(n, 2), k * nbk + tail(k, 3), 0.6, 0.6, 0.5, [1, m], [1, n], [1, k])
+    alpha, beta = 0.6, 1.4
+    ref, info = O.multiply("N", "N", alpha, A, B, beta, Cm)
+    eng = MultiplyEngine()
+    dA, dB, dC = to_dev(A), to_dev(B), to_dev(Cm)
+    flop = [0]
+    dbcsr_multiply("N", "N", alpha, dA, dB, beta, dC, flop=flop, engine=eng)
+    torch.cuda.synchronize()
+    assert eng.last_kernel().startswith(expect), (eng.last_kernel(), expect)
+    assert flop[0] == info["flop"]
+    out = dev_to_bcsr(dC)
+    assert np.array_equal(out.row_p, ref.row_p) and np.array_equal(out.col_i, ref.col_i) and np.array_equal(out.blk_p, ref.blk_p)
+    assert rel_err(out.data, ref.data) <= 1e-12
