@@ -791,69 +791,6 @@ __global__ void __launch_bounds__(256) block_size_stats(const int* __restrict__ 
   if (hist && threadIdx.x < 33) hist[(d == 0 ? 0 : (d == 2 ? 33 : 66)) + threadIdx.x] = h[threadIdx.x];
 }
 
-// max and (negated) min of an int array (block sizes): out[0] = max v, out[1] = max -v
-__global__ void __launch_bounds__(256) max_of(const int* __restrict__ v, int n, int* __restrict__ out) {
-  int mx = 0, mn = -0x7fffffff;
-  for (int i = threadIdx.x; i < n; i += 256) {
-    mx = max(mx, v[i]);
-    mn = max(mn, -v[i]);
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    mx = max(mx, __shfl_down(mx, off, 64));
-    mn = max(mn, __shfl_down(mn, off, 64));
-  }
-  if ((threadIdx.x & 63) == 0) {
-    atomicMax(out, mx);
-    atomicMax(out + 1, mn);
-  }
-}
-
-// most frequent size IN UNITS OF 4 ((s + 3) / 4, sizes 1 ... 48) among the entries of v: out[0] = units (0: none), out[1] = how often -- the share of the
-// blocks the exact launch of the one-wave slab kernels (mm_numeric_f64_mid.h) would multiply when no size dominates
-__global__ void __launch_bounds__(256) units_mode_of(const int* __restrict__ v, int n, int* __restrict__ out) {
-  __shared__ int h[13];
-  if (threadIdx.x < 13) h[threadIdx.x] = 0;
-  __syncthreads();
-  for (int i = threadIdx.x; i < n; i += 256) {
-    const int s = v[i];
-    if (s >= 1 && s <= 48) atomicAdd(&h[(s + 3) >> 2], 1);
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int best = 0, cnt = 0;
-    for (int u = 12; u >= 1; --u)   // (ties: the larger shape)
-      if (h[u] > cnt) {
-        cnt = h[u];
-        best = u;
-      }
-    out[0] = best;
-    out[1] = cnt;
-  }
-}
-
-// most frequent value among the entries of v that lie in 1..32: out[0] = value (0: none), out[1] = how often
-__global__ void __launch_bounds__(256) mode_of(const int* __restrict__ v, int n, int* __restrict__ out) {
-  __shared__ int h[33];
-  if (threadIdx.x < 33) h[threadIdx.x] = 0;
-  __syncthreads();
-  for (int i = threadIdx.x; i < n; i += 256) {
-    const int s = v[i];
-    if (s >= 1 && s <= 32) atomicAdd(&h[s], 1);
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int best = 0, cnt = 0;
-    for (int s = 1; s <= 32; ++s)
-      if (h[s] > cnt) {
-        cnt = h[s];
-        best = s;
-      }
-    out[0] = best;
-    out[1] = cnt;
-  }
-}
-
 // ---- fp64, C blocks of at most 4 x 4 (BASELINE config 1: 4 x 4 x 4 blocks) -------------------------------------------
 // v_mfma_f64_4x4x4_4b_f64 multiplies FOUR independent 4x4x4 block triples at once (lane bits 2-3 select the triple).  With
 // one wave per C block three quarters of every instruction are padding and a wave lives for ten products; here a wave

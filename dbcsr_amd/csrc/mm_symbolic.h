@@ -659,21 +659,6 @@ __global__ void order_len(const int64_t* __restrict__ base, int64_t total, int N
 // ----------------------------------------------------------------------------
 constexpr int kNumClasses = 10;
 
-__global__ void __launch_bounds__(256) size_hist(const int* __restrict__ sizes, int n, int* __restrict__ hist /* 33 */) {
-  // per-workgroup histogram in LDS first: with a single block size every global atomic would hit the same address
-  // (5699 serialised atomics = 66 us on config 4)
-  __shared__ int h[33];
-  if (threadIdx.x < 33) h[threadIdx.x] = 0;
-  __syncthreads();
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) {
-    const int s = sizes[i];
-    atomicAdd(&h[(s >= 1 && s <= 32) ? s : 0], 1);
-  }
-  __syncthreads();
-  if (threadIdx.x < 33 && h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
-}
-
 __global__ void __launch_bounds__(256) class_ids(const int* __restrict__ sizes, int n, int s0, int s1, int s2, unsigned char* __restrict__ cls) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
