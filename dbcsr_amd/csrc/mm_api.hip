@@ -142,6 +142,11 @@ int symbolic_numeric(void* h, libsmm_acc_data_t dt, double alpha, const dbcsr_am
   if (alloc_arrays(out, c_in->nblkrows, c_in->nblkcols, c_in->row_blk_size, c_in->col_blk_size, counts->c_nblks, counts->c_nze, elem_size(dt),
                    false))
     return -1;
+  // (this helper's product goes straight into the block filter with the same eps: the blocks it will drop need not be written)
+  if (eps > 0.0 && !retain) {
+    static const bool off = getenv("DBCSR_AMD_MM_EXPECT_FILTER") && atoi(getenv("DBCSR_AMD_MM_EXPECT_FILTER")) == 0;
+    if (!off) dbcsr_amd_mm_expect_filter(h, eps);
+  }
   return dbcsr_amd_mm_numeric(h, dt, alpha, a, b, beta, c_in, &out.m, stream);
 }
 

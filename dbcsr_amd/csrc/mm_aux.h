@@ -291,6 +291,8 @@ desym_fill(const int* __restrict__ s_row_p, const int* __restrict__ s_col_i, con
   }
 }
 
+__global__ void store_scalar_f64(double* __restrict__ p, double v) { *p = v; }
+
 // ---- block filter (dbcsr_mm_multrec.F:694-748 multrec_filtering / dbcsr_filter): drop blocks with ||blk||^2 < eps^2
 __global__ void __launch_bounds__(256) filter_flags(const double* __restrict__ norms64, int64_t nblks, const int* __restrict__ row_p,
                                                     const int* __restrict__ col_i, const int* __restrict__ rs, const int* __restrict__ cs,

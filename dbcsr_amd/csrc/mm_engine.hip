@@ -535,6 +535,17 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
     epi_norms = E->norms64.p;
     if (E->dbg & 8) epi_norms = nullptr;  // (profiling epilogue of the exact-size kernel: it leaves no norms, the filter then computes them)
   }
+  // the final block filter announced for this numeric phase (dbcsr_amd_mm_expect_filter): its eps^2 rides behind the norms, norms64[nblk], where the exact-size and
+  // class kernels pick it up -- a block below it is not written
+  {
+    const double drop = epi_norms ? E->drop_pending : 0.0;
+    E->drop_pending = 0.0;
+    E->unwritten_below = 0.0;
+    if (epi_norms) {
+      hipLaunchKernelGGL(store_scalar_f64, dim3(1), dim3(1), 0, st, epi_norms + nblk, drop);
+      E->unwritten_below = drop;
+    }
+  }
   ACC_CHECK(hipEventRecord(E->ev[1], st));
   if (datatype == dbcsr_type_real_8) {
     // LDS path: blocks of at most 32 x 32 (any smaller size: the staging loads are bounds-checked buffer loads)

@@ -144,7 +144,13 @@ int dbcsr_amd_bcsr_filter_count(void* handle, libsmm_acc_data_t datatype, const 
   int64_t* dsc = reinterpret_cast<int64_t*>(E->dev_scalars.p);
   ACC_CHECK(hipMemsetAsync(dsc, 0, 16 * sizeof(int64_t), st));
   const bool have_norms = E->norms_data != nullptr && E->norms_data == m->data && E->norms_nblks == nb && datatype == dbcsr_type_real_8;
+  if (have_norms && E->unwritten_below > eps * eps) {
+    fprintf(stderr, "dbcsr_amd_bcsr_filter_count: this matrix was multiplied with a final filter of eps^2 = %g announced (dbcsr_amd_mm_expect_filter); "
+                    "blocks below that were not written and cannot be kept with eps^2 = %g\n", E->unwritten_below, eps * eps);
+    return -3;
+  }
   E->norms_data = nullptr;
+  E->unwritten_below = 0.0;
   if (nbr > 0 && nb > 0) {
     const int sm = row_split(nbr, nb);
     if (have_norms) {
@@ -385,6 +391,13 @@ const char* dbcsr_amd_mm_kernel_name(libsmm_acc_data_t datatype) {
 const char* dbcsr_amd_mm_last_kernel(void* handle) {
   Engine* E = static_cast<Engine*>(handle);
   return E ? E->last_kernel : "";
+}
+
+int dbcsr_amd_mm_expect_filter(void* handle, double eps) {
+  Engine* E = static_cast<Engine*>(handle);
+  if (!E || !(eps >= 0.0)) return -1;
+  E->drop_pending = eps * eps;
+  return 0;
 }
 
 int dbcsr_amd_mm_trust_plan(void* handle, int on) {

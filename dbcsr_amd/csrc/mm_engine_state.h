@@ -68,6 +68,8 @@ struct Engine {
   Window crop_win = {0, 0, 0, 0};       // window of the last dbcsr_amd_bcsr_crop_count
   bool crop_pending = false;
   int hot_m = 0, hot_n = 0, hot_k = 0;  // dominant block sizes of the last symbolic phase (0: none)
+  double drop_pending = 0.0;       // dbcsr_amd_mm_expect_filter: eps^2 of the final block filter announced for the next numeric phase (0: none)
+  double unwritten_below = 0.0;    // the C of the last numeric phase lacks the blocks with ||blk||^2 below this (their norms are in norms64)
   int units_m = 0, units_cnt_m = 0, units_n = 0, units_cnt_n = 0;   // most frequent size of C's rows / columns in units of 4 (sizes up to 48) and how often (block_size_stats)
   int use_tiny = 1;                     // DBCSR_AMD_MM_TINY=0: no packed kernel for blocks of at most 4 x 4
   int use_small = 2;                    // DBCSR_AMD_MM_SMALL=0: no one-tile kernel for multiplies whose block dimensions are all <= 8 (mm_numeric_f64_small.h); 2 (default) / 3 / 4 / 6 / 8: products in flight per wave

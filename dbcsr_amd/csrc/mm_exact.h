@@ -110,7 +110,7 @@ __device__ __forceinline__ void cblock_f64_classes(const Desc& d, const Entry fi
                                                    const double* __restrict__ a_data,
                                                    const double* __restrict__ b_data, double* __restrict__ c_out,
                                                    const double* __restrict__ c_in, double alpha, double beta, const LaneMap& L, int lane,
-                                                   char* lds, double* __restrict__ norm_out) {
+                                                   char* lds, double* __restrict__ norm_out, double drop_below = 0.0) {
   typedef ClassShape<M, N, K0, K1, K2> CS;
   constexpr int MA = CS::MA, NC = CS::NC;
   constexpr int AP = Pitch<M>::P;
@@ -262,6 +262,26 @@ __device__ __forceinline__ void cblock_f64_classes(const Desc& d, const Entry fi
     if (!in_set(ep.ks())) block_product_f64<MA, NC, false>(acc, a_data + ep.a_off(), b_data + ep.b_off(), M, N, ep.ks(), L);
   }
 
+  const bool has_in = d.cin_off >= 0;
+  // the final block filter is known and the block is new (mm_numeric_f64.h: cblock_f64_exact): its norm from the accumulators; a block the filter will drop is
+  // neither staged nor written
+  if (norm_out && drop_below > 0.0 && !has_in) {
+    double s2 = 0.0;
+#pragma unroll
+    for (int a = 0; a < MA; ++a)
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const int row = 8 * a + L.rowd, col = 8 * c + L.coll;
+        const double v = alpha * acc[a][c];
+        if (row < M && col < N) s2 += v * v;
+      }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s2 += __shfl_down(s2, off, 64);
+    s2 = __shfl(s2, 0, 64);
+    if (lane == 0) *norm_out = s2;
+    if (s2 < drop_below) return;
+    norm_out = nullptr;   // (written)
+  }
   // C epilogue through LDS: the block leaves as stored, in whole 1 KiB pieces (16 B per lane), streaming hint
   constexpr int CC = (M * N * 8 + 1023) / 1024;
   double* lds_c = reinterpret_cast<double*>(lds);
@@ -272,7 +292,6 @@ __device__ __forceinline__ void cblock_f64_classes(const Desc& d, const Entry fi
       const int row = 8 * a + L.rowd, col = 8 * c + L.coll;
       if (row < M && col < N) lds_c[row + M * col] = alpha * acc[a][c];
     }
-  const bool has_in = d.cin_off >= 0;
   const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc((void*)(c_out + d.c_off), 0, M * N * 8, 0x00020000);
   typedef double f64x2 __attribute__((ext_vector_type(2)));
   double ss = 0.0;  // squared Frobenius norm of the stored block for the final filter of a filtered multiply: summed as the values leave
@@ -343,10 +362,11 @@ __device__ __forceinline__ void mm_class_kernel_body(const Desc* __restrict__ de
     d = descs[cb];
     cbi = cb;
   }
+  const double drop_below = norms ? norms[nblk] : 0.0;   // (the final filter's threshold when the host announced it: mm_numeric_f64.h)
   if (skip_empty && d.prod_cnt == 0) return;
   const LaneMap L(lane);
   cblock_f64_classes<M, N, K0, K1, K2>(d, first, have_first, entries, a_data, b_data, c_out, c_in, alpha, beta, L, lane,
-                                       smem + (size_t)wid * ClassShape<M, N, K0, K1, K2>::WAVE_LDS, norms ? norms + cbi : nullptr);
+                                       smem + (size_t)wid * ClassShape<M, N, K0, K1, K2>::WAVE_LDS, norms ? norms + cbi : nullptr, drop_below);
 }
 
 

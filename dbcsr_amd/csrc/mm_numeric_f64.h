@@ -194,7 +194,8 @@ template <int M, int N, int K, int VAR, class Hook = NoHook>
 __device__ __forceinline__ void cblock_f64_exact(const Desc& d, const Entry first, const Entry* __restrict__ entries, const double* __restrict__ a_data,
                                                  const double* __restrict__ b_data, double* __restrict__ c_out,
                                                  const double* __restrict__ c_in, double alpha, double beta, const LaneMap& L, int lane,
-                                                 char* lds_a, char* lds_b, int dbg_rt, double* __restrict__ norm_out, Hook before_epilogue = Hook()) {
+                                                 char* lds_a, char* lds_b, int dbg_rt, double* __restrict__ norm_out, Hook before_epilogue = Hook(),
+                                                 double drop_below = 0.0) {
   const int dbg = VAR == 1 ? dbg_rt : 0;
   constexpr int MA = (M + 7) / 8, NC = (N + 7) / 8, KS = (K + 3) / 4, K4 = 4 * KS;
   constexpr int CA = (M * K4 * 8 + 1023) / 1024, CB = (K * N * 8 + 1023) / 1024;
@@ -328,6 +329,26 @@ __device__ __forceinline__ void cblock_f64_exact(const Desc& d, const Entry firs
   if constexpr (VAR == 3 || VAR == 4) asm volatile("" ::"v"(touch));  // the keep-alive loads are loads the compiler must keep
   before_epilogue();
   const bool has_in = d.cin_off >= 0;
+  // A filtered multiply whose final block filter is known (dbcsr_amd_mm_expect_filter; drop_below = its eps^2): a NEW block (no C_in: the usual case of a sparse
+  // product) has its norm in the accumulators -- formed here, before anything touches LDS, and a block the filter is going to drop (||blk||^2 < eps^2: the double
+  // written to norm_out, the comparison of filter_flags) is neither staged nor written.  Nobody reads it.  (Blocks with C_in take the epilogue below as always.)
+  if (norm_out && drop_below > 0.0 && !has_in && !(dbg & 8)) {
+    double s2 = 0.0;
+#pragma unroll
+    for (int a = 0; a < MA; ++a)
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const int row = 8 * a + L.rowd, col = 8 * c + L.coll;
+        const double v = alpha * acc[a][c];
+        if (row < M && col < N) s2 += v * v;
+      }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s2 += __shfl_down(s2, off, 64);
+    s2 = __shfl(s2, 0, 64);
+    if (lane == 0) *norm_out = s2;
+    if (s2 < drop_below) return;
+    norm_out = nullptr;   // (written)
+  }
   if (dbg & 8) {  // scattered 8-byte stores straight from the accumulators (the first version; kept for comparison)
     double* C = c_out + d.c_off;
     const double* Ci = c_in + (has_in ? d.cin_off : 0);
@@ -424,6 +445,8 @@ __global__ void __launch_bounds__(256) mm_numeric_f64_hot(const Desc* __restrict
   // launch-order records (build_work): descriptor and first product in one read -- no order[] -> descs[] -> entries[] chain
   const Work w = work[pos];
   if (w.prod_cnt < 0) return;  // padding position
+  // norms[nblk]: the threshold of the final block filter when the host announced it (0: every block is written); asked for now, needed in the epilogue
+  const double drop_below = norms ? norms[nblk] : 0.0;
   const Desc d = {w.c_off, w.cin_off, w.prod_start, w.prod_cnt, w.m, w.n};
   Entry first;
   first.a_lo = w.a_lo, first.b_lo = w.b_lo, first.w = w.w;
@@ -438,7 +461,7 @@ __global__ void __launch_bounds__(256) mm_numeric_f64_hot(const Desc* __restrict
   const LaneMap L(lane);
   if (d.m == M && d.n == N) {
     cblock_f64_exact<M, N, K, VAR>(d, first, entries, a_data, b_data, c_out, c_in, alpha, beta, L, lane, lds_a, lds_b, dbg,
-                              norms ? norms + w.cb : nullptr);
+                              norms ? norms + w.cb : nullptr, NoHook(), drop_below);
     return;
   }
   // the few blocks of another size (tail block row / column): straight from global memory, as one 32 x 32 tile (they leave their norm too: no pass over

@@ -29,7 +29,7 @@ LIBSMM_SYMBOLS = [
 ]
 MM_SYMBOLS = [
     "dbcsr_amd_mm_create", "dbcsr_amd_mm_destroy", "dbcsr_amd_mm_symbolic", "dbcsr_amd_mm_numeric", "dbcsr_amd_bcsr_transpose",
-    "dbcsr_amd_bcsr_checksum", "dbcsr_amd_bcsr_fill_random", "dbcsr_amd_mm_kernel_name", "dbcsr_amd_mm_last_kernel", "dbcsr_amd_fabric_probe", "dbcsr_amd_mm_plan_stats", "dbcsr_amd_mm_trust_plan", "dbcsr_amd_mm_stats", "dbcsr_amd_mm_timing", "dbcsr_amd_mm_init_c", "dbcsr_amd_bcsr_fill_random_dist",
+    "dbcsr_amd_bcsr_checksum", "dbcsr_amd_bcsr_fill_random", "dbcsr_amd_mm_kernel_name", "dbcsr_amd_mm_last_kernel", "dbcsr_amd_fabric_probe", "dbcsr_amd_mm_plan_stats", "dbcsr_amd_mm_trust_plan", "dbcsr_amd_mm_expect_filter", "dbcsr_amd_mm_stats", "dbcsr_amd_mm_timing", "dbcsr_amd_mm_init_c", "dbcsr_amd_bcsr_fill_random_dist",
     "dbcsr_amd_mm_symbolic_filtered", "dbcsr_amd_bcsr_filter_count", "dbcsr_amd_bcsr_filter_apply",
     "dbcsr_amd_bcsr_crop_count", "dbcsr_amd_bcsr_crop_apply", "dbcsr_amd_bcsr_scale_window",
     "dbcsr_amd_multiply", "dbcsr_amd_bcsr_release", "dbcsr_amd_bcsr_desymmetrize_count", "dbcsr_amd_bcsr_desymmetrize_apply",
@@ -166,6 +166,8 @@ def load_library(lab=False):
     L.dbcsr_amd_fabric_probe.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.dbcsr_amd_mm_plan_stats.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
     L.dbcsr_amd_mm_trust_plan.argtypes = [vp, C.c_int]
+    L.dbcsr_amd_mm_expect_filter.argtypes = [vp, C.c_double]
+    L.dbcsr_amd_mm_expect_filter.restype = C.c_int
     if lab:   # diagnostics of the experimental dataflows (dbcsr_amd/csrc/mm_lab_api.h): the shipping build does not export them
         L.dbcsr_amd_mm_tile_stats.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
         L.dbcsr_amd_mm_band_stats.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]

@@ -472,6 +472,9 @@ class MultiplyEngine:
                           torch.empty(counts.c_nblks, dtype=torch.int64, device=dev),
                           torch.empty(counts.c_nze, dtype=A.dtype, device=dev), Cm.name)
         cout = out.desc(out=True)
+        if filter_eps and filter_eps > 0 and not retain_sparsity and os.environ.get("DBCSR_AMD_MM_EXPECT_FILTER", "1") != "0":
+            # the product goes straight into the block filter below with the same eps (dbcsr_mm_multrec.F:373-383): blocks it will drop need not be written
+            self.L.dbcsr_amd_mm_expect_filter(self.h, float(filter_eps))
         rc = self.L.dbcsr_amd_mm_numeric(self.h, A.dtype_code, float(alpha), C.byref(a), C.byref(b), float(beta), C.byref(cin),
                                          C.byref(cout), st.ptr)
         if rc != 0:

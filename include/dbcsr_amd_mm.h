@@ -222,6 +222,13 @@ const char* dbcsr_amd_smm_last_kernel(void);
    none: 0 is never trusted) and is compared on the device as always.  For callers that own these arrays (the panels of a distributed
    multiply, dbcsr_amd/cannon.py; the benchmark's operands). */
 int dbcsr_amd_mm_trust_plan(void* handle, int on);
+
+/* A filtered multiply (reference: src/mm/dbcsr_mm_multrec.F:373-383 -- the product of a multiply with filter_eps is filtered with the same eps before it is
+   finalized): announce the final block filter of the NEXT dbcsr_amd_mm_numeric of this handle.  Its product kernels form a block's squared norm before they write it
+   and leave a block with ||blk||^2 < eps^2 UNWRITTEN -- the block filter is going to drop it (same double, same comparison), nobody may read it before.  The C that
+   comes back is therefore only good for dbcsr_amd_bcsr_filter_count / _apply with an eps that is not smaller (a smaller one is refused: -3).  On products with many
+   dropped blocks the dropped share of C's write traffic is saved.  Without this call every block is written.  fp64; ignored for retain_sparsity and in-place accumulation. */
+int dbcsr_amd_mm_expect_filter(void* handle, double eps);
 int dbcsr_amd_mm_plan_stats(void* handle, int64_t* reused, int64_t* built);
 
 /* Measurement helper (bench.py, roofline.fabric): what the L2 <-> Infinity-Cache fabric of the current device delivers, in TB/s -- a

@@ -190,3 +190,54 @@ def test_kernel_families_at_scale_with_tails(monkeypatch, shape, counts, expect)
     out = dev_to_bcsr(dC)
     assert np.array_equal(out.row_p, ref.row_p) and np.array_equal(out.col_i, ref.col_i) and np.array_equal(out.blk_p, ref.blk_p)
     assert rel_err(out.data, ref.data) <= 1e-12
+
+
+def test_announced_filter_leaves_dropped_blocks_unwritten_and_refuses_a_smaller_eps(monkeypatch):
+    """dbcsr_amd_mm_expect_filter (include/dbcsr_amd_mm.h): the filtered product equals the one computed without the announcement and the oracle's; the C ABI refuses to
+    filter the unannounced-for way (a smaller eps) afterwards, because blocks below the announced threshold were never written."""
+    import ctypes as C
+    from dbcsr_amd import lib as _lib
+    for k in ENV + ("DBCSR_AMD_MM_EXPECT_FILTER",):
+        monkeypatch.delenv(k, raising=False)
+    case = (23 * 40 + 16, 23 * 38 + 9, 23 * 30 + 5, 0.8, 0.8, 0.97, [1, 23], [1, 23], [1, 23])   # sparse C_in: most C blocks are new
+    A, B, Cm = O.perf_case(*case)
+    eps = 200.0   # keeps 489 of 1093 blocks
+    ref, info = O.multiply("N", "N", 1.0, A, B, 1.0, Cm, filter_eps=eps)
+    full, _ = O.multiply("N", "N", 1.0, A, B, 1.0, Cm)
+    assert 0 < ref.nblks < 0.8 * full.nblks, (ref.nblks, full.nblks)
+    outs = []
+    for sw in (None, "0"):
+        if sw:
+            monkeypatch.setenv("DBCSR_AMD_MM_EXPECT_FILTER", sw)
+        eng = MultiplyEngine()
+        dA, dB, dC = to_dev(A), to_dev(B), to_dev(Cm)
+        dbcsr_multiply("N", "N", 1.0, dA, dB, 1.0, dC, filter_eps=eps, engine=eng)
+        torch.cuda.synchronize()
+        assert eng.last_kernel() == "mm_numeric_f64_hot<23,23,23>"
+        out = dev_to_bcsr(dC)
+        assert np.array_equal(out.row_p, ref.row_p) and np.array_equal(out.col_i, ref.col_i) and np.array_equal(out.blk_p, ref.blk_p)
+        assert rel_err(out.data, ref.data) <= 1e-10
+        outs.append(out)
+    assert np.array_equal(outs[0].data, outs[1].data)
+    # the C ABI: announce, multiply, then ask for a SMALLER filter than announced
+    monkeypatch.delenv("DBCSR_AMD_MM_EXPECT_FILTER", raising=False)
+    eng = MultiplyEngine()
+    dA, dB, dC = to_dev(A), to_dev(B), to_dev(Cm)
+    L = eng.L
+    from dbcsr_amd.matrix import StreamHandle
+    sth = StreamHandle(None)
+    st = sth.ptr
+    a, b, cin = dA.desc(), dB.desc(), dC.desc()
+    row_p = torch.empty(dC.nblkrows + 1, dtype=torch.int32, device="cuda")
+    counts = _lib.MmCounts()
+    assert L.dbcsr_amd_mm_symbolic_filtered(eng.h, dA.dtype_code, 1.0, eps, C.byref(a), C.byref(b), C.byref(cin), 0, row_p.data_ptr(), C.byref(counts), st) == 0
+    from dbcsr_amd.matrix import DbcsrMatrix
+    out = DbcsrMatrix(dC.row_blk_size, dC.col_blk_size, row_p, torch.empty(counts.c_nblks, dtype=torch.int32, device="cuda"),
+                      torch.empty(counts.c_nblks, dtype=torch.int64, device="cuda"), torch.empty(counts.c_nze, dtype=torch.float64, device="cuda"), "C")
+    cout = out.desc(out=True)
+    assert L.dbcsr_amd_mm_expect_filter(eng.h, eps) == 0
+    assert L.dbcsr_amd_mm_numeric(eng.h, dA.dtype_code, 1.0, C.byref(a), C.byref(b), 1.0, C.byref(cin), C.byref(cout), st) == 0
+    new_row_p = torch.empty(dC.nblkrows + 1, dtype=torch.int32, device="cuda")
+    nb, nz = C.c_int64(0), C.c_int64(0)
+    src = out.desc()
+    assert L.dbcsr_amd_bcsr_filter_count(eng.h, out.dtype_code, C.byref(src), 0.5 * eps, new_row_p.data_ptr(), C.byref(nb), C.byref(nz), st) == -3
