@@ -91,6 +91,11 @@ struct BigSub {
   // (a wave whose block is smaller than the variant's sub-block multiplied a few blocks nobody stores); zeroes the sums
   template <class F>
   __device__ __forceinline__ void drain(int lane, int own_r, int own_c, F f) {
+    visit<true>(lane, own_r, own_c, f);
+  }
+  // ZERO = false: the sums stay (a look at them before they are drained: the block's norm for an announced filter)
+  template <bool ZERO, class F>
+  __device__ __forceinline__ void visit(int lane, int own_r, int own_c, F f) {
     const int kq = lane >> 4, blk = (lane >> 2) & 3, x = lane & 3;
     const int p = blk >> 1, q = blk & 1;
     const int rlim = 4 * own_r, clim = 4 * own_c;
@@ -100,19 +105,19 @@ struct BigSub {
       for (int c = 0; c < PC; ++c) {
         const int r = 8 * a + 4 * p + kq, cc = 8 * c + 4 * q + x;
         if (r < rlim && cc < clim) f(r, cc, acc[a][c]);
-        acc[a][c] = 0.0;
+        if (ZERO) acc[a][c] = 0.0;
       }
 #pragma unroll
     for (int j = 0; j < NEB; ++j) {
       const int r = 4 * (RB - 1) + kq, cc = 16 * j + 4 * blk + x;
       if (4 * j + blk < CB && r < rlim && cc < clim) f(r, cc, accb[j]);
-      accb[j] = 0.0;
+      if (ZERO) accb[j] = 0.0;
     }
 #pragma unroll
     for (int j = 0; j < NER; ++j) {
       const int r = 16 * j + 4 * blk + kq, cc = 4 * (CB - 1) + x;
       if (4 * j + blk < RBE && r < rlim && cc < clim) f(r, cc, accr[j]);
-      accr[j] = 0.0;
+      if (ZERO) accr[j] = 0.0;
     }
   }
 };
@@ -263,6 +268,24 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) mm
       k0 = k2;
     }
     double ss = 0.0;
+    // the final block filter announced (norms[nblk] = its eps^2; mm_numeric_f64.h: cblock_f64_exact): a new block's norm from the accumulators, and a block the
+    // filter is going to drop is neither staged nor written
+    if (norms && d.cin_off < 0) {
+      const double drop_below = norms[nblk];
+      if (drop_below > 0.0) {
+        double s2 = 0.0;
+        S.template visit<false>(lane, own_r, own_c, [&](int row, int col, double sum) {
+          const double v = alpha * sum;
+          if (row < m && col < n) s2 += v * v;
+        });
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s2 += __shfl_down(s2, off, 64);
+        s2 = __shfl(s2, 0, 64);
+        if (lane == 0) norms[cb_index] = s2;
+        if (s2 < drop_below) return;
+        norms = nullptr;   // (written)
+      }
+    }
     if constexpr (RBX <= 8 && CBX <= 8) {
       // C epilogue through LDS (as the exact-size kernels, mm_numeric_f64.h): the block is laid out as stored (column-major, contiguous) in the wave's
       // slice -- up to 32 x 32: it fits the slabs' 9 KB -- and leaves in whole 1 KiB pieces, 16 bytes per lane, with the streaming hint.  These shapes
