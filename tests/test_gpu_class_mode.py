@@ -241,3 +241,30 @@ def test_announced_filter_leaves_dropped_blocks_unwritten_and_refuses_a_smaller_
     nb, nz = C.c_int64(0), C.c_int64(0)
     src = out.desc()
     assert L.dbcsr_amd_bcsr_filter_count(eng.h, out.dtype_code, C.byref(src), 0.5 * eps, new_row_p.data_ptr(), C.byref(nb), C.byref(nz), st) == -3
+
+
+# The announced final filter at scale: tens to hundreds of thousands of C blocks, a third to two thirds of them dropped (and therefore never written), index bit-exact
+# and values 1e-10 against the oracle's filtered product
+@pytest.mark.parametrize("shape,counts,sp,eps,expect", [
+    ((23, 23, 23), (330, 320, 50), (0.8, 0.8, 0.97), 200.0, "mm_numeric_f64_hot<23,23,23>"),
+    ((9, 32, 13), (470, 450, 60), (0.75, 0.75, 0.97), 200.0, "mm_numeric_f64_class["),
+    ((36, 36, 36), (200, 190, 30), (0.7, 0.7, 0.97), 800.0, "mm_numeric_f64_mid<9,9>"),
+], ids=["hot23", "class9x32", "mid36"])
+def test_announced_filter_at_scale(monkeypatch, shape, counts, sp, eps, expect):
+    for k in ENV + ("DBCSR_AMD_MM_EXPECT_FILTER",):
+        monkeypatch.delenv(k, raising=False)
+    m, n, k = shape
+    nbr, nbc, nbk = counts
+    tail = lambda s, salt: 1 + (s * 7 + salt) % (s - 1)
+    A, B, Cm = O.perf_case(m * nbr + tail(m, 1), n * nbc + tail(n, 2), k * nbk + tail(k, 3), *sp, [1, m], [1, n], [1, k])
+    ref, info = O.multiply("N", "N", 1.0, A, B, 1.0, Cm, filter_eps=eps)
+    eng = MultiplyEngine()
+    dA, dB, dC = to_dev(A), to_dev(B), to_dev(Cm)
+    flop = [0]
+    dbcsr_multiply("N", "N", 1.0, dA, dB, 1.0, dC, filter_eps=eps, flop=flop, engine=eng)
+    torch.cuda.synchronize()
+    assert eng.last_kernel().startswith(expect), (eng.last_kernel(), expect)
+    assert flop[0] == info["flop"]
+    out = dev_to_bcsr(dC)
+    assert np.array_equal(out.row_p, ref.row_p) and np.array_equal(out.col_i, ref.col_i) and np.array_equal(out.blk_p, ref.blk_p)
+    assert rel_err(out.data, ref.data) <= 1e-10
