@@ -453,10 +453,11 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
     ACC_CHECK(hipMemsetAsync(E->tmp_i32.p, 0, sizeof(int) * (size_t)nblk, st));
     hipLaunchKernelGGL(fill_products_rows, grid_for((int64_t)nbr * 64), dim3(256), 0, st, a->row_p, a->col_i, a->blk_p, a->col_blk_size, b->row_p,
                        b->col_i, b->blk_p, E->c_bm.p, E->c_pre.p, c_out->row_p, E->prod_start.p, nbr, W, E->tmp_i32.p, E->entries.p, E->filter);
-    hipLaunchKernelGGL(finish_descs_rows, grid_for((int64_t)nbr * W), dim3(256), 0, st, c_in->row_p, c_in->blk_p, c_out->row_blk_size,
+    const int nJr = (b->nblkcols + 63) / 64;
+    hipLaunchKernelGGL(finish_descs_grid, grid_for((int64_t)nbr * nJr * 64), dim3(256), 0, st, c_in->row_p, c_in->blk_p, c_out->row_blk_size,
                        c_out->col_blk_size, E->have_cin ? E->cin_bm.p : (const uint32_t*)nullptr,
                        E->have_cin ? E->cin_pre.p : (const int*)nullptr, E->c_bm.p, E->c_pre.p, c_out->row_p, E->c_blk_p_ws.p, E->prod_start.p,
-                       E->prod_cnt.p, nbr, W, c_out->col_i, c_out->blk_p, E->descs.p);
+                       E->prod_cnt.p, nbr, W, nJr, c_out->col_i, c_out->blk_p, E->descs.p);
   } else if (E->grid_kernels) {
     const int nbc = b->nblkcols, nJ = (nbc + 63) / 64;
     hipLaunchKernelGGL(fill_products_grid, grid_for((int64_t)nbr * nJ * 64), dim3(256), 0, st, a->row_p, a->col_i, a->blk_p, b->row_p,

@@ -512,6 +512,42 @@ finish_descs_rows(const int* __restrict__ cin_row_p, const int64_t* __restrict__
   }
 }
 
+// The same, one LANE per (row, column) candidate (a wave covers 64 consecutive columns of a row): the blocks of a wave are consecutive in C's index, so the
+// descriptors, column indices and offsets leave in whole cache lines -- finish_descs_rows gives a thread 32 candidates and its neighbours write 14 descriptors apart
+// (config 4's shape, 14.3 M C blocks: 0.99 ms; round 6, session r06_60).
+__global__ void __launch_bounds__(256)
+finish_descs_grid(const int* __restrict__ cin_row_p, const int64_t* __restrict__ cin_blk_p, const int* __restrict__ rs,
+                  const int* __restrict__ cs, const uint32_t* __restrict__ cin_bm, const int* __restrict__ cin_pre,
+                  const uint32_t* __restrict__ c_bm, const int* __restrict__ c_pre, const int* __restrict__ c_row_p,
+                  const int64_t* __restrict__ c_blk_p_ws, const int64_t* __restrict__ prod_start, const int* __restrict__ prod_cnt, int nbr,
+                  int W, int nJ, int* __restrict__ c_col_i, int64_t* __restrict__ c_blk_p, Desc* __restrict__ descs) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wv = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (wv >= (int64_t)nbr * nJ) return;
+  const int i = (int)(wv / nJ), jb = (int)(wv % nJ);
+  const int j = jb * 64 + lane, w = j >> 5, bit = j & 31;
+  if (w >= W) return;
+  const size_t t = (size_t)i * W + w;
+  const uint32_t cw = c_bm[t];
+  if (!((cw >> bit) & 1u)) return;
+  const uint32_t below = (1u << bit) - 1u;
+  const int cb = c_row_p[i] + c_pre[t] + __popc(cw & below);
+  Desc d;
+  d.c_off = c_blk_p_ws[cb];
+  d.cin_off = -1;
+  if (cin_bm) {
+    const uint32_t cinw = cin_bm[t];
+    if ((cinw >> bit) & 1u) d.cin_off = cin_blk_p[cin_row_p[i] + cin_pre[t] + __popc(cinw & below)];
+  }
+  d.prod_start = prod_start[cb];
+  d.prod_cnt = prod_cnt[cb];
+  d.m = (int16_t)rs[i];
+  d.n = (int16_t)cs[j];
+  descs[cb] = d;
+  c_col_i[cb] = j;
+  c_blk_p[cb] = d.c_off;
+}
+
 // ---- C structure only (multi-tick / Cannon use): emit the sorted index of the pattern
 // computed by the symbolic phase and describe where each block's initial value comes from.
 __global__ void __launch_bounds__(256)
