@@ -156,6 +156,7 @@ int dbcsr_amd_mm_symbolic_filtered(void* handle, libsmm_acc_data_t datatype, dou
                                    dbcsr_amd_mm_counts* counts, void* stream) {
   Engine* E = static_cast<Engine*>(handle);
   if (!E || !a || !b || !c_in || !c_out_row_p || !counts) return -1;
+  E->drop_pending = 0.0;   // (an announced final filter belongs to ONE numeric phase: a new symbolic phase cancels whatever an abandoned multiply left)
   const bool filtering = filter_eps > 0.0;
   if (filtering && datatype != dbcsr_type_real_8 && datatype != dbcsr_type_real_4) return -10;
   if (a->nblkcols != b->nblkrows || a->nblkrows != c_in->nblkrows || b->nblkcols != c_in->nblkcols) {

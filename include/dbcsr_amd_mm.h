@@ -227,7 +227,8 @@ int dbcsr_amd_mm_trust_plan(void* handle, int on);
    finalized): announce the final block filter of the NEXT dbcsr_amd_mm_numeric of this handle.  Its product kernels form a block's squared norm before they write it
    and leave a block with ||blk||^2 < eps^2 UNWRITTEN -- the block filter is going to drop it (same double, same comparison), nobody may read it before.  The C that
    comes back is therefore only good for dbcsr_amd_bcsr_filter_count / _apply with an eps that is not smaller (a smaller one is refused: -3).  On products with many
-   dropped blocks the dropped share of C's write traffic is saved.  Without this call every block is written.  fp64; ignored for retain_sparsity and in-place accumulation. */
+   dropped blocks the dropped share of C's write traffic is saved.  Without this call every block is written.  Call it AFTER the symbolic phase of the
+   multiply it is meant for (a symbolic phase cancels an announcement that was never consumed).  fp64; ignored for retain_sparsity and in-place accumulation. */
 int dbcsr_amd_mm_expect_filter(void* handle, double eps);
 int dbcsr_amd_mm_plan_stats(void* handle, int64_t* reused, int64_t* built);
 
