@@ -566,7 +566,11 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
         hipLaunchKernelGGL(tiny, dim3(nwg_t), dim3(256), 0, st, E->descs.p, nblk, E->entries.p, ad, bd, cd, cid, alpha, beta, skip_empty, E->order.p);
       }
     } else if (small8) {
-      const unsigned nwg_s = (unsigned)(8 * E->order_len / 4);
+      // C blocks per wave (DBCSR_AMD_MM_SMALL_G; 0 = by the list length): with one or two products per C block a wave lives for a microsecond and the launch is
+      // bound by the rate at which waves start (5 x 5 blocks at 1 % fill, 14 M C blocks: 4.96 ms with one block per wave, 4.2 with eight); with fourteen it is not
+      const int sg = E->small_group > 0 ? E->small_group : (E->nproducts < 4 * nblk ? 8 : 1);
+      const int64_t npos_s = 8 * E->order_len;
+      const unsigned nwg_s = (unsigned)((npos_s + 4 * (int64_t)sg - 1) / (4 * (int64_t)sg));
       const int depth = E->use_small == 3 || E->use_small == 4 || E->use_small == 6 || E->use_small == 8 ? E->use_small : 2;
       snprintf(E->last_kernel, sizeof E->last_kernel, "mm_numeric_f64_small<%d>", depth);
       if (nwg_s > 0) {
@@ -576,7 +580,7 @@ int dbcsr_amd_mm_numeric(void* handle, libsmm_acc_data_t datatype, double alpha,
                                 depth == 6 ? mm_numeric_f64_small<6, false> : mm_numeric_f64_small<8, false>);
         hipLaunchKernelGGL(kern, dim3(nwg_s), dim3(256), 0, st, E->descs.p, nblk, E->entries.p, static_cast<const double*>(a->data),
                            static_cast<const double*>(b->data), static_cast<double*>(c_out->data), static_cast<const double*>(c_in->data), alpha, beta,
-                           skip_empty, E->order.p, hot_work);
+                           skip_empty, E->order.p, hot_work, sg, npos_s);
       }
     } else if (mid_rb && launch_mid_f64(mid_rb, mid_cb, E->min_m != E->max_m || E->min_n != E->max_n, (unsigned)(8 * E->order_len), st, E->descs.p, nblk,
                                          E->entries.p, static_cast<const double*>(a->data), static_cast<const double*>(b->data),

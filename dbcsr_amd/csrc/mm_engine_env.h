@@ -23,6 +23,7 @@ static void engine_read_env(Engine* E) {
   if (const char* k = getenv("DBCSR_AMD_MM_HOT")) E->use_hot = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_TINY")) E->use_tiny = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_SMALL")) E->use_small = atoi(k);
+  if (const char* k = getenv("DBCSR_AMD_MM_SMALL_G")) E->small_group = std::min(64, std::max(0, atoi(k)));
   if (const char* k = getenv("DBCSR_AMD_MM_F32_DIRECT")) E->f32_direct = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_BIG")) E->use_big = atoi(k);
   if (const char* k = getenv("DBCSR_AMD_MM_MID")) E->use_mid = atoi(k);

@@ -72,6 +72,7 @@ struct Engine {
   double unwritten_below = 0.0;    // the C of the last numeric phase lacks the blocks with ||blk||^2 below this (their norms are in norms64)
   int units_m = 0, units_cnt_m = 0, units_n = 0, units_cnt_n = 0;   // most frequent size of C's rows / columns in units of 4 (sizes up to 48) and how often (block_size_stats)
   int use_tiny = 1;                     // DBCSR_AMD_MM_TINY=0: no packed kernel for blocks of at most 4 x 4
+  int small_group = 0;                  // DBCSR_AMD_MM_SMALL_G: C blocks a wave of the small-block kernel takes one after the other (0: eight when the lists are short, else one)
   int use_small = 2;                    // DBCSR_AMD_MM_SMALL=0: no one-tile kernel for multiplies whose block dimensions are all <= 8 (mm_numeric_f64_small.h); 2 (default) / 3 / 4 / 6 / 8: products in flight per wave
   int use_hot = 1;                      // DBCSR_AMD_MM_HOT=0: never use the exact-size kernels
   int lds_pad = 0;                      // DBCSR_AMD_MM_LDS_PAD: extra LDS bytes per workgroup (occupancy experiments)

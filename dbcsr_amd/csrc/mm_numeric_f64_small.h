@@ -22,16 +22,12 @@ namespace dbcsr_amd {
 
 typedef unsigned int u32x2_small __attribute__((ext_vector_type(2)));
 
+// one C block (position `pos` of the launch order) by one wave; la: the wave's 1 KiB of LDS
 template <int D, bool WORK>
-__global__ void __launch_bounds__(256) mm_numeric_f64_small(const Desc* __restrict__ descs, int64_t nblk, const Entry* __restrict__ entries,
-                                                            const double* __restrict__ a_data, const double* __restrict__ b_data,
-                                                            double* __restrict__ c_out, const double* __restrict__ c_in, double alpha, double beta,
-                                                            int skip_empty, const int* __restrict__ order, const Work* __restrict__ work) {
-  __shared__ double smem[4][128];
-  const int lane = threadIdx.x & 63;
-  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int64_t pos = (int64_t)wg * 4 + wid;  // gridDim.x * 4 == padded length of order[]
+__device__ __forceinline__ void small_block(int64_t pos, int lane, double* la, const Desc* __restrict__ descs, int64_t nblk, const Entry* __restrict__ entries,
+                                            const double* __restrict__ a_data, const double* __restrict__ b_data, double* __restrict__ c_out,
+                                            const double* __restrict__ c_in, double alpha, double beta, int skip_empty, const int* __restrict__ order,
+                                            const Work* __restrict__ work) {
   Desc d;
   Entry first = Entry::make(0, 0, 0);
   if constexpr (WORK) {
@@ -58,7 +54,6 @@ __global__ void __launch_bounds__(256) mm_numeric_f64_small(const Desc* __restri
   if (skip_empty && cnt == 0) return;  // in-place accumulation (beta = 1): untouched blocks stay as they are
   const int m = d.m, n = d.n;
   const LaneMap L(lane);
-  double* la = smem[wid];
   double* lb = la + 64;
   const int a_i0 = L.rowl + m * L.kq, a_i1 = a_i0 + 4 * m;  // <= 7 + 8 * 7: inside the image whatever m is (rows past m feed rows of C nobody stores)
   const int voff = lane * 8;
@@ -130,6 +125,29 @@ __global__ void __launch_bounds__(256) mm_numeric_f64_small(const Desc* __restri
   if (cnt > 0) batch(0, IntC<1>{});
   for (int base = NB; base < cnt; base += NB) batch(base, IntC<0>{});
   if (mine) c_out[d.c_off + L.rowd + m * L.coll] = alpha * acc + (d.cin_off >= 0 ? beta * cin : 0.0);
+}
+
+// A wave takes G consecutive positions of the launch order, one after the other.  With SHORT product lists (one or two products per C block: a sparse product)
+// a wave lives for about a microsecond and the launch is bound by the rate at which waves start: 5 x 5 blocks at 1 % fill (14 M C blocks) 4.96 ms with G = 1,
+// 4.2 with G = 8 ... 16; with fourteen products per C block G makes no difference (2.21 ms either way): the host passes 8 or 1 (session r06_63).
+// (Counters of the final form at fourteen products per block, session r06_62: LDS 0.46, scalar unit 0.31, VALU 0.18 busy -- no pipe is the bound, the dependent
+//  chain of a product is: wait for the operands, LDS write, LDS read, two dependent MFMAs.)
+template <int D, bool WORK>
+__global__ void __launch_bounds__(256) mm_numeric_f64_small(const Desc* __restrict__ descs, int64_t nblk, const Entry* __restrict__ entries,
+                                                            const double* __restrict__ a_data, const double* __restrict__ b_data,
+                                                            double* __restrict__ c_out, const double* __restrict__ c_in, double alpha, double beta,
+                                                            int skip_empty, const int* __restrict__ order, const Work* __restrict__ work, int G,
+                                                            int64_t npos) {
+  __shared__ double smem[4][128];
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int64_t pos0 = ((int64_t)wg * 4 + wid) * G;
+  for (int g = 0; g < G; ++g) {
+    const int64_t pos = pos0 + g;
+    if (pos >= npos) break;
+    small_block<D, WORK>(pos, lane, smem[wid], descs, nblk, entries, a_data, b_data, c_out, c_in, alpha, beta, skip_empty, order, work);
+  }
 }
 
 }  // namespace dbcsr_amd
